@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X-native LIBXSMM engine.
+
+Workload (BASELINE.json configs[1]): batched dense SMM, fp32, M=N=K=32, batch 1,048,576 per GPU, alpha=1, beta=1,
+three contiguous operand arrays resident in HBM (the layout of samples/smm/specialized.cpp:143-146, streamed case).
+One "step" = one pass of the hot path over the whole batch: a single call of the C-ABI entry point
+libxsmm_amd_gemm_batch_strided (same kernel family as libxsmm_gemm_batch; --mode index goes through
+libxsmm_gemm_batch with device index arrays).
+
+Output: ONE JSON line (rank 0) with the driver's contract fields plus
+  roofline     -- dominant kernel's algorithmic bytes per launch / HIP-event launch time vs 8 TB/s HBM peak
+  cpu_baseline -- the CPU oracle (a port of the reference arithmetic, NOT the product) timed on host cores, N=1 only
+  secondary    -- spmdm CSR compute phase (BASELINE config 4 shape) and fsspmdm (config 3) rates on this GPU.
+Multi-GPU: one process per GPU (torch.distributed over RCCL); the batch axis shards with no data-path collective
+("weak" scaling: fixed per-GPU batch). value = work of all ranks / max-over-ranks time.
+"""
+import argparse
+import ctypes as C
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=1048576, help="items per GPU")
+    ap.add_argument("--mfma", type=int, default=1, help="1: MFMA kernels where shapes allow, 0: scalar-FMA kernels only")
+    ap.add_argument("--mode", default="strided", choices=["strided", "index"])
+    ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--cpu-items", type=int, default=131072, help="bounded CPU-baseline sample (items)")
+    return ap.parse_args()
+
+
+def time_steps(torch, fn, steps, warmup, dist):
+    """W untimed steps, then exactly K steps bracketed by barrier + synchronize; returns (wall seconds, per-step ms list)"""
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    t0 = time.perf_counter()
+    for (e0, e1) in evs:
+        e0.record()
+        fn()
+        e1.record()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    return t1 - t0, [e0.elapsed_time(e1) for (e0, e1) in evs]
+
+
+def main():
+    args = parse()
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist_mod.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        dist = dist_mod
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU compute path")
+    torch.cuda.set_device(local)
+    xs = importlib.import_module("libxsmm-1_amd")
+    L = xs.lib()
+    if L.libxsmm_amd_device_count() < 1:
+        raise SystemExit("libxsmm.so sees no HIP device")
+    L.libxsmm_amd_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream))  # events and kernels on one stream
+    L.libxsmm_amd_set_mfma(args.mfma)
+
+    M = N = K = 32
+    B = args.batch
+    # synthetic data of the configured shape: uniform [-0.5, 0.5) (random data: zero/trivial operands flatter the clock)
+    g = torch.Generator(device="cuda"); g.manual_seed(1 + rank)
+    a = torch.rand(B * M * K, device="cuda", dtype=torch.float32, generator=g) - 0.5
+    b = torch.rand(B * K * N, device="cuda", dtype=torch.float32, generator=g) - 0.5
+    c = torch.rand(B * M * N, device="cuda", dtype=torch.float32, generator=g) - 0.5
+    blob, desc = xs.descriptor(xs.F32, M, N, K, M, K, M, 1.0, 1.0)
+    assert desc, "descriptor rejected"
+    if args.mode == "index":
+        ia = (torch.arange(B, device="cuda", dtype=torch.int32) * (M * K)).contiguous()
+        ib = (torch.arange(B, device="cuda", dtype=torch.int32) * (K * N)).contiguous()
+        ic = (torch.arange(B, device="cuda", dtype=torch.int32) * (M * N)).contiguous()
+
+        def step():  # negative batchsize: no two items share a C (reference src/libxsmm_gemm.c:1338)
+            xs.gemm_batch(xs.F32, "N", "N", M, N, K, 1.0, a, M, b, K, 1.0, c, M, 0, 4, ia, ib, ic, -B)
+    else:
+        pa, pb, pc = xs.dptr(a), xs.dptr(b), xs.dptr(c)
+
+        def step():
+            rc = L.libxsmm_amd_gemm_batch_strided(desc, pa, pb, pc, M * K, K * N, M * N, B)
+            assert rc == 0
+
+    wall, per_step = time_steps(torch, step, args.steps, args.warmup, dist)
+    kernel_name = xs.last_kernel()
+    wall_t = torch.tensor([wall], device="cuda", dtype=torch.float64)
+    if dist is not None:
+        dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
+    wall_max = float(wall_t.item())
+    ms_per_step = 1e3 * wall_max / args.steps
+    flops_item = 2.0 * M * N * K
+    bytes_item = 4.0 * (M * K + K * N + 2 * M * N)  # A + B + C read + C write = 16384 B (specialized.cpp:91-92)
+    total_items = float(B) * world
+    gflops = total_items * flops_item / (wall_max / args.steps) / 1e9
+
+    out = {
+        "metric": "batched SMM fp32 32x32x32 GFLOP/s (whole job)", "value": round(gflops, 1), "unit": "GFLOP/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "configs[1]: batched dense SMM fp32 M=N=K=32 alpha=1 beta=1, batch=%d per GPU, %s addressing, MFMA %s"
+                   % (B, args.mode, "on" if args.mfma else "off"), "batch_per_gpu": B, "parallelism": "batch-shard x%d" % world},
+        "hbm_gbs_per_gpu": round(float(B) * bytes_item / (wall_max / args.steps) / 1e9, 1),
+        "gflops_per_gpu": round(gflops / world, 1),
+    }
+    if rank == 0:
+        import statistics
+        kms = statistics.mean(per_step)  # HIP events on the launch stream around each launch (one kernel per step)
+        achieved = float(B) * bytes_item / (kms * 1e-3) / 1e9
+        out["roofline"] = {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                           "launch_ms_avg": round(kms, 4), "launch_ms_min": round(min(per_step), 4),
+                           "algorithmic_bytes_per_launch": float(B) * bytes_item}
+    if rank == 0 and world == 1 and not args.no_secondary:
+        try:
+            out["secondary"] = secondary(torch, xs, L)
+        except Exception as exc:  # secondary numbers must never take the headline down
+            out["secondary"] = {"error": repr(exc)}
+    if rank == 0 and world == 1 and not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline(M, N, K, args.cpu_items)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+def secondary(torch, xs, L):
+    """Other BASELINE configs on one GPU (reported, not the headline): spmdm compute phase and fsspmdm."""
+    res = {}
+    # config 4 shape: spmdm fp32 M=K=64 N=48, 50% zeros, beta=0
+    M, N, K, B = 64, 48, 64, 131072
+    g = torch.Generator(device="cuda"); g.manual_seed(1)
+    a = torch.rand(B * M * K, device="cuda", generator=g) - 0.5
+    a = torch.where(torch.rand(B * M * K, device="cuda", generator=g) >= 0.5, a, torch.zeros_like(a))
+    b = torch.rand(B * K * N, device="cuda", generator=g) - 0.5
+    c = torch.zeros(B * M * N, device="cuda")
+    sb = L.libxsmm_amd_spmdm_batch_create(M, N, K, B)
+    assert sb
+    beta = C.c_float(0.0)
+
+    def create():
+        assert 0 == L.libxsmm_amd_spmdm_batch_create_slices(sb, b"N", xs.dptr(a))
+
+    def compute():
+        assert 0 == L.libxsmm_amd_spmdm_batch_compute(sb, b"N", xs.dptr(b), b"N", C.byref(beta), xs.dptr(c))
+    _, t_create = time_steps(torch, create, 5, 2, None)
+    k_create = xs.last_kernel()
+    _, t_comp = time_steps(torch, compute, 5, 2, None)
+    k_comp = xs.last_kernel()
+    nnz = float((a != 0).sum().item()) / B
+    by_create = 4.0 * M * K + 6.0 * nnz + 2.0 * (M + 1)
+    by_comp = 6.0 * nnz + 2.0 * (M + 1) + 4.0 * K * N + 4.0 * M * N
+    mc, mp = min(t_create) * 1e-3, min(t_comp) * 1e-3
+    res["spmdm_f32_64x48x64_nnz50"] = {
+        "batch": B, "nnz_per_item": round(nnz, 1),
+        "create": {"kernel": k_create, "ms": round(mc * 1e3, 4), "hbm_gbs": round(B * by_create / mc / 1e9, 1), "frac": round(B * by_create / mc / 1e9 / HBM_PEAK_GBS, 4)},
+        "compute": {"kernel": k_comp, "ms": round(mp * 1e3, 4), "hbm_gbs": round(B * by_comp / mp / 1e9, 1), "frac": round(B * by_comp / mp / 1e9 / HBM_PEAK_GBS, 4),
+                    "gflops": round(B * 2.0 * nnz * N / mp / 1e9, 1)}}
+    L.libxsmm_amd_spmdm_batch_destroy(sb)
+    del a, b, c
+    # config 3 shape: fsspmdm fp64 M=K=35, ~15% nnz, N=96 per item
+    import numpy as np
+    M, K, N, B = 35, 35, 96, 65536
+    rng = np.random.default_rng(1)
+    palette = np.array([0.25, -0.5, 0.75, 1.0, -1.25, 1.5, -2.0])
+    A = np.where(rng.random((M, K)) < 0.15, palette[rng.integers(0, 7, (M, K))], 0.0)
+    ntot = N * B
+    Bm = torch.rand(K * ntot, device="cuda", dtype=torch.float64, generator=g) - 0.5
+    Cm = torch.zeros(M * ntot, device="cuda", dtype=torch.float64)
+    h = L.libxsmm_dfsspmdm_create(M, N, K, K, ntot, ntot, 1.0, 1.0, xs.dptr(np.ascontiguousarray(A)))
+    assert h
+
+    def run():
+        assert 0 == L.libxsmm_amd_dfsspmdm_execute_batch(h, xs.dptr(Bm), xs.dptr(Cm), B)
+    _, t = time_steps(torch, run, 5, 2, None)
+    mt = min(t) * 1e-3
+    by = 8.0 * N * (K + 2 * M)  # beta=1: B read + C read + C write = 80640 B per item
+    res["fsspmdm_f64_35x96x35_nnz15"] = {"batch": B, "nnz": int((A != 0).sum()), "kernel": xs.last_kernel(), "ms": round(mt * 1e3, 4),
+                                         "hbm_gbs": round(B * by / mt / 1e9, 1), "frac": round(B * by / mt / 1e9 / HBM_PEAK_GBS, 4)}
+    L.libxsmm_dfsspmdm_destroy(h)
+    return res
+
+
+def cpu_baseline(M, N, K, items):
+    """The oracle (a plain-C port of the reference's AVX2-path arithmetic, OpenMP over the batch) on the host cores."""
+    import numpy as np
+    import oracle_binding as orc
+    try:
+        cores = len(os.sched_getaffinity(0))  # the box grants a CPU share, not the whole host
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, int(os.environ.get("XSMM_BENCH_CPU_THREADS", "16"))))
+    rng = np.random.default_rng(1)
+    a = rng.random(items * M * K, dtype=np.float32) - 0.5
+    b = rng.random(items * K * N, dtype=np.float32) - 0.5
+    c = rng.random(items * M * N, dtype=np.float32) - 0.5
+    orc.gemm_batch_strided(orc.FMA, 0, M, N, K, M, K, M, a, b, c, M * K, K * N, M * N, min(items, 4096), cores)  # warm-up
+    reps, t_total = 0, 0.0
+    while t_total < 10.0 and reps < 200:
+        t0 = time.perf_counter()
+        orc.gemm_batch_strided(orc.FMA, 0, M, N, K, M, K, M, a, b, c, M * K, K * N, M * N, items, cores)
+        t_total += time.perf_counter() - t0
+        reps += 1
+    gf = reps * items * 2.0 * M * N * K / t_total / 1e9
+    return {"value": round(gf, 2), "unit": "GFLOP/s", "cores": cores, "kind": "port",
+            "sample": "%d items of the same fp32 32x32x32 beta=1 workload x %d passes (%.1f s), OpenMP static over the batch"
+                      % (items, reps, t_total)}
+
+
+if __name__ == "__main__":
+    main()

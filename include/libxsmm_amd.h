@@ -1,0 +1,77 @@
+/*
+ * libxsmm_amd.h -- engine-specific additions to the LIBXSMM C-ABI (no counterpart in the reference).
+ *
+ * The reference is a CPU library: a kernel call returns when C is written. On MI355X the operands
+ * normally live in HBM and a call only enqueues work on a HIP stream. These entry points expose that
+ * model (stream, synchronisation, device allocation) plus batch forms for the paths whose reference
+ * API processes one problem per call (spmdm, fsspmdm) -- the batch axis is what fills 256 CUs.
+ */
+#ifndef LIBXSMM_AMD_H
+#define LIBXSMM_AMD_H
+
+#if !defined(LIBXSMM_H)
+# include "libxsmm.h"
+#endif
+
+/* ---- device / stream ------------------------------------------------------------------------ */
+/** Number of usable HIP devices (0: none; every compute entry point then fails loudly). */
+LIBXSMM_API int libxsmm_amd_device_count(void);
+/** HIP stream (hipStream_t) on which device-resident work is enqueued; NULL selects the default stream. */
+LIBXSMM_API void libxsmm_amd_set_stream(void* hip_stream);
+LIBXSMM_API void* libxsmm_amd_get_stream(void);
+/** Block until all work enqueued by this library on its stream has completed. Returns EXIT_SUCCESS/FAILURE. */
+LIBXSMM_API int libxsmm_amd_synchronize(void);
+/** Device memory (hipMalloc/hipFree) -- what libxsmm_malloc returns when a device is present is host-pinned
+ *  memory (usable by unchanged callers); these return HBM. */
+LIBXSMM_API void* libxsmm_amd_device_malloc(size_t size);
+LIBXSMM_API void libxsmm_amd_device_free(void* ptr);
+LIBXSMM_API int libxsmm_amd_memcpy_h2d(void* dst_device, const void* src_host, size_t size);
+LIBXSMM_API int libxsmm_amd_memcpy_d2h(void* dst_host, const void* src_device, size_t size);
+/** 1 if ptr is device-accessible memory (hipMalloc, managed, or pinned host), else 0. */
+LIBXSMM_API int libxsmm_amd_is_device_pointer(const void* ptr);
+
+/* ---- kernel selection ----------------------------------------------------------------------- */
+/** MFMA policy for dense SMM: 0 = scalar-FMA kernels only (bit-identical to a k-ordered fma chain),
+ *  1 = use v_mfma_* where the shape maps onto matrix-core tiles (default; env LIBXSMM_AMD_MFMA).
+ *  Returns the previous value. */
+LIBXSMM_API int libxsmm_amd_set_mfma(int mode);
+LIBXSMM_API int libxsmm_amd_get_mfma(void);
+/** Name of the device kernel variant chosen for the most recent launch of the calling thread
+ *  (e.g. "smm_f32_32x32x32_mfma"); "" if nothing was launched. Used by the tests to prove that the
+ *  native path ran. */
+LIBXSMM_API const char* libxsmm_amd_last_kernel(void);
+/** Number of device kernel launches issued by this process (monotonic). */
+LIBXSMM_API unsigned long long libxsmm_amd_launch_count(void);
+
+/* ---- batch forms ---------------------------------------------------------------------------- */
+/** Constant-stride batch: item i uses a + i*stride_a, b + i*stride_b, c + i*stride_c (strides in elements,
+ *  0 = operand shared). This is the layout of samples/smm/specialized.cpp:143-146,172-190 (contiguous
+ *  A[s][m*k], B[s][k*n], C[s][m*n]) without materialising index arrays. Device-resident operands only.
+ *  Returns EXIT_SUCCESS, or EXIT_FAILURE if the descriptor is not supported / no device. */
+LIBXSMM_API int libxsmm_amd_gemm_batch_strided(const libxsmm_gemm_descriptor* descriptor,
+  const void* a, const void* b, void* c, long long stride_a, long long stride_b, long long stride_c,
+  long long batchsize);
+
+/** Batched spmdm: `batch` independent problems of the handle's geometry (M,N,K), operands back to back
+ *  (A: M*K, B: K*N, C: M*N elements per item, layouts/transposes as libxsmm_spmdm_*_thread).
+ *  The CSR scratch lives in HBM and is owned by the returned object. */
+typedef struct libxsmm_amd_spmdm_batch libxsmm_amd_spmdm_batch;
+LIBXSMM_API libxsmm_amd_spmdm_batch* libxsmm_amd_spmdm_batch_create(int M, int N, int K, long long batch);
+LIBXSMM_API void libxsmm_amd_spmdm_batch_destroy(libxsmm_amd_spmdm_batch* sb);
+/** dense A (device) -> per-item CSR slices (uint16 column indexes, identical content/order to
+ *  libxsmm_spmdm_createSparseSlice_fp32_thread on every item). */
+LIBXSMM_API int libxsmm_amd_spmdm_batch_create_slices(libxsmm_amd_spmdm_batch* sb, char transa, const float* a);
+/** C = beta*C + A_sparse*B for every item (alpha ignored as in the reference). */
+LIBXSMM_API int libxsmm_amd_spmdm_batch_compute(libxsmm_amd_spmdm_batch* sb, char transb, const float* b,
+  char transc, const float* beta, float* c);
+/** Geometry and CSR access for tests: copies item `i`'s rowidx (M+1), and the first nnz colidx/values to host. */
+LIBXSMM_API int libxsmm_amd_spmdm_batch_get_slice(const libxsmm_amd_spmdm_batch* sb, long long item,
+  uint16_t* rowidx, uint16_t* colidx, float* values, int capacity);
+
+/** Batched fsspmdm: the operator of `handle` applied to `batch` column panels of width handle->N that sit
+ *  side by side in B (K x ldb) / C (M x ldc): panel i = columns [i*N, (i+1)*N). Equivalent to calling
+ *  libxsmm_?fsspmdm_execute(handle, B + i*N, C + i*N) for every i (samples/pyfr/pyfr_driver_asp_reg.c:295-309). */
+LIBXSMM_API int libxsmm_amd_dfsspmdm_execute_batch(const libxsmm_dfsspmdm* handle, const double* B, double* C, long long batch);
+LIBXSMM_API int libxsmm_amd_sfsspmdm_execute_batch(const libxsmm_sfsspmdm* handle, const float* B, float* C, long long batch);
+
+#endif /* LIBXSMM_AMD_H */

@@ -1,0 +1,219 @@
+// smm_generic.hip -- batched small dense GEMM for gfx950, any (M,N,K), any leading dimensions, f32/f64.
+//
+// Replaces the reference's dense JIT back end (src/generator_gemm*.c) behind libxsmm_mmbatch_kernel
+// (src/libxsmm_gemm.c:1315-1608). Contract per C element (reference src/generator_gemm_noarch.c:59-84 and the
+// AVX2 microkernel): C[n*ldc+m] = (beta ? C : 0) + sum over k ascending of A[k*lda+m]*B[n*ldb+k]
+// (TRANS_B: B[k*ldb+n]), one fused multiply-add per step -- this kernel keeps exactly that chain, so its
+// result is bit-identical to a k-ordered fma() loop (the reference's AVX2/AVX-512 path).
+//
+// Mapping: a "unit" is a group of G threads (G=64: one wavefront, G=256: one work-group) that owns one
+// problem at a time: A (K x M) and B (N x K) are staged through LDS with coalesced loads along the
+// contiguous axis, every thread keeps a TM x TN register tile of C, C is read/written directly in HBM.
+// Units stride over the batch, so consecutive units stream consecutive problems.
+#include "smm_common.cuh"
+
+namespace xsmm {
+namespace {
+
+template<int G> __device__ __forceinline__ void unit_sync()
+{
+  if constexpr (G == 64) wave_lds_sync(); else __syncthreads();
+}
+
+// T: element type; TM,TN: register tile; TGM x TGN = G threads per problem; GENERAL: alpha/beta/TRANS_A form
+template<typename T, int TM, int TN, int TGM, int TGN, bool GENERAL>
+__global__ __launch_bounds__(256)
+void smm_generic_kernel(DevAddr ad, int M, int N, int K, int lda, int ldb, int ldc, int flags, int sync,
+                        long long batch, int KC, int kshift, T alpha, T beta)
+{
+  constexpr int G = TGM * TGN;
+  constexpr int PPB = 256 / G;
+  constexpr int MP = TGM * TM;
+  constexpr int NP = TGN * TN;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+
+  const int slot = threadIdx.x / G;
+  const int t = threadIdx.x % G;
+  const int tx = t % TGM, ty = t / TGM;
+  const int KP = KC | 1;                              // odd row stride: conflict-free column reads of B
+  const size_t slot_elems = (size_t)KC * MP + (size_t)NP * KP;
+  T* const As = reinterpret_cast<T*>(smem_raw) + (size_t)slot * slot_elems;   // As[kc][MP]
+  T* const Bs = As + (size_t)KC * MP;                                          // Bs[NP][KP]
+  const bool transa = GENERAL && (0 != (flags & LIBXSMM_GEMM_FLAG_TRANS_A));
+  const bool transb = (0 != (flags & LIBXSMM_GEMM_FLAG_TRANS_B));
+  const bool beta0 = (0 != (flags & LIBXSMM_GEMM_FLAG_BETA_0));
+  const int KL = 1 << kshift;                         // lanes along the contiguous axis while staging B
+
+  const long long unit = (long long)blockIdx.x * PPB + slot;
+  const long long nunits = (long long)gridDim.x * PPB;
+
+  for (long long item = unit; item < batch; item += nunits) {
+    T* const pc = addr_c<T>(ad, item);
+    long long count = 1;
+    if (SYNC_RUNS == sync) { // only the head of a run of equal C works; it walks the run in batch order
+      if (0 < item && addr_c<T>(ad, item - 1) == pc) continue;
+      while (item + count < batch && addr_c<T>(ad, item + count) == pc) ++count;
+    }
+    for (int m0 = 0; m0 < M; m0 += MP) {
+      for (int n0 = 0; n0 < N; n0 += NP) {
+        T acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const int m = m0 + tx * TM + i, n = n0 + ty * TN + j;
+            acc[i][j] = (!GENERAL && !beta0 && SYNC_ATOMIC != sync && m < M && n < N) ? pc[(size_t)n * ldc + m] : T(0);
+          }
+        }
+        for (long long r = 0; r < count; ++r) {
+          const T* const pa = addr_a<T>(ad, item + r);
+          const T* const pb = addr_b<T>(ad, item + r);
+          for (int k0 = 0; k0 < K; k0 += KC) {
+            const int kc = (K - k0 < KC) ? (K - k0) : KC;
+            unit_sync<G>(); // previous tile fully consumed
+            // stage A[k0..k0+kc) x [m0..m0+MP): lanes run along m (contiguous in memory unless TRANS_A)
+            for (int idx = t; idx < kc * MP; idx += G) {
+              const int kk = idx / MP, mm = idx % MP;
+              const int m = m0 + mm;
+              T v = T(0);
+              if (m < M) v = transa ? pa[(size_t)m * lda + (k0 + kk)] : pa[(size_t)(k0 + kk) * lda + m];
+              As[idx] = v;
+            }
+            // stage B: Bs[nn][kk] = B[k0+kk][n0+nn]
+            if (!transb) { // B[n*ldb+k]: lanes along k
+              const int kk = t & (KL - 1);
+              for (int nn = t >> kshift; nn < NP; nn += (G >> kshift)) {
+                const int n = n0 + nn;
+                for (int kb = kk; kb < kc; kb += KL) {
+                  Bs[nn * KP + kb] = (n < N) ? pb[(size_t)n * ldb + (k0 + kb)] : T(0);
+                }
+              }
+            }
+            else { // B[k*ldb+n]: lanes along n
+              for (int idx = t; idx < kc * NP; idx += G) {
+                const int kk = idx / NP, nn = idx % NP;
+                const int n = n0 + nn;
+                Bs[nn * KP + kk] = (n < N) ? pb[(size_t)(k0 + kk) * ldb + n] : T(0);
+              }
+            }
+            unit_sync<G>();
+            for (int kk = 0; kk < kc; ++kk) {
+              T av[TM], bv[TN];
+#pragma unroll
+              for (int i = 0; i < TM; ++i) av[i] = As[kk * MP + tx * TM + i];
+#pragma unroll
+              for (int j = 0; j < TN; ++j) bv[j] = Bs[(ty * TN + j) * KP + kk];
+#pragma unroll
+              for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = xfma(av[i], bv[j], acc[i][j]);
+              }
+            }
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const int m = m0 + tx * TM + i, n = n0 + ty * TN + j;
+            if (m < M && n < N) {
+              T* const dst = pc + (size_t)n * ldc + m;
+              if constexpr (GENERAL) {
+                *dst = (T(0) == beta) ? (alpha * acc[i][j]) : (alpha * acc[i][j] + beta * (*dst));
+              }
+              else if (SYNC_ATOMIC == sync) {
+                if (beta0) *dst = acc[i][j]; else atomicAdd(dst, acc[i][j]);
+              }
+              else {
+                *dst = acc[i][j];
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+// counts adjacent C operands that are equal (out[0]) or decreasing (out[1])
+template<typename T>
+__global__ __launch_bounds__(256) void c_order_kernel(DevAddr ad, long long batch, int* out)
+{
+  int eq = 0, dec = 0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x + 1; i < batch; i += (long long)gridDim.x * blockDim.x) {
+    const T* const c0 = addr_c<T>(ad, i - 1);
+    const T* const c1 = addr_c<T>(ad, i);
+    eq += (c1 == c0) ? 1 : 0;
+    dec += (c1 < c0) ? 1 : 0;
+  }
+  if (eq) atomicAdd(out + 0, eq);
+  if (dec) atomicAdd(out + 1, dec);
+}
+
+template<typename T, int TM, int TGM, bool GENERAL>
+int launch_generic_t(const SmmBatch& s, hipStream_t stream)
+{
+  constexpr int G = TGM * TGM, PPB = 256 / G, MP = TGM * TM, NP = TGM * TM;
+  // K chunk: keep a unit's LDS tile <= 16 KiB (G=64) / 48 KiB (G=256) so several work-groups fit a CU
+  const size_t budget = (G == 64 ? 16384 : 49152) / sizeof(T);
+  int KC = s.k;
+  while (KC > 1 && ((size_t)KC * MP + (size_t)NP * (KC | 1)) > budget) KC = (KC + 1) / 2;
+  if (KC < 1) KC = 1;
+  const size_t slot_elems = (size_t)KC * MP + (size_t)NP * (KC | 1);
+  const size_t smem = slot_elems * sizeof(T) * PPB;
+  int kshift = 0;
+  while ((1 << kshift) < KC && (1 << kshift) < G) ++kshift; // lanes along k when staging B
+  const long long units = s.batch;
+  long long blocks = (units + PPB - 1) / PPB;
+  const long long maxblocks = 256LL * 16; // 256 CUs, enough resident groups; units stride over the batch
+  if (blocks > maxblocks) blocks = maxblocks;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL((smm_generic_kernel<T, TM, TM, TGM, TGM, GENERAL>), dim3((unsigned)blocks), dim3(256), smem, stream,
+    make_addr(s), s.m, s.n, s.k, s.lda, s.ldb, s.ldc, s.flags, s.sync, s.batch, KC, kshift, (T)s.alpha, (T)s.beta);
+  return (int)hipGetLastError();
+}
+
+template<typename T, bool GENERAL>
+int launch_generic(const SmmBatch& s, hipStream_t stream, const char** name)
+{
+  const int mx = (s.m > s.n ? s.m : s.n);
+  static const char* const names_f32[] = {
+    "smm_f32_generic_w8", "smm_f32_generic_w16", "smm_f32_generic_w24", "smm_f32_generic_w32",
+    "smm_f32_generic_g48", "smm_f32_generic_g64" };
+  static const char* const names_f64[] = {
+    "smm_f64_generic_w8", "smm_f64_generic_w16", "smm_f64_generic_w24", "smm_f64_generic_w32",
+    "smm_f64_generic_g48", "smm_f64_generic_g64" };
+  const char* const* names = (sizeof(T) == 4 ? names_f32 : names_f64);
+  if (mx <= 8) { *name = names[0]; return launch_generic_t<T, 1, 8, GENERAL>(s, stream); }
+  if (mx <= 16) { *name = names[1]; return launch_generic_t<T, 2, 8, GENERAL>(s, stream); }
+  if (mx <= 24) { *name = names[2]; return launch_generic_t<T, 3, 8, GENERAL>(s, stream); }
+  if (mx <= 32) { *name = names[3]; return launch_generic_t<T, 4, 8, GENERAL>(s, stream); }
+  if (mx <= 48) { *name = names[4]; return launch_generic_t<T, 3, 16, GENERAL>(s, stream); }
+  *name = names[5]; return launch_generic_t<T, 4, 16, GENERAL>(s, stream);
+}
+
+} // namespace
+
+int launch_smm_generic(const SmmBatch& s, void* stream, const char** name)
+{
+  hipStream_t st = (hipStream_t)stream;
+  if (0 != s.general) {
+    return (8 == s.typesize) ? launch_generic<double, true>(s, st, name) : launch_generic<float, true>(s, st, name);
+  }
+  return (8 == s.typesize) ? launch_generic<double, false>(s, st, name) : launch_generic<float, false>(s, st, name);
+}
+
+int launch_c_order_check(const SmmBatch& s, int* d_out, void* stream)
+{
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(d_out, 0, 2 * sizeof(int), st);
+  if (hipSuccess != e) return (int)e;
+  long long blocks = (s.batch + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  if (8 == s.typesize) hipLaunchKernelGGL((c_order_kernel<double>), dim3((unsigned)blocks), dim3(256), 0, st, make_addr(s), s.batch, d_out);
+  else hipLaunchKernelGGL((c_order_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, st, make_addr(s), s.batch, d_out);
+  return (int)hipGetLastError();
+}
+
+} // namespace xsmm

@@ -1,0 +1,256 @@
+// sparse.hip -- sparse x dense kernels for gfx950: CSR-A-sparse operator times column panels (fsspmdm,
+// libxsmm_create_?csr_reg), spmdm createSparseSlice (dense -> CSR with uint16 indexes) and spmdm compute.
+//
+// Reference arithmetic:
+//  - csr_reg kernel (src/generator_spgemm_csr_asparse_reg.c:227-300): row-major, per row with nnz > 0:
+//    acc = beta ? C[m*ldc+n] : 0; for p in row (ascending): acc = fma(val[p], B[col[p]*ldb+n], acc); store.
+//    Rows without nnz are skipped (:229,287). The dense fallback of fsspmdm (src/libxsmm_fsspmdm.c:134-142)
+//    zeroes such rows when beta == 0 -- `skip_empty_rows` selects between the two.
+//  - createSparseSlice (src/template/libxsmm_spmdm_createSparseSlice_fp32_thread.tpl.c:47-141): row scan,
+//    ascending column, keep v != 0, uint16 local column index, rowidx[r] = running count.
+//  - compute (src/template/libxsmm_spmdm_compute_fp32_thread.tpl.c:81-558): acc = beta*C (beta == 0: C is not
+//    read), then fma(val, B[col][n], acc) over the k-blocks in order and the row's nnz in order.
+#include "smm_common.cuh"
+
+namespace xsmm {
+namespace {
+
+// ---- CSR operator x panels ------------------------------------------------------------------------------------
+// The panels sit side by side in one row-major B (K x ldb) / C (M x ldc), so the whole batch is simply
+// C[:, 0:ncols] (+)= A_csr * B[:, 0:ncols]: every thread owns VEC adjacent columns, the CSR arrays are
+// wave-uniform (scalar loads), B rows are fetched as coalesced row segments (re-reads served by L1/L2;
+// the LDS-staged variant lives in csr_panels_lds_kernel).
+template<typename T, int VEC>
+__global__ __launch_bounds__(256)
+void csr_panels_kernel(int M, long long ncols, int ldb, int ldc, int beta0, int skip_empty,
+                       const unsigned* __restrict__ rowptr, const unsigned* __restrict__ colidx, const T* __restrict__ values,
+                       const T* __restrict__ B, T* __restrict__ C)
+{
+  const long long ngroups = (ncols + VEC - 1) / VEC;
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < ngroups; g += (long long)gridDim.x * blockDim.x) {
+    const long long n0 = g * VEC;
+    for (int m = 0; m < M; ++m) {
+      const unsigned p0 = rowptr[m], p1 = rowptr[m + 1];
+      if (p0 == p1 && (0 != skip_empty || 0 == beta0)) continue; // nothing to add; beta==1 keeps C, quirk keeps C
+      T acc[VEC];
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) acc[v] = (0 == beta0 && n0 + v < ncols) ? C[(size_t)m * ldc + n0 + v] : T(0);
+      for (unsigned p = p0; p < p1; ++p) {
+        const T a = values[p];
+        const T* const brow = B + (size_t)colidx[p] * ldb + n0;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) if (n0 + v < ncols) acc[v] = xfma(a, brow[v], acc[v]);
+      }
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) if (n0 + v < ncols) C[(size_t)m * ldc + n0 + v] = acc[v];
+    }
+  }
+}
+
+// ---- spmdm: dense -> CSR ----------------------------------------------------------------------------------------
+// One wavefront per slice (batch item, or (kb,mb) block of a large matrix). Rows are scanned in order; within a
+// row the 64 lanes test 64 consecutive columns, __ballot gives the keep-mask and the popcount of the lower lanes
+// the write position -- the output order is exactly the sequential scan of the reference.
+__global__ __launch_bounds__(256)
+void spmdm_create_kernel(long long nslices, int nrows_full, int ncols_full, int transa,
+                         const float* __restrict__ a, long long a_slice_stride, int ld,
+                         // block decomposition of one matrix (mb_count > 0) or batch of whole matrices (mb_count == 0)
+                         int mb_count, int bm, int bk, int M, int K,
+                         uint16_t* __restrict__ rowidx, uint16_t* __restrict__ colidx, float* __restrict__ values,
+                         long long rowidx_stride, long long cap)
+{
+  const int lane = threadIdx.x & 63;
+  const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+  for (long long s = wave; s < nslices; s += nwaves) {
+    const float* in; int nrows, ncols;
+    if (0 < mb_count) { // slice s = kb*mb_count + mb of one M x K matrix (reference: kb = id / mb, mb = id % mb)
+      const int kb = (int)(s / mb_count), mb = (int)(s % mb_count);
+      nrows = ((mb + 1) * bm > M) ? (M - mb * bm) : bm;
+      ncols = ((kb + 1) * bk > K) ? (K - kb * bk) : bk;
+      in = transa ? (a + (size_t)mb * bm + (size_t)kb * bk * M) : (a + (size_t)kb * bk + (size_t)mb * bm * K);
+    }
+    else { nrows = nrows_full; ncols = ncols_full; in = a + s * a_slice_stride; }
+    uint16_t* const ri = rowidx + s * rowidx_stride;
+    uint16_t* const ci = colidx + s * cap;
+    float* const va = values + s * cap;
+    unsigned cnt = 0; // wave-uniform running count
+    for (int r = 0; r < nrows; ++r) {
+      if (0 == lane) ri[r] = (uint16_t)cnt;
+      for (int c0 = 0; c0 < ncols; c0 += 64) {
+        const int c = c0 + lane;
+        float v = 0.f;
+        if (c < ncols) v = transa ? in[(size_t)c * ld + r] : in[(size_t)r * ld + c];
+        const bool keep = (c < ncols) && !(0.f == v); // LIBXSMM_FEQ(0, v) ? 0 : 1  (-0 is zero, NaN is kept)
+        const unsigned long long mask = __ballot(keep);
+        if (keep) {
+          const unsigned pos = cnt + __popcll(mask & ((1ULL << lane) - 1ULL));
+          ci[pos] = (uint16_t)c; va[pos] = v;
+        }
+        cnt += __popcll(mask);
+      }
+    }
+    if (0 == lane) ri[nrows] = (uint16_t)cnt;
+  }
+}
+
+// ---- spmdm: CSR x dense -----------------------------------------------------------------------------------------
+// Generic form (any geometry, transposes, beta): one thread per C element of one item; B is read through the
+// caches. The tuned batch kernel for small problems is spmdm_compute_lds_kernel.
+__global__ __launch_bounds__(256)
+void spmdm_compute_kernel(long long batch, int M, int N, int K, int bm, int bk, int mb_count, int kb_count,
+                          int transb, int transc, float beta,
+                          const uint16_t* __restrict__ rowidx, const uint16_t* __restrict__ colidx, const float* __restrict__ values,
+                          long long rowidx_stride, long long cap, long long slices_per_item,
+                          const float* __restrict__ b, float* __restrict__ c, long long b_stride, long long c_stride,
+                          int m_begin, int m_end, int n_begin, int n_end)
+{
+  const int tm = m_end - m_begin, tn = n_end - n_begin;
+  const long long per_item = (long long)tm * tn, total = per_item * batch;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const long long item = e / per_item;
+    const int rem = (int)(e % per_item);
+    const int m = m_begin + rem / tn, n = n_begin + rem % tn;
+    const float* const bi = b + item * b_stride;
+    float* const pc = c + item * c_stride + (transc ? ((size_t)n * M + m) : ((size_t)m * N + n));
+    float acc = (0.f == beta) ? 0.f : ((1.f == beta) ? *pc : beta * (*pc));
+    const int mb = m / bm, ml = m % bm;
+    for (int kb = 0; kb < kb_count; ++kb) {
+      const long long s = item * slices_per_item + (long long)kb * mb_count + mb;
+      const uint16_t* const ri = rowidx + s * rowidx_stride;
+      const uint16_t* const ci = colidx + s * cap;
+      const float* const va = values + s * cap;
+      const unsigned p0 = ri[ml], p1 = ri[ml + 1];
+      for (unsigned p = p0; p < p1; ++p) {
+        const int kk = kb * bk + ci[p];
+        const float bv = transb ? bi[(size_t)n * K + kk] : bi[(size_t)kk * N + n];
+        acc = xfma(va[p], bv, acc);
+      }
+    }
+    *pc = acc;
+  }
+}
+
+// ---- blocked_gemm layout conversions (reference template/libxsmm_blocked_gemm_copy*.tpl.c) -----------------------------
+template<typename T>
+__global__ __launch_bounds__(256)
+void bgemm_copy_kernel(int which, const T* __restrict__ src, int ld, T* __restrict__ dst,
+                       int mb, int nb, int kb, int bm, int bn, int bk)
+{
+  long long total;
+  if (0 == which) total = (long long)mb * kb * bk * bm; else if (1 == which) total = (long long)nb * kb * bn * bk; else total = (long long)nb * mb * bn * bm;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    if (0 == which) { // A: dst[mb][kb][bk][bm] = src[(kb*bk+k)*ld + mb*bm+m]
+      const int m = (int)(e % bm); long long r = e / bm; const int k = (int)(r % bk); r /= bk; const int ikb = (int)(r % kb); const int imb = (int)(r / kb);
+      dst[e] = src[((size_t)ikb * bk + k) * ld + (size_t)imb * bm + m];
+    }
+    else if (1 == which) { // B: dst[nb][kb][bn][bk] = src[(nb*bn+n)*ld + kb*bk+k]
+      const int k = (int)(e % bk); long long r = e / bk; const int n = (int)(r % bn); r /= bn; const int ikb = (int)(r % kb); const int inb = (int)(r / kb);
+      dst[e] = src[((size_t)inb * bn + n) * ld + (size_t)ikb * bk + k];
+    }
+    else { // C: blocked[nb][mb][bn][bm] <-> plain[(nb*bn+n)*ld + mb*bm+m]
+      const int m = (int)(e % bm); long long r = e / bm; const int n = (int)(r % bn); r /= bn; const int imb = (int)(r % mb); const int inb = (int)(r / mb);
+      const size_t plain = ((size_t)inb * bn + n) * ld + (size_t)imb * bm + m;
+      if (2 == which) dst[e] = src[plain]; else dst[plain] = src[e];
+    }
+  }
+}
+
+unsigned grid_for(long long work, int per_block)
+{
+  long long blocks = (work + per_block - 1) / per_block;
+  if (blocks > 256LL * 32) blocks = 256LL * 32;
+  if (blocks < 1) blocks = 1;
+  return (unsigned)blocks;
+}
+
+} // namespace
+
+int launch_csr_panels(const CsrPanels& p, void* stream, const char** name)
+{
+  hipStream_t st = (hipStream_t)stream;
+  const long long ncols = (long long)p.n * p.batch;
+  if (0 == ncols || 0 == p.m) { *name = "csr_panels_noop"; return 0; }
+  if (8 == p.typesize) {
+    *name = "fsspmdm_f64_csr_cols";
+    hipLaunchKernelGGL((csr_panels_kernel<double, 1>), dim3(grid_for(ncols, 256)), dim3(256), 0, st,
+      p.m, ncols, p.ldb, p.ldc, p.beta0, p.skip_empty_rows, p.rowptr, p.colidx, (const double*)p.values, (const double*)p.b, (double*)p.c);
+  }
+  else {
+    *name = "fsspmdm_f32_csr_cols";
+    hipLaunchKernelGGL((csr_panels_kernel<float, 1>), dim3(grid_for(ncols, 256)), dim3(256), 0, st,
+      p.m, ncols, p.ldb, p.ldc, p.beta0, p.skip_empty_rows, p.rowptr, p.colidx, (const float*)p.values, (const float*)p.b, (float*)p.c);
+  }
+  return (int)hipGetLastError();
+}
+
+int launch_spmdm_create(const SpmdmGeom& g, int transa, const float* a, uint16_t* rowidx, uint16_t* colidx, float* values,
+                        void* stream, const char** name)
+{ // batch form: every item is one slice of M rows x K columns
+  hipStream_t st = (hipStream_t)stream;
+  *name = "spmdm_create_slices_wave";
+  if (0 == g.batch) return 0;
+  hipLaunchKernelGGL(spmdm_create_kernel, dim3(grid_for(g.batch, 4)), dim3(256), 0, st,
+    g.batch, g.m, g.k, transa, a, (long long)g.m * g.k, transa ? g.m : g.k, 0, g.m, g.k, g.m, g.k,
+    rowidx, colidx, values, (long long)g.m + 1, (long long)g.cap);
+  return (int)hipGetLastError();
+}
+
+int launch_spmdm_create_blocks(int M, int K, int bm, int bk, int mb, int first_slice, int nslices, int transa, const float* a,
+                               uint16_t* rowidx, uint16_t* colidx, float* values, void* stream, const char** name)
+{ // single matrix decomposed into (kb,mb) slices; slices [first_slice, first_slice+nslices)
+  hipStream_t st = (hipStream_t)stream;
+  *name = "spmdm_create_slices_wave";
+  const long long cap = (long long)bm * bk, rstride = (long long)bm + 1;
+  // the kernel numbers slices from 0: offset the outputs and let it skip the leading ids via the pointer arithmetic
+  // (slice id is needed for kb/mb, so pass a shifted count and shift inside through a wrapper loop)
+  for (int s = first_slice; s < first_slice + nslices; ++s) {
+    const int kb = s / mb, imb = s % mb;
+    const int nrows = ((imb + 1) * bm > M) ? (M - imb * bm) : bm;
+    const int ncols = ((kb + 1) * bk > K) ? (K - kb * bk) : bk;
+    const float* in = transa ? (a + (size_t)imb * bm + (size_t)kb * bk * M) : (a + (size_t)kb * bk + (size_t)imb * bm * K);
+    hipLaunchKernelGGL(spmdm_create_kernel, dim3(1), dim3(64), 0, st,
+      1LL, nrows, ncols, transa, in, 0LL, transa ? M : K, 0, bm, bk, M, K,
+      rowidx + s * rstride, colidx + s * cap, values + s * cap, rstride, cap);
+  }
+  return (int)hipGetLastError();
+}
+
+int launch_spmdm_compute_generic(long long batch, int M, int N, int K, int bm, int bk, int mb, int kb, int transb, int transc, float beta,
+                                 const uint16_t* rowidx, const uint16_t* colidx, const float* values, long long rowidx_stride, long long cap,
+                                 const float* b, float* c, long long b_stride, long long c_stride,
+                                 int m_begin, int m_end, int n_begin, int n_end, void* stream, const char** name)
+{
+  hipStream_t st = (hipStream_t)stream;
+  *name = "spmdm_compute_elem";
+  const long long total = (long long)(m_end - m_begin) * (n_end - n_begin) * batch;
+  if (0 >= total) return 0;
+  hipLaunchKernelGGL(spmdm_compute_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st,
+    batch, M, N, K, bm, bk, mb, kb, transb, transc, beta, rowidx, colidx, values, rowidx_stride, cap, (long long)mb * kb,
+    b, c, b_stride, c_stride, m_begin, m_end, n_begin, n_end);
+  return (int)hipGetLastError();
+}
+
+int launch_spmdm_compute(const SpmdmGeom& g, int transb, int transc, float beta, const uint16_t* rowidx, const uint16_t* colidx,
+                         const float* values, const float* b, float* c, void* stream, const char** name)
+{
+  return launch_spmdm_compute_generic(g.batch, g.m, g.n, g.k, g.m, g.k, 1, 1, transb, transc, beta, rowidx, colidx, values,
+    (long long)g.m + 1, (long long)g.cap, b, c, (long long)g.k * g.n, (long long)g.m * g.n, 0, g.m, 0, g.n, stream, name);
+}
+
+int launch_bgemm_copy(const BgemmGeom& g, int which, const void* src, int ld, void* dst, void* stream)
+{
+  hipStream_t st = (hipStream_t)stream;
+  const long long total = (0 == which) ? (long long)g.m * g.k : ((1 == which) ? (long long)g.n * g.k : (long long)g.m * g.n);
+  if (8 == g.typesize) {
+    hipLaunchKernelGGL((bgemm_copy_kernel<double>), dim3(grid_for(total, 256)), dim3(256), 0, st, which, (const double*)src, ld, (double*)dst,
+      g.mb, g.nb, g.kb, g.bm, g.bn, g.bk);
+  }
+  else {
+    hipLaunchKernelGGL((bgemm_copy_kernel<float>), dim3(grid_for(total, 256)), dim3(256), 0, st, which, (const float*)src, ld, (float*)dst,
+      g.mb, g.nb, g.kb, g.bm, g.bn, g.bk);
+  }
+  return (int)hipGetLastError();
+}
+
+} // namespace xsmm

@@ -1,0 +1,129 @@
+// xsmm_device.cpp -- HIP device context of the engine: device probe, stream, pointer classification,
+// scratch memory and staging copies. Host-only translation unit (HIP runtime API, no kernels).
+#include "xsmm_internal.hpp"
+
+#include <hip/hip_runtime_api.h>
+
+#include <atomic>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+namespace xsmm {
+
+namespace {
+std::once_flag g_probe_once;
+Device g_device;
+std::atomic<unsigned long long> g_launches{0};
+thread_local const char* tl_last_kernel = "";
+
+struct Scratch { void* ptr = nullptr; size_t size = 0; };
+thread_local Scratch tl_scratch[8];
+}
+
+Device& device() { return g_device; }
+
+bool device_ready()
+{
+  std::call_once(g_probe_once, []() {
+    int n = 0;
+    const hipError_t e = hipGetDeviceCount(&n);
+    g_device.count = (hipSuccess == e ? n : 0);
+  });
+  return 0 < g_device.count;
+}
+
+void fail_no_device(const char* what)
+{ // the product has no CPU compute path: say so loudly, independent of the verbosity level
+  fprintf(stderr, "LIBXSMM-AMD FATAL: %s requires a HIP device (gfx950) but none is usable; "
+                  "there is no CPU fallback in this library.\n", what);
+}
+
+bool is_device_ptr(const void* p)
+{
+  if (nullptr == p || !device_ready()) return false;
+  hipPointerAttribute_t attr;
+  memset(&attr, 0, sizeof(attr));
+  const hipError_t e = hipPointerGetAttributes(&attr, p);
+  if (hipSuccess != e) { (void)hipGetLastError(); return false; } // plain host memory on older runtimes
+  return hipMemoryTypeDevice == attr.type || hipMemoryTypeManaged == attr.type || hipMemoryTypeHost == attr.type
+      || hipMemoryTypeArray == attr.type;
+}
+
+void* dev_alloc(size_t bytes)
+{
+  void* p = nullptr;
+  if (!device_ready()) return nullptr;
+  if (hipSuccess != hipMalloc(&p, 0 != bytes ? bytes : 1)) { (void)hipGetLastError(); return nullptr; }
+  return p;
+}
+
+void dev_free(void* p) { if (nullptr != p) (void)hipFree(p); }
+
+int h2d(void* dst, const void* src, size_t bytes)
+{
+  if (0 == bytes) return 0;
+  return (int)hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)g_device.stream);
+}
+
+int d2h(void* dst, const void* src, size_t bytes)
+{
+  if (0 == bytes) return 0;
+  hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)g_device.stream);
+  if (hipSuccess == e) e = hipStreamSynchronize((hipStream_t)g_device.stream);
+  return (int)e;
+}
+
+int stream_sync() { return (int)hipStreamSynchronize((hipStream_t)g_device.stream); }
+
+void note_launch(const char* name)
+{
+  tl_last_kernel = (nullptr != name ? name : "");
+  g_launches.fetch_add(1, std::memory_order_relaxed);
+}
+
+void* scratch(int slot, size_t bytes)
+{
+  Scratch& s = tl_scratch[slot & 7];
+  if (s.size < bytes) {
+    if (nullptr != s.ptr) { (void)hipStreamSynchronize((hipStream_t)g_device.stream); (void)hipFree(s.ptr); }
+    s.ptr = nullptr; s.size = 0;
+    const size_t want = bytes + bytes / 4 + 4096;
+    if (hipSuccess == hipMalloc(&s.ptr, want)) s.size = want; else { (void)hipGetLastError(); s.ptr = nullptr; }
+  }
+  return s.ptr;
+}
+
+} // namespace xsmm
+
+using namespace xsmm;
+
+LIBXSMM_API int libxsmm_amd_device_count(void) { return device_ready() ? device().count : 0; }
+LIBXSMM_API void libxsmm_amd_set_stream(void* hip_stream) { device().stream = hip_stream; }
+LIBXSMM_API void* libxsmm_amd_get_stream(void) { return device().stream; }
+
+LIBXSMM_API int libxsmm_amd_synchronize(void)
+{
+  if (!device_ready()) return EXIT_FAILURE;
+  return 0 == stream_sync() ? EXIT_SUCCESS : EXIT_FAILURE;
+}
+
+LIBXSMM_API void* libxsmm_amd_device_malloc(size_t size) { return dev_alloc(size); }
+LIBXSMM_API void libxsmm_amd_device_free(void* ptr) { dev_free(ptr); }
+
+LIBXSMM_API int libxsmm_amd_memcpy_h2d(void* dst_device, const void* src_host, size_t size)
+{
+  if (!device_ready()) return EXIT_FAILURE;
+  if (0 != h2d(dst_device, src_host, size)) return EXIT_FAILURE;
+  return 0 == stream_sync() ? EXIT_SUCCESS : EXIT_FAILURE; // the host buffer may be reused right away
+}
+
+LIBXSMM_API int libxsmm_amd_memcpy_d2h(void* dst_host, const void* src_device, size_t size)
+{
+  if (!device_ready()) return EXIT_FAILURE;
+  return 0 == d2h(dst_host, src_device, size) ? EXIT_SUCCESS : EXIT_FAILURE;
+}
+
+LIBXSMM_API int libxsmm_amd_is_device_pointer(const void* ptr) { return is_device_ptr(ptr) ? 1 : 0; }
+LIBXSMM_API const char* libxsmm_amd_last_kernel(void) { return tl_last_kernel; }
+LIBXSMM_API unsigned long long libxsmm_amd_launch_count(void) { return g_launches.load(std::memory_order_relaxed); }

@@ -1,0 +1,580 @@
+// xsmm_gemm.cpp -- batched SMM front end: libxsmm_mmbatch / gemm_batch(_omp) / ?gemm_batch / ?gemm, the
+// per-call kernel thunks, and the staging path for host-resident operands.
+//
+// Reference: src/libxsmm_gemm.c (libxsmm_mmbatch_kernel :1315-1608, libxsmm_mmbatch :1809-1875,
+// libxsmm_gemm_batch :1878-1888, ?gemm_batch :1231-1262, ?gemm :1265-1290) and src/libxsmm_ext_gemm.c
+// (OpenMP batch driver :758-1013, auto-batch :1016-1135). The reference iterates the batch on the CPU and
+// calls one JIT kernel per item; here the batch *is* the launch: one grid over all items, three addressing
+// modes resolved on the device.
+#include "xsmm_internal.hpp"
+
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+namespace xsmm {
+int launch_smm_generic(const SmmBatch& s, void* stream, const char** name);
+int launch_smm_special(const SmmBatch& s, void* stream, const char** name); // returns -1 if no specialised variant applies
+}
+
+using namespace xsmm;
+
+namespace {
+
+int run_smm(const SmmBatch& s)
+{
+  const char* name = "";
+  int e = -1;
+  if (0 == s.general) e = launch_smm_special(s, device().stream, &name);
+  if (e < 0) e = launch_smm_generic(s, device().stream, &name);
+  note_launch(name);
+  if (0 != e) fprintf(stderr, "LIBXSMM-AMD ERROR: kernel launch failed (%s, hip error %d)\n", name, e);
+  return e;
+}
+
+size_t span_a(const SmmBatch& s) { // elements touched by one A operand
+  return (0 != s.general && 0 != (s.flags & LIBXSMM_GEMM_FLAG_TRANS_A)) ? ((size_t)(s.m - 1) * s.lda + s.k) : ((size_t)(s.k - 1) * s.lda + s.m);
+}
+size_t span_b(const SmmBatch& s) {
+  return (0 != (s.flags & LIBXSMM_GEMM_FLAG_TRANS_B)) ? ((size_t)(s.k - 1) * s.ldb + s.n) : ((size_t)(s.n - 1) * s.ldb + s.k);
+}
+size_t span_c(const SmmBatch& s) { return (size_t)(s.n - 1) * s.ldc + s.m; }
+
+// Decide how C operands alias (see SyncMode). beta == 0 or a negative batchsize (caller's promise, reference
+// src/libxsmm_gemm.c:1338,1430) need no care. Otherwise adjacent C operands are inspected on the device:
+// strictly increasing => independent; non-decreasing => runs; anything else => atomics.
+int choose_sync(SmmBatch& s, bool nosync)
+{
+  s.sync = SYNC_NONE;
+  if (nosync || 0 != (s.flags & LIBXSMM_GEMM_FLAG_BETA_0) || s.batch < 2 || 0 != s.general) return 0;
+  if (ADDR_STRIDED == s.mode) { s.sync = (0 == s.sc ? SYNC_RUNS : SYNC_NONE); return 0; }
+  if (ADDR_INDEX == s.mode && nullptr == s.ic) { s.sync = SYNC_RUNS; return 0; }
+  if (ADDR_POINTER == s.mode && 0 == s.sc) { s.sync = SYNC_RUNS; return 0; }
+  int* d_flags = static_cast<int*>(scratch(7, 2 * sizeof(int)));
+  if (nullptr == d_flags) return -1;
+  int e = launch_c_order_check(s, d_flags, device().stream);
+  if (0 != e) return e;
+  int h[2] = { 0, 0 };
+  e = d2h(h, d_flags, sizeof(h));
+  if (0 != e) return e;
+  s.sync = (0 != h[1]) ? SYNC_ATOMIC : (0 != h[0] ? SYNC_RUNS : SYNC_NONE);
+  return 0;
+}
+
+struct IndexRange { long long lo, hi; }; // element index range [lo, hi] used by an index array
+
+IndexRange index_range(const int* idx, int index_stride, int index_base, long long n)
+{
+  IndexRange r = { 0, 0 };
+  if (nullptr == idx || 0 == n) return r;
+  r.lo = r.hi = (long long)(*idx) - index_base;
+  for (long long i = 1; i < n; ++i) {
+    const long long v = (long long)(*reinterpret_cast<const int*>(reinterpret_cast<const char*>(idx) + i * index_stride)) - index_base;
+    if (v < r.lo) r.lo = v;
+    if (v > r.hi) r.hi = v;
+  }
+  return r;
+}
+
+// Bring an index array to the device if it lives in host memory (12 bytes per item at most: negligible next
+// to the 16 KiB of operands of a 32^3 item, but it must not be dereferenced by the GPU in place).
+const int* device_indexes(const int* idx, int index_stride, long long n, int slot, bool* ok)
+{
+  if (nullptr == idx) return nullptr;
+  if (is_device_ptr(idx)) return idx;
+  const size_t bytes = (size_t)(n - 1) * index_stride + sizeof(int);
+  void* d = scratch(slot, bytes);
+  if (nullptr == d || 0 != h2d(d, idx, bytes)) { *ok = false; return nullptr; }
+  return static_cast<const int*>(d);
+}
+
+// The core of libxsmm_mmbatch for a validated problem: resolves where everything lives, stages what the GPU
+// cannot reach, launches, and copies C back when it was staged. Returns EXIT_SUCCESS/EXIT_FAILURE.
+int batch_execute(SmmBatch s, libxsmm_blasint index_base, libxsmm_blasint index_stride,
+                  const libxsmm_blasint* stride_a, const libxsmm_blasint* stride_b, const libxsmm_blasint* stride_c,
+                  const void* a, const void* b, void* c, long long begin, long long end, bool nosync)
+{
+  if (end <= begin) return EXIT_SUCCESS;
+  if (!device_ready()) { fail_no_device("libxsmm_mmbatch"); return EXIT_FAILURE; }
+  const long long n = end - begin;
+  const int ts = s.typesize;
+  s.batch = n;
+  bool ok = true;
+  if (0 != index_stride) { // ---------------- index arrays ----------------
+    s.mode = ADDR_INDEX; s.index_base = index_base; s.index_stride = index_stride;
+    const int* const sa = (nullptr != stride_a ? reinterpret_cast<const int*>(reinterpret_cast<const char*>(stride_a) + begin * index_stride) : nullptr);
+    const int* const sb = (nullptr != stride_b ? reinterpret_cast<const int*>(reinterpret_cast<const char*>(stride_b) + begin * index_stride) : nullptr);
+    const int* const sc = (nullptr != stride_c ? reinterpret_cast<const int*>(reinterpret_cast<const char*>(stride_c) + begin * index_stride) : nullptr);
+    const bool dev_ops = is_device_ptr(a) && is_device_ptr(b) && is_device_ptr(c);
+    if (dev_ops) {
+      s.a = a; s.b = b; s.c = c;
+      s.ia = device_indexes(sa, index_stride, n, 0, &ok);
+      s.ib = device_indexes(sb, index_stride, n, 1, &ok);
+      s.ic = device_indexes(sc, index_stride, n, 2, &ok);
+      if (!ok || 0 != choose_sync(s, nosync)) return EXIT_FAILURE;
+      return 0 == run_smm(s) ? EXIT_SUCCESS : EXIT_FAILURE;
+    }
+    // host operands (an unchanged CPU caller): stage the touched element ranges over PCIe
+    if (is_device_ptr(sa) || is_device_ptr(sb) || is_device_ptr(sc)) {
+      fprintf(stderr, "LIBXSMM-AMD ERROR: host matrices with device index arrays are not supported\n");
+      return EXIT_FAILURE;
+    }
+    const IndexRange ra = index_range(sa, index_stride, index_base, n), rb = index_range(sb, index_stride, index_base, n),
+                     rc = index_range(sc, index_stride, index_base, n);
+    const size_t ea = (size_t)(ra.hi - ra.lo) + span_a(s), eb = (size_t)(rb.hi - rb.lo) + span_b(s), ec = (size_t)(rc.hi - rc.lo) + span_c(s);
+    char* const da = static_cast<char*>(scratch(3, ea * ts));
+    char* const db = static_cast<char*>(scratch(4, eb * ts));
+    char* const dc = static_cast<char*>(scratch(5, ec * ts));
+    if (nullptr == da || nullptr == db || nullptr == dc) return EXIT_FAILURE;
+    const char* const ha = static_cast<const char*>(a) + ra.lo * ts;
+    const char* const hb = static_cast<const char*>(b) + rb.lo * ts;
+    char* const hc = static_cast<char*>(c) + rc.lo * ts;
+    if (0 != h2d(da, ha, ea * ts) || 0 != h2d(db, hb, eb * ts)) return EXIT_FAILURE;
+    if (0 != h2d(dc, hc, ec * ts)) return EXIT_FAILURE; // also for beta == 0: untouched gaps must survive the copy back
+    s.a = da - ra.lo * ts; s.b = db - rb.lo * ts; s.c = dc - rc.lo * ts; // index arithmetic stays valid
+    s.ia = device_indexes(sa, index_stride, n, 0, &ok);
+    s.ib = device_indexes(sb, index_stride, n, 1, &ok);
+    s.ic = device_indexes(sc, index_stride, n, 2, &ok);
+    if (!ok || 0 != choose_sync(s, nosync)) return EXIT_FAILURE;
+    if (0 != run_smm(s)) return EXIT_FAILURE;
+    return 0 == d2h(hc, dc, ec * ts) ? EXIT_SUCCESS : EXIT_FAILURE;
+  }
+  // ---------------- arrays of pointers ----------------
+  // *stride is the byte distance between consecutive pointers (reference :1426-1428, including its
+  // index_base*sizeof(void*) correction)
+  const long long da = (nullptr != stride_a ? ((long long)*stride_a - (long long)index_base * (long long)sizeof(void*)) : 0);
+  const long long db = (nullptr != stride_b ? ((long long)*stride_b - (long long)index_base * (long long)sizeof(void*)) : 0);
+  const long long dc = (nullptr != stride_c ? ((long long)*stride_c - (long long)index_base * (long long)sizeof(void*)) : 0);
+  s.mode = ADDR_POINTER; s.sa = da; s.sb = db; s.sc = dc;
+  const char* const pa = static_cast<const char*>(a) + da * begin;
+  const char* const pb = static_cast<const char*>(b) + db * begin;
+  char* const pc = static_cast<char*>(c) + dc * begin;
+  if (is_device_ptr(a) && is_device_ptr(b) && is_device_ptr(c)) { // pointer arrays already on the device
+    s.a = pa; s.b = pb; s.c = pc;
+    if (0 != choose_sync(s, nosync)) return EXIT_FAILURE;
+    return 0 == run_smm(s) ? EXIT_SUCCESS : EXIT_FAILURE;
+  }
+  // host arrays of pointers: look at the first operand of each to see where the matrices live
+  const void* const a0 = *reinterpret_cast<const void* const*>(pa);
+  const void* const b0 = *reinterpret_cast<const void* const*>(pb);
+  void* const c0 = *reinterpret_cast<void* const*>(pc);
+  const size_t na = (0 != da ? (size_t)n : 1), nb = (0 != db ? (size_t)n : 1), nc = (0 != dc ? (size_t)n : 1);
+  if (is_device_ptr(a0) && is_device_ptr(b0) && is_device_ptr(c0)) { // device matrices, host pointer arrays: upload the arrays
+    std::vector<const void*> ta(na), tb(nb); std::vector<void*> tc(nc);
+    for (size_t i = 0; i < na; ++i) ta[i] = *reinterpret_cast<const void* const*>(pa + da * (long long)i);
+    for (size_t i = 0; i < nb; ++i) tb[i] = *reinterpret_cast<const void* const*>(pb + db * (long long)i);
+    for (size_t i = 0; i < nc; ++i) tc[i] = *reinterpret_cast<void* const*>(pc + dc * (long long)i);
+    void* const xa = scratch(0, na * sizeof(void*)); void* const xb = scratch(1, nb * sizeof(void*)); void* const xc = scratch(2, nc * sizeof(void*));
+    if (nullptr == xa || nullptr == xb || nullptr == xc) return EXIT_FAILURE;
+    if (0 != h2d(xa, ta.data(), na * sizeof(void*)) || 0 != h2d(xb, tb.data(), nb * sizeof(void*)) || 0 != h2d(xc, tc.data(), nc * sizeof(void*))) return EXIT_FAILURE;
+    if (0 != stream_sync()) return EXIT_FAILURE; // the temporaries go out of scope
+    s.a = xa; s.b = xb; s.c = xc;
+    s.sa = (0 != da ? (long long)sizeof(void*) : 0); s.sb = (0 != db ? (long long)sizeof(void*) : 0); s.sc = (0 != dc ? (long long)sizeof(void*) : 0);
+    if (0 != choose_sync(s, nosync)) return EXIT_FAILURE;
+    return 0 == run_smm(s) ? EXIT_SUCCESS : EXIT_FAILURE;
+  }
+  // host matrices behind host pointer arrays: pack every operand into a dense device buffer, keep aliasing of C
+  {
+    const size_t sza = span_a(s), szb = span_b(s), szc = span_c(s);
+    char* const ba = static_cast<char*>(scratch(3, na * sza * ts));
+    char* const bb = static_cast<char*>(scratch(4, nb * szb * ts));
+    if (nullptr == ba || nullptr == bb) return EXIT_FAILURE;
+    std::vector<const void*> ta(na), tb(nb); std::vector<void*> tc(nc);
+    for (size_t i = 0; i < na; ++i) {
+      const void* src = *reinterpret_cast<const void* const*>(pa + da * (long long)i);
+      if (0 != h2d(ba + i * sza * ts, src, sza * ts)) return EXIT_FAILURE;
+      ta[i] = ba + i * sza * ts;
+    }
+    for (size_t i = 0; i < nb; ++i) {
+      const void* src = *reinterpret_cast<const void* const*>(pb + db * (long long)i);
+      if (0 != h2d(bb + i * szb * ts, src, szb * ts)) return EXIT_FAILURE;
+      tb[i] = bb + i * szb * ts;
+    }
+    // distinct host C matrices get distinct device copies; repeated pointers share one
+    std::vector<void*> uniq; std::vector<size_t> slot_of(nc);
+    {
+      std::vector<std::pair<void*, size_t>> seen; seen.reserve(nc);
+      for (size_t i = 0; i < nc; ++i) {
+        void* hc = *reinterpret_cast<void* const*>(pc + dc * (long long)i);
+        size_t j = 0;
+        // consecutive duplicates are the common case (CP2K stacks); fall back to a linear search otherwise
+        if (!uniq.empty() && uniq.back() == hc) j = uniq.size() - 1;
+        else { for (j = 0; j < uniq.size(); ++j) if (uniq[j] == hc) break; if (j == uniq.size()) uniq.push_back(hc); }
+        slot_of[i] = j;
+      }
+    }
+    char* const bc = static_cast<char*>(scratch(5, uniq.size() * szc * ts));
+    if (nullptr == bc) return EXIT_FAILURE;
+    for (size_t j = 0; j < uniq.size(); ++j) if (0 != h2d(bc + j * szc * ts, uniq[j], szc * ts)) return EXIT_FAILURE;
+    for (size_t i = 0; i < nc; ++i) tc[i] = bc + slot_of[i] * szc * ts;
+    void* const xa = scratch(0, na * sizeof(void*)); void* const xb = scratch(1, nb * sizeof(void*)); void* const xc = scratch(2, nc * sizeof(void*));
+    if (nullptr == xa || nullptr == xb || nullptr == xc) return EXIT_FAILURE;
+    if (0 != h2d(xa, ta.data(), na * sizeof(void*)) || 0 != h2d(xb, tb.data(), nb * sizeof(void*)) || 0 != h2d(xc, tc.data(), nc * sizeof(void*))) return EXIT_FAILURE;
+    if (0 != stream_sync()) return EXIT_FAILURE;
+    s.a = xa; s.b = xb; s.c = xc;
+    s.sa = (0 != da ? (long long)sizeof(void*) : 0); s.sb = (0 != db ? (long long)sizeof(void*) : 0); s.sc = (0 != dc ? (long long)sizeof(void*) : 0);
+    if (0 != choose_sync(s, nosync)) return EXIT_FAILURE;
+    if (0 != run_smm(s)) return EXIT_FAILURE;
+    for (size_t j = 0; j < uniq.size(); ++j) if (0 != d2h(uniq[j], bc + j * szc * ts, szc * ts)) return EXIT_FAILURE;
+    return EXIT_SUCCESS;
+  }
+}
+
+SmmBatch from_descriptor(const libxsmm_gemm_descriptor& d)
+{
+  SmmBatch s; memset(&s, 0, sizeof(s));
+  s.typesize = (LIBXSMM_GEMM_PRECISION_F64 == LIBXSMM_GETENUM_INP(d.datatype)) ? 8 : 4;
+  s.m = (int)d.m; s.n = (int)d.n; s.k = (int)d.k; s.lda = (int)d.lda; s.ldb = (int)d.ldb; s.ldc = (int)d.ldc;
+  s.flags = d.flags & (LIBXSMM_GEMM_FLAG_TRANS_B | LIBXSMM_GEMM_FLAG_BETA_0);
+  s.use_mfma = libxsmm_amd_get_mfma();
+  s.alpha = 1.0; s.beta = (0 != (d.flags & LIBXSMM_GEMM_FLAG_BETA_0)) ? 0.0 : 1.0;
+  return s;
+}
+
+// single operand triple, wherever it lives (used by the per-call thunk and by libxsmm_?gemm)
+int single_execute(SmmBatch s, const void* a, const void* b, void* c)
+{
+  if (!device_ready()) { fail_no_device("a dispatched SMM kernel"); return EXIT_FAILURE; }
+  s.mode = ADDR_STRIDED; s.batch = 1; s.sa = s.sb = s.sc = 0; s.sync = SYNC_NONE;
+  if (is_device_ptr(a) && is_device_ptr(b) && is_device_ptr(c)) {
+    s.a = a; s.b = b; s.c = c;
+    return 0 == run_smm(s) ? EXIT_SUCCESS : EXIT_FAILURE;
+  }
+  const int ts = s.typesize;
+  const size_t ea = span_a(s), eb = span_b(s), ec = span_c(s);
+  char* const da = static_cast<char*>(scratch(3, ea * ts));
+  char* const db = static_cast<char*>(scratch(4, eb * ts));
+  char* const dc = static_cast<char*>(scratch(5, ec * ts));
+  if (nullptr == da || nullptr == db || nullptr == dc) return EXIT_FAILURE;
+  if (0 != h2d(da, a, ea * ts) || 0 != h2d(db, b, eb * ts) || 0 != h2d(dc, c, ec * ts)) return EXIT_FAILURE;
+  s.a = da; s.b = db; s.c = dc;
+  if (0 != run_smm(s)) return EXIT_FAILURE;
+  return 0 == d2h(c, dc, ec * ts) ? EXIT_SUCCESS : EXIT_FAILURE;
+}
+
+// ---- auto-batch recording (reference src/libxsmm_ext_gemm.c:1016-1135) -----------------------------------------
+struct Recorded { const void* a; const void* b; void* c; };
+struct Recorder {
+  std::mutex lock;
+  bool active = false;
+  int precision = 0;
+  bool have[8] = { false }; int flags = 0, m = 0, n = 0, k = 0, lda = 0, ldb = 0, ldc = 0; double alpha = 1, beta = 1;
+  libxsmm_gemm_descriptor desc; bool desc_set = false;
+  std::vector<Recorded> items;
+};
+Recorder& recorder() { static Recorder* r = new Recorder(); return *r; }
+
+bool try_record(const libxsmm_gemm_descriptor& d, const void* a, const void* b, void* c)
+{
+  Recorder& r = recorder();
+  if (!r.active) return false;
+  std::lock_guard<std::mutex> guard(r.lock);
+  if (!r.active) return false;
+  const int prec = LIBXSMM_GETENUM_INP(d.datatype);
+  if (prec != r.precision) return false;
+  if ((r.have[0] && (int)(d.flags & 3) != (r.flags & 3)) || (r.have[1] && (int)d.m != r.m) || (r.have[2] && (int)d.n != r.n) ||
+      (r.have[3] && (int)d.k != r.k) || (r.have[4] && (int)d.lda != r.lda) || (r.have[5] && (int)d.ldb != r.ldb) ||
+      (r.have[6] && (int)d.ldc != r.ldc)) return false;
+  if (r.desc_set && 0 != memcmp(&r.desc, &d, sizeof(d))) return false; // one shape per recording
+  if (!r.desc_set) { r.desc = d; r.desc_set = true; }
+  r.items.push_back(Recorded{ a, b, c });
+  return true;
+}
+
+} // namespace
+
+namespace xsmm {
+
+// What a kernel thunk does when user code calls the bare function pointer.
+void call_kernel(Kernel* k, const void* a, const void* b, void* c, const void* x3)
+{
+  if (nullptr == k) return;
+  if (KC_DENSE == k->kclass) {
+    if (try_record(k->desc, a, b, c)) return;
+    (void)single_execute(from_descriptor(k->desc), a, b, c);
+  }
+  else if (KC_REDUCE == k->kclass) { // xbm(const void** a, const void** b, void* c, const unsigned long long* count)
+    if (nullptr == x3 || nullptr == a || nullptr == b || nullptr == c) return;
+    const unsigned long long count = *static_cast<const unsigned long long*>(x3);
+    if (0 == count) return;
+    const libxsmm_blasint ptrsize = (libxsmm_blasint)sizeof(void*);
+    SmmBatch s = from_descriptor(k->desc);
+    void* cc = c;
+    // one run: every product lands in the same C (stride_c == NULL), accumulated in batch order
+    (void)batch_execute(s, 0, 0, &ptrsize, &ptrsize, nullptr, a, b, &cc, 0, (long long)count, false);
+  }
+  else if (KC_CSR_REG == k->kclass) { // kernel(ignored, B, C) -- reference fsspmdm call site src/libxsmm_fsspmdm.c:267
+    if (!device_ready()) { fail_no_device("a csr_reg kernel"); return; }
+    const int ts = (LIBXSMM_GEMM_PRECISION_F64 == LIBXSMM_GETENUM_INP(k->desc.datatype)) ? 8 : 4;
+    CsrPanels p; memset(&p, 0, sizeof(p));
+    p.typesize = ts; p.m = (int)k->desc.m; p.k = (int)k->desc.k; p.n = (int)k->desc.n; p.ldb = (int)k->desc.ldb; p.ldc = (int)k->desc.ldc;
+    p.beta0 = (0 != (k->desc.flags & LIBXSMM_GEMM_FLAG_BETA_0)); p.skip_empty_rows = 1;
+    p.rowptr = k->d_rowptr; p.colidx = k->d_colidx; p.values = k->d_values; p.nnz = k->nnz; p.batch = 1;
+    const char* name = "";
+    if (is_device_ptr(b) && is_device_ptr(c)) {
+      p.b = b; p.c = c;
+      const int e = launch_csr_panels(p, device().stream, &name); note_launch(name);
+      if (0 != e) fprintf(stderr, "LIBXSMM-AMD ERROR: kernel launch failed (%s, hip error %d)\n", name, e);
+    }
+    else {
+      const size_t eb = (size_t)(p.k - 1) * p.ldb + p.n, ec = (size_t)(p.m - 1) * p.ldc + p.n;
+      char* const db = static_cast<char*>(scratch(4, eb * ts)); char* const dc = static_cast<char*>(scratch(5, ec * ts));
+      if (nullptr == db || nullptr == dc || 0 != h2d(db, b, eb * ts) || 0 != h2d(dc, c, ec * ts)) return;
+      p.b = db; p.c = dc;
+      const int e = launch_csr_panels(p, device().stream, &name); note_launch(name);
+      if (0 != e) { fprintf(stderr, "LIBXSMM-AMD ERROR: kernel launch failed (%s, hip error %d)\n", name, e); return; }
+      (void)d2h(c, dc, ec * ts);
+    }
+  }
+}
+
+} // namespace xsmm
+
+// ---- public batch interface ------------------------------------------------------------------------------------
+LIBXSMM_API int libxsmm_mmbatch_kernel(libxsmm_xmmfunction kernel, libxsmm_blasint index_base,
+  libxsmm_blasint index_stride, const libxsmm_blasint stride_a[], const libxsmm_blasint stride_b[], const libxsmm_blasint stride_c[],
+  const void* a, const void* b, void* c, libxsmm_blasint batchsize, /*unsigned*/int tid, /*unsigned*/int ntasks,
+  unsigned char itypesize, unsigned char otypesize, int flags)
+{ // reference src/libxsmm_gemm.c:1315-1324: task `tid` of `ntasks` owns the slice [tid*tasksize, min(...))
+  (void)itypesize; (void)otypesize; (void)flags;
+  Kernel* const k = kernel_from_pointer(reinterpret_cast<const void*>(kernel.xmm));
+  if (nullptr == k || KC_CSR_REG == k->kclass || nullptr == a || nullptr == b || nullptr == c || ntasks < 1 || tid < 0 || tid >= ntasks) return EXIT_FAILURE;
+  const long long size = (batchsize < 0 ? -(long long)batchsize : batchsize);
+  const long long tasksize = (size + ntasks - 1) / ntasks;
+  const long long begin = (long long)tid * tasksize, span = begin + tasksize, end = (span < size ? span : size);
+  SmmBatch s = from_descriptor(k->desc);
+  // ntasks > 1: the tasks run concurrently on the caller's threads and may share C across slices; as in the
+  // reference (lock per C, :1366-1423) correctness then needs atomic updates unless the caller opts out.
+  const bool nosync = (batchsize < 0);
+  if (KC_REDUCE == k->kclass) { // all products of the slice land in consecutive-equal C runs by construction
+    return batch_execute(s, index_base, index_stride, stride_a, stride_b, stride_c, a, b, c, begin, end, false);
+  }
+  return batch_execute(s, index_base, index_stride, stride_a, stride_b, stride_c, a, b, c, begin, end, nosync);
+}
+
+namespace {
+
+// C = alpha*op(A)*op(B) + beta*C for every item -- what the reference delegates to BLAS
+// (libxsmm_mmbatch_blas, src/libxsmm_gemm.c:1778-1806): shapes/scalars outside the SMM domain.
+int batch_general(int typesize, const char* transa, const char* transb, libxsmm_blasint m, libxsmm_blasint n, libxsmm_blasint k,
+  const void* alpha, const void* a, const libxsmm_blasint* lda, const void* b, const libxsmm_blasint* ldb,
+  const void* beta, void* c, const libxsmm_blasint* ldc, libxsmm_blasint index_base, libxsmm_blasint index_stride,
+  const libxsmm_blasint stride_a[], const libxsmm_blasint stride_b[], const libxsmm_blasint stride_c[],
+  long long begin, long long end)
+{
+  const int flags = LIBXSMM_GEMM_PFLAGS(transa, transb, LIBXSMM_FLAGS);
+  SmmBatch s; memset(&s, 0, sizeof(s));
+  s.typesize = typesize; s.m = m; s.n = n; s.k = k;
+  s.lda = (nullptr != lda ? *lda : (0 == (LIBXSMM_GEMM_FLAG_TRANS_A & flags) ? m : k));
+  s.ldb = (nullptr != ldb ? *ldb : (0 == (LIBXSMM_GEMM_FLAG_TRANS_B & flags) ? k : n));
+  s.ldc = (nullptr != ldc ? *ldc : m);
+  s.flags = flags & (LIBXSMM_GEMM_FLAG_TRANS_A | LIBXSMM_GEMM_FLAG_TRANS_B);
+  s.general = 1;
+  if (8 == typesize) { s.alpha = (nullptr != alpha ? *static_cast<const double*>(alpha) : 1.0); s.beta = (nullptr != beta ? *static_cast<const double*>(beta) : 1.0); }
+  else { s.alpha = (nullptr != alpha ? *static_cast<const float*>(alpha) : 1.f); s.beta = (nullptr != beta ? *static_cast<const float*>(beta) : 1.f); }
+  if (m <= 0 || n <= 0 || k < 0) return EXIT_SUCCESS;
+  return batch_execute(s, index_base, index_stride, stride_a, stride_b, stride_c, a, b, c, begin, end, true);
+}
+
+} // namespace
+
+LIBXSMM_API int libxsmm_mmbatch_blas(libxsmm_gemm_precision iprec, libxsmm_gemm_precision oprec,
+  const char* transa, const char* transb, libxsmm_blasint m, libxsmm_blasint n, libxsmm_blasint k,
+  const void* alpha, const void* a, const libxsmm_blasint* lda, const void* b, const libxsmm_blasint* ldb,
+  const void* beta, void* c, const libxsmm_blasint* ldc, libxsmm_blasint index_base, libxsmm_blasint index_stride,
+  const libxsmm_blasint stride_a[], const libxsmm_blasint stride_b[], const libxsmm_blasint stride_c[],
+  libxsmm_blasint batchsize)
+{
+  if (nullptr == a || nullptr == b || nullptr == c || iprec != oprec ||
+      (LIBXSMM_GEMM_PRECISION_F64 != iprec && LIBXSMM_GEMM_PRECISION_F32 != iprec)) return EXIT_FAILURE;
+  const long long size = (batchsize < 0 ? -(long long)batchsize : batchsize);
+  return batch_general(LIBXSMM_GEMM_PRECISION_F64 == iprec ? 8 : 4, transa, transb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc,
+    index_base, index_stride, stride_a, stride_b, stride_c, 0, size);
+}
+
+LIBXSMM_API void libxsmm_mmbatch(libxsmm_gemm_precision iprec, libxsmm_gemm_precision oprec,
+  const char* transa, const char* transb, libxsmm_blasint m, libxsmm_blasint n, libxsmm_blasint k,
+  const void* alpha, const void* a, const libxsmm_blasint* lda, const void* b, const libxsmm_blasint* ldb,
+  const void* beta, void* c, const libxsmm_blasint* ldc, libxsmm_blasint index_base, libxsmm_blasint index_stride,
+  const libxsmm_blasint stride_a[], const libxsmm_blasint stride_b[], const libxsmm_blasint stride_c[],
+  libxsmm_blasint batchsize, /*unsigned*/int tid, /*unsigned*/int nthreads)
+{ // reference src/libxsmm_gemm.c:1809-1875
+  static int error_once = 0;
+  if (nullptr == a || nullptr == b || nullptr == c || tid < 0 || tid >= nthreads) {
+    if (0 != libxsmm_verbosity && once(&error_once)) fprintf(stderr, "LIBXSMM ERROR: incorrect arguments (libxsmm_mmbatch)!\n");
+    return;
+  }
+  libxsmm_init();
+  int result = EXIT_FAILURE;
+  const unsigned char otypesize = libxsmm_typesize((libxsmm_datatype)oprec);
+  const int gemm_flags = LIBXSMM_GEMM_PFLAGS(transa, transb, LIBXSMM_FLAGS);
+  libxsmm_descriptor_blob blob;
+  libxsmm_gemm_descriptor* const desc = libxsmm_gemm_descriptor_init2(&blob, iprec, oprec, m, n, k,
+    nullptr != lda ? *lda : (0 == (LIBXSMM_GEMM_FLAG_TRANS_A & gemm_flags) ? m : k),
+    nullptr != ldb ? *ldb : (0 == (LIBXSMM_GEMM_FLAG_TRANS_B & gemm_flags) ? k : n),
+    nullptr != ldc ? *ldc : m, alpha, beta, gemm_flags, libxsmm_get_gemm_auto_prefetch());
+  if (nullptr != desc) { // the AI gate of the reference (:1827) selects BLAS for large shapes; one device path serves both here
+    const libxsmm_xmmfunction kernel = libxsmm_xmmdispatch(desc);
+    if (nullptr != kernel.xmm) {
+      result = libxsmm_mmbatch_kernel(kernel, index_base, index_stride, stride_a, stride_b, stride_c, a, b, c, batchsize,
+        tid, nthreads, libxsmm_typesize((libxsmm_datatype)iprec), otypesize, desc->flags);
+    }
+  }
+  if (EXIT_SUCCESS != result && iprec == oprec && (LIBXSMM_GEMM_PRECISION_F64 == iprec || LIBXSMM_GEMM_PRECISION_F32 == iprec)) {
+    // quiet fall-back (:1842-1866): general alpha/beta/transposes
+    const long long size = (batchsize < 0 ? -(long long)batchsize : batchsize);
+    const long long tasksize = (size + nthreads - 1) / nthreads;
+    const long long begin = (long long)tid * tasksize, span = begin + tasksize, end = (span < size ? span : size);
+    result = batch_general(LIBXSMM_GEMM_PRECISION_F64 == iprec ? 8 : 4, transa, transb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc,
+      index_base, index_stride, stride_a, stride_b, stride_c, begin, end);
+  }
+  if (EXIT_SUCCESS != result && 0 != libxsmm_verbosity && once(&error_once)) {
+    fprintf(stderr, "LIBXSMM ERROR: libxsmm_mmbatch failed!\n");
+  }
+}
+
+LIBXSMM_API void libxsmm_gemm_batch(libxsmm_gemm_precision iprec, libxsmm_gemm_precision oprec,
+  const char* transa, const char* transb, libxsmm_blasint m, libxsmm_blasint n, libxsmm_blasint k,
+  const void* alpha, const void* a, const libxsmm_blasint* lda, const void* b, const libxsmm_blasint* ldb,
+  const void* beta, void* c, const libxsmm_blasint* ldc, libxsmm_blasint index_base, libxsmm_blasint index_stride,
+  const libxsmm_blasint stride_a[], const libxsmm_blasint stride_b[], const libxsmm_blasint stride_c[],
+  libxsmm_blasint batchsize)
+{
+  libxsmm_mmbatch(iprec, oprec, transa, transb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, index_base, index_stride,
+    stride_a, stride_b, stride_c, batchsize, 0/*tid*/, 1/*nthreads*/);
+}
+
+LIBXSMM_APIEXT void libxsmm_gemm_batch_omp(libxsmm_gemm_precision iprec, libxsmm_gemm_precision oprec,
+  const char* transa, const char* transb, libxsmm_blasint m, libxsmm_blasint n, libxsmm_blasint k,
+  const void* alpha, const void* a, const libxsmm_blasint* lda, const void* b, const libxsmm_blasint* ldb,
+  const void* beta, void* c, const libxsmm_blasint* ldc, libxsmm_blasint index_base, libxsmm_blasint index_stride,
+  const libxsmm_blasint stride_a[], const libxsmm_blasint stride_b[], const libxsmm_blasint stride_c[],
+  libxsmm_blasint batchsize)
+{ // the reference spreads the batch over OpenMP threads (src/libxsmm_ext_gemm.c:758-972); the device grid is the
+  // parallel loop here, so the whole batch is one launch
+  libxsmm_mmbatch(iprec, oprec, transa, transb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, index_base, index_stride,
+    stride_a, stride_b, stride_c, batchsize, 0, 1);
+}
+
+#define XSMM_GROUP_BATCH(NAME, T, PREC)                                                                        \
+LIBXSMM_API void NAME(const char transa_array[], const char transb_array[],                                   \
+  const libxsmm_blasint m_array[], const libxsmm_blasint n_array[], const libxsmm_blasint k_array[],         \
+  const T alpha_array[], const T* a_array[], const libxsmm_blasint lda_array[],                              \
+  const T* b_array[], const libxsmm_blasint ldb_array[],                                                     \
+  const T beta_array[], T* c_array[], const libxsmm_blasint ldc_array[],                                     \
+  const libxsmm_blasint* group_count, const libxsmm_blasint group_size[])                                    \
+{ /* reference src/libxsmm_gemm.c:1231-1262: one pointer-array batch per homogeneous group */                \
+  const libxsmm_blasint ngroups = LIBXSMM_ABS(*group_count), ptrsize = (libxsmm_blasint)sizeof(void*);       \
+  libxsmm_blasint i, j = 0;                                                                                    \
+  for (i = 0; i < ngroups; ++i) {                                                                              \
+    const libxsmm_blasint size = group_size[i];                                                                \
+    libxsmm_gemm_batch(PREC, PREC, transa_array + i, transb_array + i, m_array[i], n_array[i], k_array[i],  \
+      alpha_array + i, a_array + j, lda_array + i, b_array + j, ldb_array + i, beta_array + i, c_array + j,  \
+      ldc_array + i, 0/*index_base*/, 0/*index_stride*/, &ptrsize, &ptrsize, &ptrsize, size);                \
+    j += LIBXSMM_ABS(size);                                                                                    \
+  }                                                                                                            \
+}
+XSMM_GROUP_BATCH(libxsmm_dgemm_batch, double, LIBXSMM_GEMM_PRECISION_F64)
+XSMM_GROUP_BATCH(libxsmm_sgemm_batch, float, LIBXSMM_GEMM_PRECISION_F32)
+XSMM_GROUP_BATCH(libxsmm_dgemm_batch_omp, double, LIBXSMM_GEMM_PRECISION_F64)
+XSMM_GROUP_BATCH(libxsmm_sgemm_batch_omp, float, LIBXSMM_GEMM_PRECISION_F32)
+
+LIBXSMM_API int libxsmm_amd_gemm_batch_strided(const libxsmm_gemm_descriptor* descriptor,
+  const void* a, const void* b, void* c, long long stride_a, long long stride_b, long long stride_c, long long batchsize)
+{
+  if (nullptr == descriptor || nullptr == a || nullptr == b || nullptr == c || batchsize < 0) return EXIT_FAILURE;
+  const libxsmm_xmmfunction kernel = libxsmm_xmmdispatch(descriptor); // validates like any dispatch
+  if (nullptr == kernel.xmm) return EXIT_FAILURE;
+  if (!device_ready()) { fail_no_device("libxsmm_amd_gemm_batch_strided"); return EXIT_FAILURE; }
+  if (!(is_device_ptr(a) && is_device_ptr(b) && is_device_ptr(c))) {
+    fprintf(stderr, "LIBXSMM-AMD ERROR: libxsmm_amd_gemm_batch_strided needs device-resident operands\n");
+    return EXIT_FAILURE;
+  }
+  if (0 == batchsize) return EXIT_SUCCESS;
+  SmmBatch s = from_descriptor(*descriptor);
+  s.mode = ADDR_STRIDED; s.a = a; s.b = b; s.c = c; s.sa = stride_a; s.sb = stride_b; s.sc = stride_c; s.batch = batchsize;
+  s.sync = (0 == stride_c && 0 == (s.flags & LIBXSMM_GEMM_FLAG_BETA_0) && 1 < batchsize) ? SYNC_RUNS : SYNC_NONE;
+  return 0 == run_smm(s) ? EXIT_SUCCESS : EXIT_FAILURE;
+}
+
+// ---- BLAS-like single GEMM (reference LIBXSMM_XGEMM, include/libxsmm_frontend.h:371-411) ---------------------------
+namespace {
+template<typename T>
+void xgemm(int prec, const char* transa, const char* transb, const libxsmm_blasint* m, const libxsmm_blasint* n, const libxsmm_blasint* k,
+           const T* alpha, const T* a, const libxsmm_blasint* lda, const T* b, const libxsmm_blasint* ldb, const T* beta, T* c, const libxsmm_blasint* ldc)
+{
+  if (nullptr == m || nullptr == a || nullptr == b || nullptr == c) return;
+  libxsmm_init();
+  const int flags = LIBXSMM_GEMM_PFLAGS(transa, transb, LIBXSMM_FLAGS);
+  const libxsmm_blasint kk = (nullptr != k ? *k : *m), nn = (nullptr != n ? *n : kk), mm = *m;
+  const libxsmm_blasint ilda = LIBXSMM_MAX(nullptr != lda ? *lda : (0 == (LIBXSMM_GEMM_FLAG_TRANS_A & flags) ? mm : kk), 1);
+  const libxsmm_blasint ildb = LIBXSMM_MAX(nullptr != ldb ? *ldb : (0 == (LIBXSMM_GEMM_FLAG_TRANS_B & flags) ? kk : nn), 1);
+  const libxsmm_blasint ildc = LIBXSMM_MAX(nullptr != ldc ? *ldc : mm, 1);
+  const T aa = (nullptr != alpha ? *alpha : (T)LIBXSMM_ALPHA), bb = (nullptr != beta ? *beta : (T)LIBXSMM_BETA);
+  if (mm <= 0 || nn <= 0) return;
+  libxsmm_descriptor_blob blob;
+  const libxsmm_gemm_descriptor* const desc = libxsmm_gemm_descriptor_dinit(&blob, (libxsmm_gemm_precision)prec, mm, nn, kk,
+    ilda, ildb, ildc, (double)aa, (double)bb, flags, LIBXSMM_GEMM_PREFETCH_NONE);
+  const libxsmm_xmmfunction kernel = libxsmm_xmmdispatch(desc);
+  if (nullptr != kernel.xmm) { kernel.xmm(a, b, c); return; } // SMM domain (goes through the thunk: recording works)
+  SmmBatch s; memset(&s, 0, sizeof(s)); // BLAS domain: alpha/beta/TRANS_A
+  s.typesize = (int)sizeof(T); s.m = mm; s.n = nn; s.k = kk; s.lda = ilda; s.ldb = ildb; s.ldc = ildc;
+  s.flags = flags & (LIBXSMM_GEMM_FLAG_TRANS_A | LIBXSMM_GEMM_FLAG_TRANS_B);
+  s.general = 1; s.alpha = (double)aa; s.beta = (double)bb;
+  if (0 >= kk) { s.k = 0; }
+  (void)single_execute(s, a, b, c);
+}
+} // namespace
+
+LIBXSMM_API void libxsmm_dgemm(const char* transa, const char* transb,
+  const libxsmm_blasint* m, const libxsmm_blasint* n, const libxsmm_blasint* k,
+  const double* alpha, const double* a, const libxsmm_blasint* lda, const double* b, const libxsmm_blasint* ldb,
+  const double* beta, double* c, const libxsmm_blasint* ldc)
+{ xgemm<double>(LIBXSMM_GEMM_PRECISION_F64, transa, transb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc); }
+
+LIBXSMM_API void libxsmm_sgemm(const char* transa, const char* transb,
+  const libxsmm_blasint* m, const libxsmm_blasint* n, const libxsmm_blasint* k,
+  const float* alpha, const float* a, const libxsmm_blasint* lda, const float* b, const libxsmm_blasint* ldb,
+  const float* beta, float* c, const libxsmm_blasint* ldc)
+{ xgemm<float>(LIBXSMM_GEMM_PRECISION_F32, transa, transb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc); }
+
+// ---- auto-batch (reference src/libxsmm_ext_gemm.c:1016-1135) ---------------------------------------------------------
+LIBXSMM_APIEXT void libxsmm_mmbatch_begin(libxsmm_gemm_precision precision, const int* flags,
+  const libxsmm_blasint* m, const libxsmm_blasint* n, const libxsmm_blasint* k,
+  const libxsmm_blasint* lda, const libxsmm_blasint* ldb, const libxsmm_blasint* ldc, const void* alpha, const void* beta)
+{ // non-NULL arguments filter which calls are recorded (NULL = "free value"); alpha/beta filters are implied by the
+  // SMM domain (alpha == 1, beta in {0,1}) because only dispatched kernels are recorded.
+  (void)alpha; (void)beta;
+  Recorder& r = recorder();
+  std::lock_guard<std::mutex> guard(r.lock);
+  if (r.active) return; // nested begin: ignored, as the reference does for a batch that is already open
+  r.precision = (int)precision;
+  r.have[0] = (nullptr != flags); if (r.have[0]) r.flags = *flags;
+  r.have[1] = (nullptr != m); if (r.have[1]) r.m = *m;
+  r.have[2] = (nullptr != n); if (r.have[2]) r.n = *n;
+  r.have[3] = (nullptr != k); if (r.have[3]) r.k = *k;
+  r.have[4] = (nullptr != lda); if (r.have[4]) r.lda = *lda;
+  r.have[5] = (nullptr != ldb); if (r.have[5]) r.ldb = *ldb;
+  r.have[6] = (nullptr != ldc); if (r.have[6]) r.ldc = *ldc;
+  r.items.clear(); r.desc_set = false; r.active = true;
+}
+
+LIBXSMM_APIEXT void libxsmm_mmbatch_end(void)
+{
+  Recorder& r = recorder();
+  std::vector<Recorded> items; libxsmm_gemm_descriptor desc;
+  {
+    std::lock_guard<std::mutex> guard(r.lock);
+    if (!r.active) return;
+    r.active = false;
+    items.swap(r.items); desc = r.desc;
+    if (!r.desc_set) return;
+  }
+  if (items.empty()) return;
+  // flush as one pointer-array batch; recorded order is kept, so products into the same C accumulate in call order
+  std::vector<const void*> pa(items.size()), pb(items.size()); std::vector<void*> pc(items.size());
+  for (size_t i = 0; i < items.size(); ++i) { pa[i] = items[i].a; pb[i] = items[i].b; pc[i] = items[i].c; }
+  const libxsmm_blasint ptrsize = (libxsmm_blasint)sizeof(void*);
+  SmmBatch s = from_descriptor(desc);
+  (void)batch_execute(s, 0, 0, &ptrsize, &ptrsize, &ptrsize, pa.data(), pb.data(), pc.data(), 0, (long long)items.size(), false);
+}

@@ -1,0 +1,135 @@
+// xsmm_internal.hpp -- shared declarations between the host runtime (.cpp, built with g++) and the
+// device launchers (.hip, built with hipcc). Nothing here is part of the public C-ABI.
+#ifndef XSMM_INTERNAL_HPP
+#define XSMM_INTERNAL_HPP
+
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+
+#include "../../include/libxsmm.h"
+
+// ---------------------------------------------------------------------------------------------------
+// The GEMM descriptor. Layout follows the reference's packed POD (src/libxsmm_main.h:157-168): it is the
+// registry key and what libxsmm_get_mmkernel_info decodes, so callers that memcpy/hash it keep working.
+// ---------------------------------------------------------------------------------------------------
+#pragma pack(push, 1)
+struct libxsmm_gemm_descriptor {
+  unsigned char datatype;   // inp | out << 4  (include/libxsmm_typedefs.h:91-95)
+  unsigned short flags;     // libxsmm_gemm_flags
+  unsigned int m, n, k;
+  unsigned int lda, ldb, ldc;
+  unsigned char prefetch;
+};
+#pragma pack(pop)
+static_assert(sizeof(libxsmm_gemm_descriptor) == 28, "descriptor must stay packed (28 bytes)");
+
+namespace xsmm {
+
+// ---- device launch descriptions ------------------------------------------------------------------
+enum AddrMode : int {
+  ADDR_STRIDED = 0,   // item i: base + i*stride (elements)
+  ADDR_INDEX = 1,     // item i: base + (idx[i*index_stride bytes] - index_base) elements; NULL idx => shared
+  ADDR_POINTER = 2    // item i: *(T**)((char*)ptrs + i*stride bytes)
+};
+
+enum SyncMode : int {
+  SYNC_NONE = 0,      // every item owns its C (or beta == 0)
+  SYNC_RUNS = 1,      // equal C only in consecutive runs: one work-group walks a whole run in batch order
+  SYNC_ATOMIC = 2     // arbitrary duplicates: product from zero, then atomic add into C
+};
+
+struct SmmBatch {
+  int typesize;             // 8: f64, 4: f32
+  int m, n, k, lda, ldb, ldc;
+  int flags;                // LIBXSMM_GEMM_FLAG_TRANS_B | LIBXSMM_GEMM_FLAG_BETA_0 (others ignored)
+  int mode;                 // AddrMode
+  const void* a; const void* b; void* c;
+  const int* ia; const int* ib; const int* ic;  // ADDR_INDEX (device arrays)
+  int index_base, index_stride;                 // ADDR_INDEX: base and byte step through the index arrays
+  long long sa, sb, sc;     // ADDR_STRIDED: element strides; ADDR_POINTER: byte distance between pointers
+  long long batch;
+  int sync;                 // SyncMode
+  int use_mfma;             // policy bit (0: scalar FMA only)
+  // general form used by the BLAS-like fallback (libxsmm_?gemm with alpha/beta/trans outside the SMM domain)
+  double alpha, beta; int general;              // general != 0: C = alpha*op(A)*op(B) + beta*C, flags may hold TRANS_A
+};
+
+// returns hipError_t as int (0 == success); *name receives a static string naming the kernel variant
+int launch_smm_batch(const SmmBatch& args, void* stream, const char** name);
+
+// detects how C operands alias across the batch: out[0] = number of i with c_i == c_{i-1},
+// out[1] = number of i with c_i < c_{i-1}. d_out is a device int[2] (zeroed by the launcher).
+int launch_c_order_check(const SmmBatch& args, int* d_out, void* stream);
+
+// CSR "register" kernel family (fsspmdm sparse path, libxsmm_create_?csr_reg): row-major
+// C[m*ldc+n] = (beta? C:0) + sum_p val[p]*B[col[p]*ldb+n], rows without nnz untouched.
+struct CsrPanels {
+  int typesize;
+  int m, k;                  // operator shape
+  int n;                     // panel width per item (multiple of the reference's chunk; any n >= 1 here)
+  int ldb, ldc;
+  int beta0;
+  int skip_empty_rows;       // 1: reference's csr_reg quirk (rows without nnz are not written even when beta == 0)
+  const unsigned* rowptr; const unsigned* colidx; const void* values; // device
+  unsigned nnz;
+  const void* b; void* c;    // device; panel i starts at column i*n
+  long long batch;
+};
+int launch_csr_panels(const CsrPanels& args, void* stream, const char** name);
+
+// spmdm batch
+struct SpmdmGeom { int m, n, k; long long batch; int cap; /* bm*bk capacity per item */ };
+int launch_spmdm_create(const SpmdmGeom& g, int transa, const float* a, uint16_t* rowidx, uint16_t* colidx, float* values,
+                        void* stream, const char** name);
+int launch_spmdm_compute(const SpmdmGeom& g, int transb, int transc, float beta, const uint16_t* rowidx, const uint16_t* colidx,
+                         const float* values, const float* b, float* c, void* stream, const char** name);
+
+// blocked_gemm helpers (layouts of template/libxsmm_blocked_gemm_copy*.tpl.c)
+struct BgemmGeom { int typesize, m, n, k, bm, bn, bk, mb, nb, kb; };
+int launch_bgemm_copy(const BgemmGeom& g, int which /*0:A 1:B 2:C-in 3:C-out*/, const void* src, int ld, void* dst, void* stream);
+int launch_bgemm_compute(const BgemmGeom& g, int beta0, const void* a, const void* b, void* c, void* stream, const char** name);
+
+// ---- host runtime ------------------------------------------------------------------------------------
+struct Device {
+  int count = -1;           // -1: not probed
+  void* stream = nullptr;   // hipStream_t
+};
+Device& device();
+bool device_ready();                      // probes once; false if no HIP device
+void fail_no_device(const char* what);    // prints a loud error (always) -- the product has no CPU compute path
+bool is_device_ptr(const void* p);
+void* dev_alloc(size_t bytes);
+void dev_free(void* p);
+int h2d(void* dst, const void* src, size_t bytes);
+int d2h(void* dst, const void* src, size_t bytes);
+int stream_sync();
+void note_launch(const char* name);
+
+// grow-only device scratch, one per thread-local slot id
+void* scratch(int slot, size_t bytes);
+
+enum KernelClass : int { KC_DENSE = 0, KC_REDUCE = 1, KC_CSR_REG = 2 };
+
+struct Kernel {                 // what a dispatched function pointer stands for
+  libxsmm_gemm_descriptor desc;
+  int kclass;
+  bool registered;
+  void* thunk;                  // the bare function pointer handed to the caller
+  // KC_CSR_REG payload
+  unsigned nnz = 0;
+  unsigned* d_rowptr = nullptr; unsigned* d_colidx = nullptr; void* d_values = nullptr;
+};
+
+Kernel* kernel_from_pointer(const void* fn);           // NULL if fn is not one of ours
+void* make_thunk(Kernel* k);                           // executable stub carrying k
+void free_thunk(void* thunk);
+void call_kernel(Kernel* k, const void* a, const void* b, void* c, const void* x3); // what a thunk does
+
+int verbosity();
+bool once(int* flag);   // true the first time
+
+} // namespace xsmm
+
+#endif

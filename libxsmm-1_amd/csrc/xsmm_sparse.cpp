@@ -1,0 +1,329 @@
+// xsmm_sparse.cpp -- host side of fsspmdm (fixed-sparsity operator) and spmdm (dense-in, sparse-compute).
+//
+// Reference: src/libxsmm_fsspmdm.c:48-329 and src/libxsmm_spmdm.c:103-627 with the fp32 templates.
+#include "xsmm_internal.hpp"
+
+#include <cassert>
+#include <cstring>
+#include <vector>
+
+namespace xsmm {
+int launch_spmdm_create_blocks(int M, int K, int bm, int bk, int mb, int first_slice, int nslices, int transa, const float* a,
+                               uint16_t* rowidx, uint16_t* colidx, float* values, void* stream, const char** name);
+int launch_spmdm_compute_generic(long long batch, int M, int N, int K, int bm, int bk, int mb, int kb, int transb, int transc, float beta,
+                                 const uint16_t* rowidx, const uint16_t* colidx, const float* values, long long rowidx_stride, long long cap,
+                                 const float* b, float* c, long long b_stride, long long c_stride,
+                                 int m_begin, int m_end, int n_begin, int n_end, void* stream, const char** name);
+}
+
+using namespace xsmm;
+
+// ---------------------------------------------------------------------------------------------------------------
+// fsspmdm. The reference builds a CSR copy of the constant operator A and JITs a kernel with the pattern and
+// the (<= 31 unique) values baked in, or falls back to a dense SMM on the transposed problem. Here the CSR
+// arrays live in HBM and are read through the scalar cache; there is no limit on the number of unique values,
+// so the sparse path always applies. What is kept from the reference: CSR order (row scan, ascending column,
+// != 0 test), N % 16 == 0 and the other preconditions, and the beta == 0 behaviour for rows without nnz --
+// which differs between the reference's two paths (csr_reg leaves such rows untouched, the dense fallback
+// zeroes them): this engine zeroes them when beta == 0 (the dense fallback's, i.e. the mathematically
+// expected, result) except for kernels created explicitly through libxsmm_create_?csr_reg.
+// ---------------------------------------------------------------------------------------------------------------
+struct libxsmm_dfsspmdm {
+  int M, N, K, ldb, ldc, N_chunksize; // first six fields as in the reference handle (src/libxsmm_main.h:695-704)
+  double* a_dense;                    // always NULL here (sparse path)
+  libxsmm_dmmfunction kernel;         // always NULL here; execution goes through the fields below
+  int typesize, beta0; unsigned nnz;
+  unsigned* d_rowptr; unsigned* d_colidx; void* d_values;
+};
+struct libxsmm_sfsspmdm {
+  int M, N, K, ldb, ldc, N_chunksize;
+  float* a_dense;
+  libxsmm_smmfunction kernel;
+  int typesize, beta0; unsigned nnz;
+  unsigned* d_rowptr; unsigned* d_colidx; void* d_values;
+};
+static_assert(sizeof(libxsmm_dfsspmdm) == sizeof(libxsmm_sfsspmdm), "handles share one layout");
+
+namespace {
+
+template<typename T, typename H>
+H* fsspmdm_create(libxsmm_blasint M, libxsmm_blasint N, libxsmm_blasint K, libxsmm_blasint lda, libxsmm_blasint ldb,
+                  libxsmm_blasint ldc, T alpha, T beta, const T* a_dense)
+{
+  // preconditions: asserts in the reference (src/libxsmm_fsspmdm.c:65-71)
+  assert(N % 16 == 0); assert(N >= 16); assert(T(1) == alpha); assert(T(1) == beta || T(0) == beta);
+  assert(K <= lda); assert(N <= ldc); assert(N <= ldb);
+  if (nullptr == a_dense || 0 != (N % 16) || N < 16 || T(1) != alpha || (T(1) != beta && T(0) != beta) || K > lda || N > ldc || N > ldb) return nullptr;
+  libxsmm_init();
+  if (!device_ready()) { fail_no_device("libxsmm_?fsspmdm_create"); return nullptr; }
+  H* h = static_cast<H*>(calloc(1, sizeof(H)));
+  if (nullptr == h) return nullptr;
+  h->M = (int)M; h->N = (int)N; h->K = (int)K; h->ldb = (int)ldb; h->ldc = (int)ldc;
+  h->N_chunksize = (8 == sizeof(T) ? 8 : 16); h->typesize = (int)sizeof(T); h->beta0 = (T(0) == beta) ? 1 : 0;
+  std::vector<unsigned> rowptr((size_t)M + 1), colidx; std::vector<T> values;
+  for (int i = 0; i < M; ++i) { // src/libxsmm_fsspmdm.c:102-113
+    rowptr[i] = (unsigned)values.size();
+    for (int j = 0; j < K; ++j) {
+      const T v = a_dense[(size_t)i * lda + j];
+      if (v != T(0)) { values.push_back(v); colidx.push_back((unsigned)j); } // LIBXSMM_NEQ: -0 dropped, NaN kept
+    }
+  }
+  rowptr[M] = (unsigned)values.size();
+  h->nnz = (unsigned)values.size();
+  h->d_rowptr = static_cast<unsigned*>(dev_alloc(sizeof(unsigned) * ((size_t)M + 1)));
+  h->d_colidx = static_cast<unsigned*>(dev_alloc(sizeof(unsigned) * (h->nnz + 1)));
+  h->d_values = dev_alloc(sizeof(T) * (h->nnz + 1));
+  bool ok = (nullptr != h->d_rowptr && nullptr != h->d_colidx && nullptr != h->d_values);
+  ok = ok && 0 == h2d(h->d_rowptr, rowptr.data(), sizeof(unsigned) * ((size_t)M + 1));
+  if (0 < h->nnz) ok = ok && 0 == h2d(h->d_colidx, colidx.data(), sizeof(unsigned) * h->nnz) && 0 == h2d(h->d_values, values.data(), sizeof(T) * h->nnz);
+  ok = ok && 0 == stream_sync();
+  if (!ok) { dev_free(h->d_rowptr); dev_free(h->d_colidx); dev_free(h->d_values); free(h); return nullptr; }
+  return h;
+}
+
+template<typename T, typename H>
+int fsspmdm_run(const H* h, const T* B, T* C, long long batch)
+{
+  if (nullptr == h || nullptr == B || nullptr == C || batch < 0) return EXIT_FAILURE;
+  if (!device_ready()) { fail_no_device("libxsmm_?fsspmdm_execute"); return EXIT_FAILURE; }
+  CsrPanels p; memset(&p, 0, sizeof(p));
+  p.typesize = h->typesize; p.m = h->M; p.k = h->K; p.n = h->N; p.ldb = h->ldb; p.ldc = h->ldc; p.beta0 = h->beta0;
+  p.skip_empty_rows = 0;
+  p.rowptr = h->d_rowptr; p.colidx = h->d_colidx; p.values = h->d_values; p.nnz = h->nnz; p.batch = batch;
+  const char* name = "";
+  if (is_device_ptr(B) && is_device_ptr(C)) {
+    p.b = B; p.c = C;
+    const int e = launch_csr_panels(p, device().stream, &name); note_launch(name);
+    return 0 == e ? EXIT_SUCCESS : EXIT_FAILURE;
+  }
+  // host panels: stage rows [0,K) x columns [0, N*batch) of B and rows [0,M) of C (strided by ldb/ldc)
+  const long long ncols = (long long)h->N * batch;
+  const size_t eb = (size_t)(h->K - 1) * h->ldb + ncols, ec = (size_t)(h->M - 1) * h->ldc + ncols;
+  char* const db = static_cast<char*>(scratch(4, eb * sizeof(T))); char* const dc = static_cast<char*>(scratch(5, ec * sizeof(T)));
+  if (nullptr == db || nullptr == dc || 0 != h2d(db, B, eb * sizeof(T)) || 0 != h2d(dc, C, ec * sizeof(T))) return EXIT_FAILURE;
+  p.b = db; p.c = dc;
+  const int e = launch_csr_panels(p, device().stream, &name); note_launch(name);
+  if (0 != e) return EXIT_FAILURE;
+  return 0 == d2h(C, dc, ec * sizeof(T)) ? EXIT_SUCCESS : EXIT_FAILURE;
+}
+
+template<typename H> void fsspmdm_destroy(H* h)
+{
+  if (nullptr == h) return;
+  if (device_ready()) (void)stream_sync();
+  dev_free(h->d_rowptr); dev_free(h->d_colidx); dev_free(h->d_values);
+  free(h);
+}
+
+} // namespace
+
+LIBXSMM_API libxsmm_dfsspmdm* libxsmm_dfsspmdm_create(libxsmm_blasint M, libxsmm_blasint N, libxsmm_blasint K,
+  libxsmm_blasint lda, libxsmm_blasint ldb, libxsmm_blasint ldc, const double alpha, const double beta, const double* a_dense)
+{ return fsspmdm_create<double, libxsmm_dfsspmdm>(M, N, K, lda, ldb, ldc, alpha, beta, a_dense); }
+LIBXSMM_API libxsmm_sfsspmdm* libxsmm_sfsspmdm_create(libxsmm_blasint M, libxsmm_blasint N, libxsmm_blasint K,
+  libxsmm_blasint lda, libxsmm_blasint ldb, libxsmm_blasint ldc, const float alpha, const float beta, const float* a_dense)
+{ return fsspmdm_create<float, libxsmm_sfsspmdm>(M, N, K, lda, ldb, ldc, alpha, beta, a_dense); }
+LIBXSMM_API void libxsmm_dfsspmdm_execute(const libxsmm_dfsspmdm* handle, const double* B, double* C) { assert(nullptr != handle); (void)fsspmdm_run<double>(handle, B, C, 1); }
+LIBXSMM_API void libxsmm_sfsspmdm_execute(const libxsmm_sfsspmdm* handle, const float* B, float* C) { assert(nullptr != handle); (void)fsspmdm_run<float>(handle, B, C, 1); }
+LIBXSMM_API void libxsmm_dfsspmdm_destroy(libxsmm_dfsspmdm* handle) { fsspmdm_destroy(handle); }
+LIBXSMM_API void libxsmm_sfsspmdm_destroy(libxsmm_sfsspmdm* handle) { fsspmdm_destroy(handle); }
+LIBXSMM_API int libxsmm_amd_dfsspmdm_execute_batch(const libxsmm_dfsspmdm* handle, const double* B, double* C, long long batch)
+{ return fsspmdm_run<double>(handle, B, C, batch); }
+LIBXSMM_API int libxsmm_amd_sfsspmdm_execute_batch(const libxsmm_sfsspmdm* handle, const float* B, float* C, long long batch)
+{ return fsspmdm_run<float>(handle, B, C, batch); }
+
+// ---------------------------------------------------------------------------------------------------------------
+// spmdm, reference API (one M x N x K problem; the caller loops over block ids, samples/spmdm/spmdm.c:99-109).
+// The handle and slice structs are caller-visible (include/libxsmm_spmdm.h:42-72); the slice arrays
+// (rowidx/colidx/values) are allocated in HBM, the slice descriptors in host memory.
+// Block geometry: bm/bn/bk only partition the work (results do not depend on them); the reference derives them
+// from the CPU ISA and thread count (src/libxsmm_spmdm.c:555-608). Here: bk = 128 and bm = 512|256 as in the
+// reference (both bound the uint16 slice-local indexes), bn = 96.
+// ---------------------------------------------------------------------------------------------------------------
+LIBXSMM_API void libxsmm_spmdm_init(int M, int N, int K, int max_threads,
+  libxsmm_spmdm_handle* handle, libxsmm_CSR_sparseslice** libxsmm_output_csr)
+{
+  (void)max_threads;
+  libxsmm_init();
+  if (nullptr == handle || nullptr == libxsmm_output_csr) return;
+  memset(handle, 0, sizeof(*handle));
+  *libxsmm_output_csr = nullptr;
+  handle->m = M; handle->n = N; handle->k = K;
+  handle->bm = (M >= 4096 || M <= 1024) ? 512 : 256;
+  if (handle->bm > M && 0 < M) handle->bm = M; // no point in a block taller than the matrix (keeps scratch small)
+  handle->bn = 96; handle->bk = 128;
+  handle->mb = (M + handle->bm - 1) / handle->bm;
+  handle->nb = (N + handle->bn - 1) / handle->bn;
+  handle->kb = (K + handle->bk - 1) / handle->bk;
+  handle->datatype = LIBXSMM_SPMDM_DATATYPE_F32;
+  if (!device_ready()) { fail_no_device("libxsmm_spmdm_init"); return; }
+  const size_t nslices = (size_t)handle->mb * handle->kb;
+  const size_t cap = (size_t)handle->bm * handle->bk, rstride = (size_t)handle->bm + 1;
+  // one device block: [rowidx | colidx | values] for all slices (capacity per slice as in the reference :109-112)
+  const size_t bytes = nslices * (rstride * sizeof(uint16_t) + cap * sizeof(uint16_t) + cap * sizeof(float)) + 256;
+  char* const block = static_cast<char*>(dev_alloc(bytes));
+  libxsmm_CSR_sparseslice* const slices = static_cast<libxsmm_CSR_sparseslice*>(calloc(nslices ? nslices : 1, sizeof(libxsmm_CSR_sparseslice)));
+  if (nullptr == block || nullptr == slices) {
+    if (0 != libxsmm_verbosity) fprintf(stderr, "LIBXSMM ERROR: SPMDM CSR scratch memory allocation failed!\n");
+    dev_free(block); free(slices); return;
+  }
+  float* const values = reinterpret_cast<float*>(block);
+  uint16_t* const colidx = reinterpret_cast<uint16_t*>(block + nslices * cap * sizeof(float));
+  uint16_t* const rowidx = colidx + nslices * cap;
+  for (size_t i = 0; i < nslices; ++i) {
+    slices[i].rowidx = rowidx + i * rstride; slices[i].colidx = colidx + i * cap; slices[i].values = values + i * cap;
+  }
+  handle->base_ptr_scratch_A = block;                                         // device memory, owned by the library
+  handle->base_ptr_scratch_B_scratch_C = reinterpret_cast<char*>(slices);     // host array of slice descriptors
+  handle->memory_for_scratch_per_thread = 0;
+  *libxsmm_output_csr = slices;
+}
+
+LIBXSMM_API void libxsmm_spmdm_destroy(libxsmm_spmdm_handle* handle)
+{
+  if (nullptr == handle) return;
+  if (device_ready()) (void)stream_sync();
+  dev_free(handle->base_ptr_scratch_A); handle->base_ptr_scratch_A = nullptr;
+  free(handle->base_ptr_scratch_B_scratch_C); handle->base_ptr_scratch_B_scratch_C = nullptr;
+}
+
+LIBXSMM_API int libxsmm_spmdm_get_num_createSparseSlice_blocks(const libxsmm_spmdm_handle* handle) { return handle->mb * handle->kb; }
+LIBXSMM_API int libxsmm_spmdm_get_num_compute_blocks(const libxsmm_spmdm_handle* handle) { return handle->mb * handle->nb; }
+
+namespace {
+// dense operands of the single-problem API may be host memory (unchanged caller): mirror them on the device once per call
+const float* mirror_in(const float* p, size_t elems, int slot, bool* ok)
+{
+  if (is_device_ptr(p)) return p;
+  void* d = scratch(slot, elems * sizeof(float));
+  if (nullptr == d || 0 != h2d(d, p, elems * sizeof(float))) { *ok = false; return nullptr; }
+  return static_cast<const float*>(d);
+}
+}
+
+LIBXSMM_API void libxsmm_spmdm_createSparseSlice_fp32_thread(const libxsmm_spmdm_handle* handle, char transa,
+  const float* a, libxsmm_CSR_sparseslice* libxsmm_output_csr_a, int block_id, int tid, int nthreads)
+{
+  (void)tid; (void)nthreads;
+  if (nullptr == handle || nullptr == a || nullptr == libxsmm_output_csr_a || nullptr == handle->base_ptr_scratch_A) return;
+  if (!device_ready()) { fail_no_device("libxsmm_spmdm_createSparseSlice_fp32_thread"); return; }
+  const int ta = ('T' == transa || 't' == transa);
+  bool ok = true;
+  const float* const da = mirror_in(a, (size_t)handle->m * handle->k, 3, &ok);
+  if (!ok) return;
+  const size_t nslices = (size_t)handle->mb * handle->kb, cap = (size_t)handle->bm * handle->bk;
+  float* const values = reinterpret_cast<float*>(handle->base_ptr_scratch_A);
+  uint16_t* const colidx = reinterpret_cast<uint16_t*>(handle->base_ptr_scratch_A + nslices * cap * sizeof(float));
+  uint16_t* const rowidx = colidx + nslices * cap;
+  const char* name = "";
+  const int e = launch_spmdm_create_blocks(handle->m, handle->k, handle->bm, handle->bk, handle->mb, block_id, 1, ta, da,
+    rowidx, colidx, values, device().stream, &name);
+  note_launch(name);
+  if (0 != e) fprintf(stderr, "LIBXSMM-AMD ERROR: kernel launch failed (%s, hip error %d)\n", name, e);
+  if (da != a) (void)stream_sync(); // the staging buffer is reused by the next call
+}
+
+LIBXSMM_API void libxsmm_spmdm_compute_fp32_thread(const libxsmm_spmdm_handle* handle, char transa, char transb,
+  const float* alpha, libxsmm_CSR_sparseslice* a_sparse, const float* b, char transc, const float* beta, float* c,
+  int block_id, int tid, int nthreads)
+{
+  (void)transa; (void)alpha; (void)tid; (void)nthreads; // alpha is ignored by the reference (include/libxsmm_spmdm.h:104)
+  if (nullptr == handle || nullptr == a_sparse || nullptr == b || nullptr == c || nullptr == beta) return;
+  if (!device_ready()) { fail_no_device("libxsmm_spmdm_compute_fp32_thread"); return; }
+  const int tb = ('T' == transb || 't' == transb), tc = ('T' == transc || 't' == transc);
+  const int mb = block_id / handle->nb, nb = block_id % handle->nb; // compute tpl :38-39
+  const int m0 = mb * handle->bm, n0 = nb * handle->bn;
+  const int m1 = LIBXSMM_MIN(m0 + handle->bm, handle->m), n1 = LIBXSMM_MIN(n0 + handle->bn, handle->n);
+  bool ok = true;
+  const float* const db = mirror_in(b, (size_t)handle->k * handle->n, 4, &ok);
+  if (!ok) return;
+  float* dc = c; const bool c_host = !is_device_ptr(c);
+  const size_t celems = (size_t)handle->m * handle->n;
+  if (c_host) {
+    dc = static_cast<float*>(scratch(5, celems * sizeof(float)));
+    if (nullptr == dc || 0 != h2d(dc, c, celems * sizeof(float))) return;
+  }
+  const size_t cap = (size_t)handle->bm * handle->bk;
+  const char* name = "";
+  // the slice arrays are one block: slice 0's pointers are the bases
+  const int e = launch_spmdm_compute_generic(1, handle->m, handle->n, handle->k, handle->bm, handle->bk, handle->mb, handle->kb,
+    tb, tc, *beta, a_sparse[0].rowidx, a_sparse[0].colidx, a_sparse[0].values, (long long)handle->bm + 1, (long long)cap,
+    db, dc, 0, 0, m0, m1, n0, n1, device().stream, &name);
+  note_launch(name);
+  if (0 != e) { fprintf(stderr, "LIBXSMM-AMD ERROR: kernel launch failed (%s, hip error %d)\n", name, e); return; }
+  if (c_host) { // copy back only this block's tile rows/columns: whole-matrix copy would clobber tiles of concurrent blocks
+    std::vector<float> tmp(celems);
+    if (0 != d2h(tmp.data(), dc, celems * sizeof(float))) return;
+    for (int m = m0; m < m1; ++m) for (int n = n0; n < n1; ++n) {
+      const size_t idx = tc ? ((size_t)n * handle->m + m) : ((size_t)m * handle->n + n);
+      c[idx] = tmp[idx];
+    }
+  }
+  else if (db != b) (void)stream_sync();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// spmdm batch extension: `batch` independent problems, one slice per item (bm = M, bk = K).
+// HBM layout: rowidx[batch][M+1] (u16), colidx[batch][M*K] (u16), values[batch][M*K] (f32): fixed-capacity slots,
+// only the first nnz entries of a slot are ever touched.
+// ---------------------------------------------------------------------------------------------------------------
+struct libxsmm_amd_spmdm_batch {
+  SpmdmGeom g;
+  uint16_t* rowidx; uint16_t* colidx; float* values;
+};
+
+LIBXSMM_API libxsmm_amd_spmdm_batch* libxsmm_amd_spmdm_batch_create(int M, int N, int K, long long batch)
+{
+  libxsmm_init();
+  if (M <= 0 || N <= 0 || K <= 0 || batch < 0 || (long long)M * K > 65535 || K > 65535) return nullptr; // uint16 counters/indexes
+  if (!device_ready()) { fail_no_device("libxsmm_amd_spmdm_batch_create"); return nullptr; }
+  libxsmm_amd_spmdm_batch* sb = static_cast<libxsmm_amd_spmdm_batch*>(calloc(1, sizeof(*sb)));
+  if (nullptr == sb) return nullptr;
+  sb->g.m = M; sb->g.n = N; sb->g.k = K; sb->g.batch = batch; sb->g.cap = M * K;
+  const size_t nb = (size_t)(batch ? batch : 1);
+  sb->rowidx = static_cast<uint16_t*>(dev_alloc(nb * ((size_t)M + 1) * sizeof(uint16_t)));
+  sb->colidx = static_cast<uint16_t*>(dev_alloc(nb * (size_t)sb->g.cap * sizeof(uint16_t)));
+  sb->values = static_cast<float*>(dev_alloc(nb * (size_t)sb->g.cap * sizeof(float)));
+  if (nullptr == sb->rowidx || nullptr == sb->colidx || nullptr == sb->values) { libxsmm_amd_spmdm_batch_destroy(sb); return nullptr; }
+  return sb;
+}
+
+LIBXSMM_API void libxsmm_amd_spmdm_batch_destroy(libxsmm_amd_spmdm_batch* sb)
+{
+  if (nullptr == sb) return;
+  if (device_ready()) (void)stream_sync();
+  dev_free(sb->rowidx); dev_free(sb->colidx); dev_free(sb->values);
+  free(sb);
+}
+
+LIBXSMM_API int libxsmm_amd_spmdm_batch_create_slices(libxsmm_amd_spmdm_batch* sb, char transa, const float* a)
+{
+  if (nullptr == sb || nullptr == a || !is_device_ptr(a)) return EXIT_FAILURE;
+  const char* name = "";
+  const int e = launch_spmdm_create(sb->g, ('T' == transa || 't' == transa) ? 1 : 0, a, sb->rowidx, sb->colidx, sb->values, device().stream, &name);
+  note_launch(name);
+  return 0 == e ? EXIT_SUCCESS : EXIT_FAILURE;
+}
+
+LIBXSMM_API int libxsmm_amd_spmdm_batch_compute(libxsmm_amd_spmdm_batch* sb, char transb, const float* b,
+  char transc, const float* beta, float* c)
+{
+  if (nullptr == sb || nullptr == b || nullptr == c || nullptr == beta || !is_device_ptr(b) || !is_device_ptr(c)) return EXIT_FAILURE;
+  const char* name = "";
+  const int e = launch_spmdm_compute(sb->g, ('T' == transb || 't' == transb) ? 1 : 0, ('T' == transc || 't' == transc) ? 1 : 0, *beta,
+    sb->rowidx, sb->colidx, sb->values, b, c, device().stream, &name);
+  note_launch(name);
+  return 0 == e ? EXIT_SUCCESS : EXIT_FAILURE;
+}
+
+LIBXSMM_API int libxsmm_amd_spmdm_batch_get_slice(const libxsmm_amd_spmdm_batch* sb, long long item,
+  uint16_t* rowidx, uint16_t* colidx, float* values, int capacity)
+{
+  if (nullptr == sb || item < 0 || item >= sb->g.batch || nullptr == rowidx) return EXIT_FAILURE;
+  if (0 != d2h(rowidx, sb->rowidx + item * (sb->g.m + 1), ((size_t)sb->g.m + 1) * sizeof(uint16_t))) return EXIT_FAILURE;
+  const int nnz = rowidx[sb->g.m];
+  const int ncopy = LIBXSMM_MIN(nnz, capacity);
+  if (nullptr != colidx && 0 < ncopy && 0 != d2h(colidx, sb->colidx + item * sb->g.cap, (size_t)ncopy * sizeof(uint16_t))) return EXIT_FAILURE;
+  if (nullptr != values && 0 < ncopy && 0 != d2h(values, sb->values + item * sb->g.cap, (size_t)ncopy * sizeof(float))) return EXIT_FAILURE;
+  return EXIT_SUCCESS;
+}

@@ -1,0 +1,43 @@
+import importlib
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def xs():
+    """the product's ctypes binding (libxsmm-1_amd/__init__.py); builds lib/libxsmm.so if it is missing"""
+    mod = importlib.import_module("libxsmm-1_amd")
+    if not os.path.exists(mod.LIB_PATH):
+        mod.build()
+    mod.lib()
+    return mod
+
+
+@pytest.fixture(scope="session")
+def orc():
+    """the CPU oracle binding (test infrastructure)"""
+    import oracle_binding
+    oracle_binding.lib()
+    return oracle_binding
+
+
+@pytest.fixture(scope="session")
+def torch_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    torch.cuda.set_device(0)
+    return torch

@@ -1,0 +1,316 @@
+"""GPU parity of the batched dense SMM path, through the C-ABI, against the CPU oracle.
+
+Mirrors how the reference tests this path: tests/gemm.c (shape table :75-82, NaN-filled C for beta=0 :159-167) and
+samples/smm/specialized.cpp (MATINIT inputs :143-146, direct kernel calls vs libxsmm_gemm_batch, CHECK :224-238).
+Bar: the scalar-FMA kernels must equal the oracle's k-ordered fma chain bit for bit; the MFMA kernels must be within
+1e-6 (fp32) / 1e-12 (fp64) relative (north_star tolerance).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = {np.float32: 1e-6, np.float64: 1e-12}
+
+
+def rel_err(ref, tst):
+    den = np.max(np.abs(ref))
+    return float(np.max(np.abs(ref.astype(np.float64) - tst.astype(np.float64))) / (den if den > 0 else 1.0))
+
+
+def make_inputs(rng, dtype, batch, m, n, k, lda, ldb, ldc, transb, matinit, orc):
+    asz, bsz, csz = lda * k, ldb * (k if transb else n), ldc * n
+    if matinit:  # samples/smm/specialized.cpp:143-146: seeds 42+i / 24+i / 22+i, scale 1/batch
+        a = np.concatenate([orc.matinit(42 + i, m, k, lda, 1.0 / batch, dtype) for i in range(batch)])
+        b = np.concatenate([orc.matinit(24 + i, (k if not transb else n), (n if not transb else k), ldb, 1.0 / batch, dtype) for i in range(batch)])
+        c = np.concatenate([orc.matinit(22 + i, m, n, ldc, 1.0 / batch, dtype) for i in range(batch)])
+    else:
+        a = rng.uniform(-1, 1, batch * asz).astype(dtype)
+        b = rng.uniform(-1, 1, batch * bsz).astype(dtype)
+        c = rng.uniform(-1, 1, batch * csz).astype(dtype)
+    return a, b, c, asz, bsz, csz
+
+
+SHAPES = [  # (m, n, k, lda, ldb, ldc) -- includes rows of the reference's table tests/gemm.c:75-82
+    (23, 23, 23, 23, 23, 23), (32, 32, 32, 32, 32, 32), (13, 13, 13, 13, 13, 13), (1, 1, 1, 1, 1, 1),
+    (3, 5, 7, 3, 7, 3), (64, 64, 64, 64, 64, 64), (16, 35, 35, 96, 35, 96), (23, 29, 31, 32, 32, 32),
+    (64, 8, 24, 64, 24, 64), (8, 64, 24, 8, 24, 8), (43, 9, 27, 48, 32, 48), (5, 13, 70, 5, 70, 5),
+    (80, 40, 16, 80, 16, 80), (13, 23, 32, 13, 32, 13), (32, 13, 23, 32, 23, 32),
+]
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("beta", [1.0, 0.0])
+def test_strided_batch_bitexact(xs, orc, torch_gpu, dtype, shape, beta):
+    torch = torch_gpu
+    m, n, k, lda, ldb, ldc = shape
+    batch = 37
+    rng = np.random.default_rng(1234 + m * 7 + n * 3 + k)
+    a, b, c, asz, bsz, csz = make_inputs(rng, dtype, batch, m, n, k, lda, ldb, ldc, False, False, orc)
+    if beta == 0.0:
+        c[:] = np.nan  # reads of C would poison the result (tests/gemm.c:159-167)
+        for i in range(batch):  # padding rows (ldc > m) are never written: keep them finite for the comparison
+            blk = c[i * csz:(i + 1) * csz].reshape(n, ldc)
+            blk[:, m:] = 0.5
+    prec = xs.F64 if dtype == np.float64 else xs.F32
+    flags = xs.FLAG_BETA_0 if beta == 0.0 else 0
+    ref = c.copy()
+    orc.gemm_batch_strided(orc.FMA, flags, m, n, k, lda, ldb, ldc, a, b, ref, asz, bsz, csz, batch)
+    old = xs.lib().libxsmm_amd_set_mfma(0)
+    try:
+        da, db, dc = (torch.from_numpy(x).cuda() for x in (a, b, c))
+        blob, desc = xs.descriptor(prec, m, n, k, lda, ldb, ldc, 1.0, beta)
+        assert desc
+        rc = xs.lib().libxsmm_amd_gemm_batch_strided(desc, xs.dptr(da), xs.dptr(db), xs.dptr(dc), asz, bsz, csz, batch)
+        assert rc == 0
+        torch.cuda.synchronize()
+        out = dc.cpu().numpy()
+    finally:
+        xs.lib().libxsmm_amd_set_mfma(old)
+    assert xs.last_kernel().startswith("smm_")
+    assert np.array_equal(out, ref), "max diff %g (kernel %s)" % (np.nanmax(np.abs(out - ref)), xs.last_kernel())
+
+
+@pytest.mark.parametrize("beta", [1.0, 0.0])
+@pytest.mark.parametrize("mfma", [0, 1])
+def test_smm32_f32_special(xs, orc, torch_gpu, beta, mfma):
+    """BASELINE config 2 shape (fp32 32^3, tight) through the tuned kernels, MFMA off (exact) and on (tolerance)."""
+    torch = torch_gpu
+    m = n = k = 32
+    batch = 4099  # not a multiple of anything
+    rng = np.random.default_rng(7)
+    a, b, c, asz, bsz, csz = make_inputs(rng, np.float32, batch, m, n, k, m, k, m, False, False, orc)
+    if beta == 0.0:
+        c[:] = np.nan
+    ref = c.copy()
+    flags = xs.FLAG_BETA_0 if beta == 0.0 else 0
+    orc.gemm_batch_strided(orc.FMA, flags, m, n, k, m, k, m, a, b, ref, asz, bsz, csz, batch, 8)
+    old = xs.lib().libxsmm_amd_set_mfma(mfma)
+    try:
+        da, db, dc = (torch.from_numpy(x).cuda() for x in (a, b, c))
+        blob, desc = xs.descriptor(xs.F32, m, n, k, m, k, m, 1.0, beta)
+        assert 0 == xs.lib().libxsmm_amd_gemm_batch_strided(desc, xs.dptr(da), xs.dptr(db), xs.dptr(dc), asz, bsz, csz, batch)
+        torch.cuda.synchronize()
+        out = dc.cpu().numpy()
+    finally:
+        xs.lib().libxsmm_amd_set_mfma(old)
+    assert xs.last_kernel() == ("smm_f32_32x32x32_mfma" if mfma else "smm_f32_32x32x32_fma")
+    if mfma:
+        assert rel_err(ref, out) <= TOL[np.float32]
+    else:
+        assert np.array_equal(out, ref)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("index_base", [0, 1])
+def test_index_arrays_match_reference_walk(xs, orc, torch_gpu, dtype, index_base):
+    """libxsmm_gemm_batch with index arrays (src/libxsmm_gemm.c:1333-1364): shuffled A/B, distinct C, shared B via NULL."""
+    torch = torch_gpu
+    m, n, k = 23, 23, 23
+    batch = 1024  # BASELINE config 1 shape
+    rng = np.random.default_rng(5)
+    a, b, c, asz, bsz, csz = make_inputs(rng, dtype, batch, m, n, k, m, k, m, False, True, orc)
+    perm_a, perm_b, perm_c = rng.permutation(batch), rng.permutation(batch), np.arange(batch)
+    sa = (perm_a * asz + index_base).astype(np.int32)
+    sb = (perm_b * bsz + index_base).astype(np.int32)
+    sc = (perm_c * csz + index_base).astype(np.int32)
+    prec = xs.F64 if dtype == np.float64 else xs.F32
+    for stride_b in (sb, None):
+        ref = c.copy()
+        assert 0 == orc.gemm_batch_idx(orc.FMA, 0, m, n, k, m, k, m, a, b, ref, index_base, sa, stride_b, sc, batch)
+        old = xs.lib().libxsmm_amd_set_mfma(0)
+        try:
+            da, db, dc = (torch.from_numpy(x).cuda() for x in (a, b, c))
+            # index arrays once on the host, once on the device
+            for on_device in (False, True):
+                dc.copy_(torch.from_numpy(c))
+                ia = torch.from_numpy(sa).cuda() if on_device else sa
+                ib = None if stride_b is None else (torch.from_numpy(stride_b).cuda() if on_device else stride_b)
+                ic = torch.from_numpy(sc).cuda() if on_device else sc
+                xs.gemm_batch(prec, "N", "N", m, n, k, 1.0, da, m, db, k, 1.0, dc, m, index_base, 4, ia, ib, ic, batch)
+                torch.cuda.synchronize()
+                assert np.array_equal(dc.cpu().numpy(), ref)
+        finally:
+            xs.lib().libxsmm_amd_set_mfma(old)
+
+
+def test_pointer_arrays_and_groups(xs, orc, torch_gpu):
+    """index_stride == 0: arrays of pointers (src/libxsmm_gemm.c:1426-1461) and libxsmm_dgemm_batch groups (:1231-1246)."""
+    torch = torch_gpu
+    rng = np.random.default_rng(11)
+    groups = [(13, 13, 13, 40), (23, 13, 32, 25), (32, 32, 32, 30)]
+    mats, ptrs, refs = [], [], []
+    tot = sum(g[3] for g in groups)
+    pa = np.zeros(tot, dtype=np.uint64); pb = np.zeros(tot, dtype=np.uint64); pc = np.zeros(tot, dtype=np.uint64)
+    ha, hb, hc = [], [], []
+    j = 0
+    for (m, n, k, cnt) in groups:
+        for _ in range(cnt):
+            a = rng.uniform(-1, 1, m * k); b = rng.uniform(-1, 1, k * n); c = rng.uniform(-1, 1, m * n)
+            ha.append(a); hb.append(b); hc.append(c)
+            da, db, dc = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), torch.from_numpy(c).cuda()
+            mats.append((da, db, dc))
+            pa[j], pb[j], pc[j] = da.data_ptr(), db.data_ptr(), dc.data_ptr()
+            ref = c.copy(); orc.smm(orc.FMA, 0, m, n, k, m, k, m, a, b, ref); refs.append(ref)
+            j += 1
+    ng = len(groups)
+    ta = (C.c_char * ng)(*[b"N"] * ng); tb = (C.c_char * ng)(*[b"N"] * ng)
+    ms = (C.c_int * ng)(*[g[0] for g in groups]); ns = (C.c_int * ng)(*[g[1] for g in groups]); ks = (C.c_int * ng)(*[g[2] for g in groups])
+    ldas = (C.c_int * ng)(*[g[0] for g in groups]); ldbs = (C.c_int * ng)(*[g[2] for g in groups]); ldcs = (C.c_int * ng)(*[g[0] for g in groups])
+    al = (C.c_double * ng)(*[1.0] * ng); be = (C.c_double * ng)(*[1.0] * ng)
+    gs = (C.c_int * ng)(*[g[3] for g in groups]); gc = C.c_int(ng)
+    old = xs.lib().libxsmm_amd_set_mfma(0)
+    try:
+        xs.lib().libxsmm_dgemm_batch(ta, tb, ms, ns, ks, al, xs.dptr(pa), ldas, xs.dptr(pb), ldbs, be, xs.dptr(pc), ldcs, C.byref(gc), gs)
+        torch.cuda.synchronize()
+    finally:
+        xs.lib().libxsmm_amd_set_mfma(old)
+    for (da, db, dc), ref in zip(mats, refs):
+        assert np.array_equal(dc.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_shared_c_runs_accumulate_in_batch_order(xs, orc, torch_gpu, dtype):
+    """CP2K-style stacks (samples/cp2k/cp2k.cpp:328-360): consecutive products update the same C; the sequential
+    reference accumulates them in batch order -- the run kernel must give the identical chain."""
+    torch = torch_gpu
+    m, n, k = 23, 23, 23
+    batch, nc = 600, 17
+    rng = np.random.default_rng(3)
+    a = rng.uniform(-1, 1, batch * m * k).astype(dtype); b = rng.uniform(-1, 1, batch * k * n).astype(dtype)
+    c = rng.uniform(-1, 1, nc * m * n).astype(dtype)
+    cidx = np.sort(rng.integers(0, nc, batch))  # non-decreasing => runs
+    sa = (np.arange(batch) * m * k).astype(np.int32); sb = (np.arange(batch) * k * n).astype(np.int32); sc = (cidx * m * n).astype(np.int32)
+    ref = c.copy()
+    orc.gemm_batch_idx(orc.FMA, 0, m, n, k, m, k, m, a, b, ref, 0, sa, sb, sc, batch)
+    prec = xs.F64 if dtype == np.float64 else xs.F32
+    old = xs.lib().libxsmm_amd_set_mfma(0)
+    try:
+        da, db, dc = (torch.from_numpy(x).cuda() for x in (a, b, c))
+        xs.gemm_batch(prec, "N", "N", m, n, k, 1.0, da, m, db, k, 1.0, dc, m, 0, 4, sa, sb, sc, batch)
+        torch.cuda.synchronize()
+        out = dc.cpu().numpy()
+    finally:
+        xs.lib().libxsmm_amd_set_mfma(old)
+    assert np.array_equal(out, ref)
+
+
+def test_unsorted_duplicate_c_uses_atomics_within_tolerance(xs, orc, torch_gpu):
+    torch = torch_gpu
+    m, n, k = 16, 16, 16
+    batch, nc = 500, 11
+    rng = np.random.default_rng(9)
+    a = rng.uniform(-1, 1, batch * m * k); b = rng.uniform(-1, 1, batch * k * n); c = rng.uniform(-1, 1, nc * m * n)
+    cidx = rng.integers(0, nc, batch)
+    sa = (np.arange(batch) * m * k).astype(np.int32); sb = (np.arange(batch) * k * n).astype(np.int32); sc = (cidx * m * n).astype(np.int32)
+    ref = c.copy()
+    orc.gemm_batch_idx(orc.FMA, 0, m, n, k, m, k, m, a, b, ref, 0, sa, sb, sc, batch)
+    da, db, dc = (torch.from_numpy(x).cuda() for x in (a, b, c))
+    xs.gemm_batch(xs.F64, "N", "N", m, n, k, 1.0, da, m, db, k, 1.0, dc, m, 0, 4, sa, sb, sc, batch)
+    torch.cuda.synchronize()
+    assert rel_err(ref, dc.cpu().numpy()) <= 1e-12
+
+
+def test_trans_b_and_general_fallback(xs, orc, torch_gpu):
+    """TRANS_B is an SMM kernel (src/generator_gemm.c:219-223); alpha/beta outside {1}/{0,1} and TRANS_A are the BLAS
+    fall-back domain of libxsmm_mmbatch (src/libxsmm_gemm.c:1842-1866) -- served by the general device kernel."""
+    torch = torch_gpu
+    m, n, k, batch = 20, 12, 28, 33
+    rng = np.random.default_rng(2)
+    a = rng.uniform(-1, 1, batch * m * k); bt = rng.uniform(-1, 1, batch * n * k); c = rng.uniform(-1, 1, batch * m * n)
+    ref = c.copy()
+    orc.gemm_batch_strided(orc.FMA, orc.FLAG_TRANS_B, m, n, k, m, n, m, a, bt, ref, m * k, n * k, m * n, batch)
+    sa = (np.arange(batch) * m * k).astype(np.int32); sb = (np.arange(batch) * n * k).astype(np.int32); sc = (np.arange(batch) * m * n).astype(np.int32)
+    old = xs.lib().libxsmm_amd_set_mfma(0)
+    try:
+        da, db, dc = (torch.from_numpy(x).cuda() for x in (a, bt, c))
+        xs.gemm_batch(xs.F64, "N", "T", m, n, k, 1.0, da, m, db, n, 1.0, dc, m, 0, 4, sa, sb, sc, batch)
+        torch.cuda.synchronize()
+        assert np.array_equal(dc.cpu().numpy(), ref)
+        # general: C = 0.5*A^T*B^T - 2*C, against numpy
+        at = rng.uniform(-1, 1, batch * k * m)
+        c2 = rng.uniform(-1, 1, batch * m * n)
+        A = at.reshape(batch, m, k)           # column-major k x m  == row-major (m,k): A^T[m][k]
+        B = bt.reshape(batch, k, n)           # column-major n x k (ld n) == row-major (k,n): B^T[k][n]
+        Cm = c2.reshape(batch, n, m).transpose(0, 2, 1)
+        expect = 0.5 * np.einsum("bmk,bkn->bmn", A, B) - 2.0 * Cm
+        dat, dc2 = torch.from_numpy(at).cuda(), torch.from_numpy(c2).cuda()
+        sat = (np.arange(batch) * k * m).astype(np.int32)
+        xs.gemm_batch(xs.F64, "T", "T", m, n, k, 0.5, dat, k, db, n, -2.0, dc2, m, 0, 4, sat, sb, sc, batch)
+        torch.cuda.synchronize()
+        got = dc2.cpu().numpy().reshape(batch, n, m).transpose(0, 2, 1)
+        assert np.max(np.abs(got - expect)) <= 1e-12 * max(1.0, np.max(np.abs(expect)))
+    finally:
+        xs.lib().libxsmm_amd_set_mfma(old)
+
+
+def test_dispatched_kernel_pointer_call_device_and_host(xs, orc, torch_gpu):
+    """A dispatched kernel is a bare function pointer called as f(a,b,c[,pa,pb,pc]) (samples/smm/specialized.cpp:172-190):
+    works on device operands (asynchronous) and on plain host memory (staged)."""
+    torch = torch_gpu
+    m, n, k = 23, 23, 23
+    a = orc.matinit(42, m, k, m, 1.0, np.float64); b = orc.matinit(24, k, n, k, 1.0, np.float64); c = orc.matinit(22, m, n, m, 1.0, np.float64)
+    ref = c.copy(); orc.smm(orc.FMA, 0, m, n, k, m, k, m, a, b, ref)
+    fn = xs.lib().libxsmm_dmmdispatch(m, n, k, None, None, None, None, None, None, None)
+    assert fn
+    assert fn == xs.lib().libxsmm_dmmdispatch(m, n, k, None, None, None, None, None, None, None)  # registry hit: same pointer
+    old = xs.lib().libxsmm_amd_set_mfma(0)
+    try:
+        da, db, dc = (torch.from_numpy(x).cuda() for x in (a, b, c))
+        xs.call_kernel(fn, da, db, dc)
+        torch.cuda.synchronize()
+        assert np.array_equal(dc.cpu().numpy(), ref)
+        hc = c.copy()
+        xs.call_kernel(fn, a, b, hc)  # host pointers: synchronous
+        assert np.array_equal(hc, ref)
+    finally:
+        xs.lib().libxsmm_amd_set_mfma(old)
+
+
+def test_batch_reduce_kernel(xs, orc, torch_gpu):
+    """libxsmm_dmmdispatch_reducebatch (src/libxsmm_main.c:2262-2276): C += sum_i A_i*B_i, one chain in batch order."""
+    torch = torch_gpu
+    m, n, k, cnt = 32, 13, 23, 9
+    rng = np.random.default_rng(4)
+    As = [rng.uniform(-1, 1, m * k) for _ in range(cnt)]; Bs = [rng.uniform(-1, 1, k * n) for _ in range(cnt)]
+    c = rng.uniform(-1, 1, m * n)
+    ref = c.copy(); orc.smm_reduce(orc.FMA, 0, m, n, k, m, k, m, As, Bs, ref)
+    fn = xs.lib().libxsmm_dmmdispatch_reducebatch(m, n, k, None, None, None, None, None, None, None)
+    assert fn
+    dA = [torch.from_numpy(x).cuda() for x in As]; dB = [torch.from_numpy(x).cuda() for x in Bs]; dc = torch.from_numpy(c).cuda()
+    pa = np.array([t.data_ptr() for t in dA], dtype=np.uint64); pb = np.array([t.data_ptr() for t in dB], dtype=np.uint64)
+    count = np.array([cnt], dtype=np.uint64)
+    old = xs.lib().libxsmm_amd_set_mfma(0)
+    try:
+        xs.call_kernel(fn, pa, pb, dc, count)
+        torch.cuda.synchronize()
+    finally:
+        xs.lib().libxsmm_amd_set_mfma(old)
+    assert np.array_equal(dc.cpu().numpy(), ref)
+
+
+def test_host_operands_are_staged(xs, orc, torch_gpu):
+    """An unchanged CPU caller passes malloc'ed memory: libxsmm_gemm_batch must still produce the reference result."""
+    m, n, k, batch = 13, 13, 13, 200
+    rng = np.random.default_rng(8)
+    a = rng.uniform(-1, 1, batch * m * k); b = rng.uniform(-1, 1, batch * k * n); c = rng.uniform(-1, 1, batch * m * n)
+    sa = (np.arange(batch) * m * k).astype(np.int32); sb = (np.arange(batch) * k * n).astype(np.int32); sc = (np.arange(batch) * m * n).astype(np.int32)
+    ref = c.copy(); orc.gemm_batch_idx(orc.FMA, 0, m, n, k, m, k, m, a, b, ref, 0, sa, sb, sc, batch)
+    old = xs.lib().libxsmm_amd_set_mfma(0)
+    try:
+        out = c.copy()
+        xs.gemm_batch(xs.F64, "N", "N", m, n, k, 1.0, a, m, b, k, 1.0, out, m, 0, 4, sa, sb, sc, batch)
+        assert np.array_equal(out, ref)
+        # pointer arrays of host matrices
+        out2 = c.copy()
+        pa = np.array([a.ctypes.data + 8 * i * m * k for i in range(batch)], dtype=np.uint64)
+        pb = np.array([b.ctypes.data + 8 * i * k * n for i in range(batch)], dtype=np.uint64)
+        pc = np.array([out2.ctypes.data + 8 * i * m * n for i in range(batch)], dtype=np.uint64)
+        eight = np.array([8], dtype=np.int32)
+        xs.gemm_batch(xs.F64, "N", "N", m, n, k, 1.0, pa, m, pb, k, 1.0, pc, m, 0, 0, eight, eight, eight, batch)
+        assert np.array_equal(out2, ref)
+    finally:
+        xs.lib().libxsmm_amd_set_mfma(old)

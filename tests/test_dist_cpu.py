@@ -1,0 +1,81 @@
+"""N>1 path on CPUs: world_size-2 gloo processes shard the batch exactly as bench.py / the GPU ranks do, all-gather
+their C shards (config-4 epilogue) and sum-reduce partial C blocks (config-5 epilogue). The per-shard arithmetic is done
+by the oracle here (tests may use it); what is under test is the sharding and collective plumbing in libxsmm-1_amd/dist.py.
+"""
+import importlib
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, tmpdir):
+    os.environ.update({"RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_RANK": str(rank), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import oracle_binding as orc
+    dist_mod = importlib.import_module("libxsmm-1_amd.dist")
+    r, w, dist = dist_mod.init("gloo")
+    assert (r, w) == (rank, world)
+    m = n = k = 13
+    batch = 101  # not divisible by the world size
+    rng = np.random.default_rng(5)
+    a = rng.uniform(-1, 1, batch * m * k); b = rng.uniform(-1, 1, batch * k * n); c = rng.uniform(-1, 1, batch * m * n)
+    full = c.copy(); orc.gemm_batch_strided(orc.FMA, 0, m, n, k, m, k, m, a, b, full, m * k, k * n, m * n, batch)
+    # ---- independent items: shard, compute, all-gather C ----
+    b0, b1 = dist_mod.shard_range(batch, rank, world)
+    mine = c[b0 * m * n:b1 * m * n].copy()
+    orc.gemm_batch_strided(orc.FMA, 0, m, n, k, m, k, m, a[b0 * m * k:], b[b0 * k * n:], mine, m * k, k * n, m * n, b1 - b0)
+    gathered = dist_mod.allgather_shards(torch.from_numpy(mine), batch, dist).numpy()
+    assert np.array_equal(gathered, full)
+    # ---- reduction: 7 C blocks, products of one block split over the ranks => partial sums + all-reduce ----
+    nc = 7
+    cid = np.sort(rng.integers(0, nc, batch))
+    cblocks = rng.uniform(-1, 1, nc * m * n)
+    sa = (np.arange(batch) * m * k).astype(np.int32); sb = (np.arange(batch) * k * n).astype(np.int32); sc = (cid * m * n).astype(np.int32)
+    ref = cblocks.copy(); orc.gemm_batch_idx(orc.FMA, 0, m, n, k, m, k, m, a, b, ref, 0, sa, sb, sc, batch)
+    part = np.zeros_like(cblocks)
+    orc.gemm_batch_idx(orc.FMA, 0, m, n, k, m, k, m, a, b, part, 0, sa[b0:b1], sb[b0:b1], sc[b0:b1], b1 - b0)
+    total = dist_mod.reduce_partial_c(torch.from_numpy(part), dist).numpy() + cblocks
+    assert np.max(np.abs(total - ref)) <= 1e-12 * np.max(np.abs(ref))
+    # ---- ownership partition: no exchange at all ----
+    owned = dist_mod.shard_by_c_owner(cid, world)
+    assert sorted(i for lst in owned for i in lst) == list(range(batch))
+    mine_idx = np.array(owned[rank], dtype=np.int64)
+    own = cblocks.copy()
+    if len(mine_idx):
+        orc.gemm_batch_idx(orc.FMA, 0, m, n, k, m, k, m, a, b, own, 0, sa[mine_idx], sb[mine_idx], sc[mine_idx], len(mine_idx))
+    for blk in set(int(x) for x in cid[mine_idx]):
+        assert np.array_equal(own[blk * m * n:(blk + 1) * m * n], ref[blk * m * n:(blk + 1) * m * n])  # bit-exact: order kept
+    t = dist_mod.max_over_ranks(1.0 + rank, dist)
+    assert t == float(world)
+    dist.barrier()
+    dist.destroy_process_group()
+    open(os.path.join(tmpdir, "ok%d" % rank), "w").write("ok")
+
+
+def test_two_rank_gloo_shard_gather_reduce(tmp_path, orc):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert os.path.exists(tmp_path / "ok0") and os.path.exists(tmp_path / "ok1")
+
+
+def test_shard_range_properties():
+    dist_mod = importlib.import_module("libxsmm-1_amd.dist")
+    for n in (0, 1, 7, 8, 1048576, 1048577):
+        for world in (1, 2, 3, 8):
+            spans = [dist_mod.shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            assert max(e - b for b, e in spans) - min(e - b for b, e in spans) <= (n + world - 1) // world

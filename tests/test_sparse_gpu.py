@@ -1,0 +1,244 @@
+"""GPU parity of the sparse paths (fsspmdm, csr_reg kernels, spmdm) through the C-ABI against the CPU oracle.
+
+Reference self-checks mirrored here: samples/pyfr/pyfr_driver_asp_reg.c:275-347 (CSR gold loop, beta=0 and beta=1, operator
+matrices from samples/pyfr/mats), samples/spmdm/spmdm.c:212-224,274-301 (inputs keep a value iff r > 0.85, naive gold,
+NN / TN+transC / NT variants). Index structures (CSR slices) must be bit-exact; values follow the same fma chains as the
+oracle, so they are compared for equality as well.
+"""
+import ctypes as C
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def palette_operator(rng, M, K, density, nvalues):
+    pal = np.array([0.25, -0.5, 0.75, 1.0, -1.25, 1.5, -2.0, 3.0, -0.125, 0.0625][:nvalues])
+    return np.where(rng.random((M, K)) < density, pal[rng.integers(0, nvalues, (M, K))], 0.0)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("beta", [1.0, 0.0])
+@pytest.mark.parametrize("unique", ["palette", "random"])
+def test_fsspmdm_synthetic(xs, orc, torch_gpu, dtype, beta, unique):
+    """BASELINE config 3 operator shape (M=K=35, ~15% nnz, N=96 panels). palette -> the reference's csr_reg path,
+    random values -> its dense fallback; both follow the same per-element chain as the device kernel."""
+    torch = torch_gpu
+    M, K, N, panels = 35, 35, 96, 7
+    rng = np.random.default_rng(1)
+    A = palette_operator(rng, M, K, 0.15, 7) if unique == "palette" else np.where(rng.random((M, K)) < 0.15, rng.uniform(-1, 1, (M, K)), 0.0)
+    A[5, :] = 0.0  # a row without non-zeros (the beta == 0 quirk row)
+    A = np.ascontiguousarray(A.astype(dtype))
+    ntot = N * panels
+    B = rng.uniform(-1, 1, (K, ntot)).astype(dtype)
+    Cin = rng.uniform(-1, 1, (M, ntot)).astype(dtype)
+    ref = Cin.copy()
+    h = orc.Fsspmdm(A, M, N, K, K, ntot, ntot, 1.0, beta, have_avx512=True)
+    assert h.sparse() == (1 if unique == "palette" else 0)
+    for p in range(panels):  # pyfr_driver_asp_reg.c:295-309: execute(handle, B + i*N, C + i*N)
+        h.execute(B.reshape(-1)[p * N:], ref.reshape(-1)[p * N:])
+    h.close()
+    L = xs.lib()
+    create = L.libxsmm_dfsspmdm_create if dtype == np.float64 else L.libxsmm_sfsspmdm_create
+    execute = L.libxsmm_dfsspmdm_execute if dtype == np.float64 else L.libxsmm_sfsspmdm_execute
+    execb = L.libxsmm_amd_dfsspmdm_execute_batch if dtype == np.float64 else L.libxsmm_amd_sfsspmdm_execute_batch
+    destroy = L.libxsmm_dfsspmdm_destroy if dtype == np.float64 else L.libxsmm_sfsspmdm_destroy
+    hd = create(M, N, K, K, ntot, ntot, 1.0, beta, xs.dptr(A))
+    assert hd
+    dB = torch.from_numpy(B).cuda()
+    # (1) panel by panel through the reference entry point, (2) all panels in one batch launch
+    for batched in (False, True):
+        dC = torch.from_numpy(Cin).cuda()
+        if batched:
+            assert 0 == execb(hd, xs.dptr(dB), xs.dptr(dC), panels)
+        else:
+            es = dC.element_size()
+            for p in range(panels):
+                execute(hd, C.c_void_p(dB.data_ptr() + p * N * es), C.c_void_p(dC.data_ptr() + p * N * es))
+        torch.cuda.synchronize()
+        out = dC.cpu().numpy()
+        assert xs.last_kernel().startswith("fsspmdm_")
+        rows = [r for r in range(M) if r != 5]
+        assert np.array_equal(out[rows], ref[rows])
+        if beta == 0.0:  # empty row: zeroed (the dense fallback's result); the reference's csr_reg path leaves it untouched
+            assert np.all(out[5] == 0.0)
+            assert np.array_equal(ref[5], Cin[5]) if unique == "palette" else np.all(ref[5] == 0.0)
+        else:
+            assert np.array_equal(out[5], Cin[5])
+    destroy(hd)
+
+
+def test_fsspmdm_pyfr_operators_sparse_equals_dense(xs, orc, torch_gpu):
+    """Fixtures the reference holds: each PyFR operator exists as a sparse (-sp.mtx) and a dense (-de.mtx) file
+    (samples/pyfr/mats). The operator read through the CSR reader and applied by fsspmdm must agree with the dense
+    file applied as a plain GEMM -- on the oracle and on the device."""
+    torch = torch_gpu
+    files = sorted(glob.glob(os.path.join(GOLDEN, "mtx", "pyfr", "*-sp.mtx")))
+    assert len(files) >= 8
+    rng = np.random.default_rng(3)
+    N = 96
+    for sp in files:
+        rowptr, colidx, vals, rows, cols, nnz = orc.read_csr(sp)
+        dense = orc.read_dense_mtx(sp.replace("-sp.mtx", "-de.mtx"))
+        assert dense.shape == (rows, cols)
+        A = np.zeros((rows, cols))
+        for r in range(rows):
+            for q in range(rowptr[r], rowptr[r + 1]):
+                A[r, colidx[q]] = vals[q]
+        # the sparse file drops entries the dense file holds as (near) zeros; the operators agree to rounding of the text format
+        assert np.max(np.abs(A - dense)) <= 1e-10 * max(1.0, np.max(np.abs(dense)))
+        B = rng.uniform(-1, 1, (cols, N)); Cin = rng.uniform(-1, 1, (rows, N))
+        for beta in (1.0, 0.0):
+            expect = A @ B + beta * Cin
+            hd = xs.lib().libxsmm_dfsspmdm_create(rows, N, cols, cols, N, N, 1.0, beta, xs.dptr(np.ascontiguousarray(A)))
+            assert hd
+            dB, dC = torch.from_numpy(B).cuda(), torch.from_numpy(Cin.copy()).cuda()
+            xs.lib().libxsmm_dfsspmdm_execute(hd, xs.dptr(dB), xs.dptr(dC))
+            torch.cuda.synchronize()
+            got = dC.cpu().numpy()
+            xs.lib().libxsmm_dfsspmdm_destroy(hd)
+            # oracle on the same operator
+            ref = Cin.copy()
+            h = orc.Fsspmdm(np.ascontiguousarray(A), rows, N, cols, cols, N, N, 1.0, beta, have_avx512=False)
+            h.execute(B, ref); h.close()
+            scale = max(1.0, np.max(np.abs(expect)))
+            assert np.max(np.abs(ref - expect)) <= 1e-12 * scale
+            assert np.max(np.abs(got - expect)) <= 1e-12 * scale
+            assert np.array_equal(got, ref)
+
+
+def test_create_csr_reg_kernel_and_limits(xs, orc, torch_gpu):
+    """libxsmm_create_dcsr_reg / scsr_reg (src/libxsmm_main.c:2523-2582): N must equal the reference's vector length,
+    at most 31 unique values, rows without nnz are not touched; released with libxsmm_release_kernel."""
+    torch = torch_gpu
+    rng = np.random.default_rng(5)
+    M, K = 20, 27
+    A = palette_operator(rng, M, K, 0.2, 6); A[3, :] = 0.0
+    rowptr = np.zeros(M + 1, dtype=np.uint32); cols = []; vals = []
+    for r in range(M):
+        rowptr[r] = len(cols)
+        for c in range(K):
+            if A[r, c] != 0: cols.append(c); vals.append(A[r, c])
+    rowptr[M] = len(cols)
+    colidx = np.array(cols, dtype=np.uint32); values = np.array(vals)
+    for dtype, prec, vlen, creator in ((np.float64, xs.F64, 8, "libxsmm_create_dcsr_reg"), (np.float32, xs.F32, 16, "libxsmm_create_scsr_reg")):
+        ldb, ldc = vlen + 3, vlen + 5
+        for beta in (1.0, 0.0):
+            blob, desc = xs.descriptor(prec, M, vlen, K, 0, ldb, ldc, 1.0, beta)
+            fn = getattr(xs.lib(), creator)(desc, xs.dptr(rowptr), xs.dptr(colidx), xs.dptr(values.astype(dtype)))
+            assert fn
+            B = rng.uniform(-1, 1, (K, ldb)).astype(dtype); Cin = rng.uniform(-1, 1, (M, ldc)).astype(dtype)
+            ref = Cin.copy()
+            assert 0 == orc.csr_reg(orc.FLAG_BETA_0 if beta == 0 else 0, M, vlen, K, ldb, ldc, rowptr, colidx, values.astype(dtype), B, ref)
+            dB, dC = torch.from_numpy(B).cuda(), torch.from_numpy(Cin).cuda()
+            xs.call_kernel(fn, None, dB, dC)
+            torch.cuda.synchronize()
+            assert np.array_equal(dC.cpu().numpy(), ref)       # includes row 3 untouched and the ld padding untouched
+            hC = Cin.copy(); xs.call_kernel(fn, None, B, hC)   # host operands
+            assert np.array_equal(hC, ref)
+            xs.lib().libxsmm_release_kernel(fn)
+        # wrong chunk width and too many unique values => NULL, as in the reference generator
+        blob, desc = xs.descriptor(prec, M, vlen + 1, K, 0, ldb, ldc, 1.0, 1.0)
+        assert not getattr(xs.lib(), creator)(desc, xs.dptr(rowptr), xs.dptr(colidx), xs.dptr(values.astype(dtype)))
+        many = rng.uniform(-1, 1, len(values)).astype(dtype)
+        blob, desc = xs.descriptor(prec, M, vlen, K, 0, ldb, ldc, 1.0, 1.0)
+        assert not getattr(xs.lib(), creator)(desc, xs.dptr(rowptr), xs.dptr(colidx), xs.dptr(many))
+
+
+def spmdm_inputs(M, N, K, keep, seed, orc):
+    """samples/spmdm/spmdm.c:212-243: A first (value kept iff r > threshold), then B, then C, from rng seed 1"""
+    orc.rng_seed(seed)
+    a = np.zeros(M * K, dtype=np.float32)
+    for i in range(M * K):
+        r = orc.rng_f64()
+        a[i] = np.float32(r) if r > keep else 0.0
+    b = np.array([orc.rng_f64() for _ in range(K * N)], dtype=np.float32)
+    c = np.array([orc.rng_f64() for _ in range(M * N)], dtype=np.float32)
+    return a, b, c
+
+
+@pytest.mark.parametrize("variant", [("N", "N", "N"), ("T", "N", "T"), ("N", "T", "N"), ("T", "T", "T")])
+@pytest.mark.parametrize("beta", [0.0, 1.0, 0.5])
+def test_spmdm_reference_api(xs, orc, torch_gpu, variant, beta):
+    """libxsmm_spmdm_init / createSparseSlice_fp32_thread / compute_fp32_thread on one problem that spans several
+    (mb, nb, kb) blocks with ragged edges; call sequence of samples/spmdm/spmdm.c:74-112."""
+    torch = torch_gpu
+    ta, tb, tc = variant
+    M, N, K = 301, 131, 263
+    a, b, c = spmdm_inputs(M, N, K, 0.85, 1, orc)
+    if beta == 0.0:
+        c[:] = np.nan  # beta == 0 never reads C (compute tpl :81-105)
+    ref = c.copy()
+    orc.spmdm_exec(orc.FMA, M, N, K, 48, ta, tb, tc, beta, a, b, ref)
+    L = xs.lib()
+    h = xs.SpmdmHandle(); slices = C.POINTER(xs.CSRSlice)()
+    L.libxsmm_spmdm_init(M, N, K, 1, C.byref(h), C.byref(slices))
+    assert h.m == M and h.n == N and h.k == K and h.mb * h.bm >= M and h.kb * h.bk >= K and h.nb * h.bn >= N
+    da, db, dc = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), torch.from_numpy(c).cuda()
+    alpha, be = C.c_float(1.0), C.c_float(beta)
+    for blk in range(L.libxsmm_spmdm_get_num_createSparseSlice_blocks(C.byref(h))):
+        L.libxsmm_spmdm_createSparseSlice_fp32_thread(C.byref(h), ta.encode(), xs.dptr(da), slices, blk, 0, 1)
+    for blk in range(L.libxsmm_spmdm_get_num_compute_blocks(C.byref(h))):
+        L.libxsmm_spmdm_compute_fp32_thread(C.byref(h), ta.encode(), tb.encode(), C.byref(alpha), slices, xs.dptr(db), tc.encode(),
+                                            C.byref(be), xs.dptr(dc), blk, 0, 1)
+    torch.cuda.synchronize()
+    out = dc.cpu().numpy()
+    L.libxsmm_spmdm_destroy(C.byref(h))
+    assert np.array_equal(out, ref)
+    # and against the sample's own gold: a naive triple loop in float64 (samples/spmdm/spmdm.c:274-297), max abs error
+    if beta == 0.0:
+        A = a.reshape(K, M).T if ta == "T" else a.reshape(M, K)
+        B = b.reshape(N, K).T if tb == "T" else b.reshape(K, N)
+        gold = A.astype(np.float64) @ B.astype(np.float64)
+        got = out.reshape(N, M).T if tc == "T" else out.reshape(M, N)
+        assert np.max(np.abs(got - gold)) <= 1e-4
+
+
+@pytest.mark.parametrize("keep", [0.5, 0.85])
+@pytest.mark.parametrize("variant", [("N", "N", "N"), ("T", "N", "T"), ("N", "T", "N")])
+def test_spmdm_batch_config4(xs, orc, torch_gpu, keep, variant):
+    """BASELINE config 4 problem (M=K=64, N=48) as a batch: CSR slices bit-exact per item, C equal to the oracle."""
+    torch = torch_gpu
+    ta, tb, tc = variant
+    M, N, K, batch = 64, 48, 64, 97
+    rng = np.random.default_rng(17)
+    a = rng.uniform(-1, 1, batch * M * K).astype(np.float32)
+    a[rng.random(batch * M * K) < keep] = 0.0
+    a[0:K] = 0.0                      # an empty first row in item 0
+    a[5 * M * K:6 * M * K] = 0.0      # item 5: all zeros
+    a[7 * M * K + 3] = -0.0           # -0 counts as zero (LIBXSMM_FEQ)
+    a[8 * M * K:9 * M * K] = 1.5      # item 8: fully dense (4096 nnz)
+    b = rng.uniform(-1, 1, batch * K * N).astype(np.float32)
+    L = xs.lib()
+    sb = L.libxsmm_amd_spmdm_batch_create(M, N, K, batch)
+    assert sb
+    da, db = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    assert 0 == L.libxsmm_amd_spmdm_batch_create_slices(sb, ta.encode(), xs.dptr(da))
+    assert xs.last_kernel().startswith("spmdm_create")
+    ri = np.zeros(M + 1, dtype=np.uint16); ci = np.zeros(M * K, dtype=np.uint16); va = np.zeros(M * K, dtype=np.float32)
+    for item in (0, 1, 5, 7, 8, 50, batch - 1):
+        assert 0 == L.libxsmm_amd_spmdm_batch_get_slice(sb, item, xs.dptr(ri), xs.dptr(ci), xs.dptr(va), M * K)
+        hnd, sl = orc.spmdm_slices(M, N, K, 48, ta, a[item * M * K:(item + 1) * M * K])
+        assert hnd.mb == 1 and hnd.kb == 1
+        oi, oc, ov = sl[0]
+        nnz = int(oi[M])
+        assert np.array_equal(ri, oi)
+        assert np.array_equal(ci[:nnz], oc) and np.array_equal(va[:nnz].view(np.uint32), ov.view(np.uint32))
+    for beta in (0.0, 1.0):
+        c = rng.uniform(-1, 1, batch * M * N).astype(np.float32)
+        if beta == 0.0:
+            c[:] = np.nan
+        ref = c.copy()
+        orc.spmdm_exec_batch(orc.FMA, M, N, K, 48, ta, tb, tc, beta, a, b, ref, batch, 4)
+        dc = torch.from_numpy(c).cuda()
+        be = C.c_float(beta)
+        assert 0 == L.libxsmm_amd_spmdm_batch_compute(sb, tb.encode(), xs.dptr(db), tc.encode(), C.byref(be), xs.dptr(dc))
+        torch.cuda.synchronize()
+        assert xs.last_kernel().startswith("spmdm_compute")
+        assert np.array_equal(dc.cpu().numpy(), ref)
+    L.libxsmm_amd_spmdm_batch_destroy(sb)

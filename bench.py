@@ -139,6 +139,15 @@ def main():
                            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                            "launch_ms_avg": round(kms, 4), "launch_ms_min": round(min(per_step), 4),
                            "algorithmic_bytes_per_launch": float(B) * bytes_item}
+        # measured ceiling for this traffic mix: c += a + b over the same three arrays (3 reads : 1 write, no arithmetic)
+        nbytes = B * M * K * 4
+
+        def probe():
+            assert 0 == L.libxsmm_amd_stream_probe(xs.dptr(a), xs.dptr(b), xs.dptr(c), nbytes)
+        _, pt = time_steps(torch, probe, 5, 2, None)
+        ceil = 4.0 * nbytes / (min(pt) * 1e-3) / 1e9
+        out["roofline"]["stream_ceiling_gbs"] = round(ceil, 1)
+        out["roofline"]["frac_of_stream_ceiling"] = round(achieved / ceil, 4)
     if rank == 0 and world == 1 and not args.no_secondary:
         try:
             out["secondary"] = secondary(torch, xs, L)

@@ -43,6 +43,11 @@ LIBXSMM_API const char* libxsmm_amd_last_kernel(void);
 /** Number of device kernel launches issued by this process (monotonic). */
 LIBXSMM_API unsigned long long libxsmm_amd_launch_count(void);
 
+/** Measurement aid: c[i] += a[i] + b[i] over `bytes` bytes per operand (device memory, 16-byte aligned) -- the
+ *  3-read/1-write traffic mix of a beta=1 SMM batch with no arithmetic; bench.py reports its rate as the measured
+ *  streaming ceiling next to the 8 TB/s datasheet peak. */
+LIBXSMM_API int libxsmm_amd_stream_probe(const void* a, const void* b, void* c, long long bytes);
+
 /* ---- batch forms ---------------------------------------------------------------------------- */
 /** Constant-stride batch: item i uses a + i*stride_a, b + i*stride_b, c + i*stride_c (strides in elements,
  *  0 = operand shared). This is the layout of samples/smm/specialized.cpp:143-146,172-190 (contiguous

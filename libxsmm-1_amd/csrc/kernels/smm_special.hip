@@ -5,10 +5,11 @@
 // neighbouring waves stream neighbouring 4 KiB matrices. Per problem: A and B arrive as four 16-byte loads
 // per lane (1 KiB per wave instruction), are parked in the wave's private 8 KiB of LDS, C is read and written
 // directly. The loads of problem i+1 are issued before the arithmetic of problem i (the GPU analogue of the
-// reference's prefetch chaining, src/libxsmm_gemm.c:1348).
+// reference's prefetch chaining, src/libxsmm_gemm.c:1348). Every byte is touched exactly once, so loads and
+// stores carry the non-temporal hint.
 //   "fma"  variant: 4x4 register tile per lane, v_fma_f32, k ascending -- bit-identical to the reference's
 //                   per-element fma chain.
-//   "mfma" variant: v_mfma_f32_32x32x2_f32; the two k of one instruction are (s, 16+s), i.e. the chain per C
+//   "mfma" variants: v_mfma_f32_32x32x2_f32; the two k of one instruction are (s, 16+s), i.e. the chain per C
 //                   element runs k = 0,16,1,17,...; same products, different association (tolerance parity).
 #include "smm_common.cuh"
 
@@ -20,30 +21,45 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ bool aligned16(const void* p) { return 0 == (reinterpret_cast<uintptr_t>(p) & 15); }
 
-// 4 x float4 per lane covering a tight 32x32 fp32 matrix: chunk index c = 64*j + lane (16-byte chunks)
-__device__ __forceinline__ void load_mat32(const float* p, int lane, f32x4 (&r)[4])
+template<bool NT> __device__ __forceinline__ f32x4 ld4(const float* p, bool al)
 {
-  if (aligned16(p)) {
-    const f32x4* const v = reinterpret_cast<const f32x4*>(p);
+  if (al) return NT ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p)) : *reinterpret_cast<const f32x4*>(p);
+  return f32x4{ p[0], p[1], p[2], p[3] }; // operands that are only element-aligned (arbitrary index arrays)
+}
+template<bool NT> __device__ __forceinline__ void st4(float* p, bool al, f32x4 v)
+{
+  if (al) { if (NT) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p)); else *reinterpret_cast<f32x4*>(p) = v; }
+  else { p[0] = v[0]; p[1] = v[1]; p[2] = v[2]; p[3] = v[3]; }
+}
+template<bool NT> __device__ __forceinline__ float ld1(const float* p) { return NT ? __builtin_nontemporal_load(p) : *p; }
+template<bool NT> __device__ __forceinline__ void st1(float* p, float v) { if (NT) __builtin_nontemporal_store(v, p); else *p = v; }
+
+// 4 x float4 per lane covering a tight 32x32 fp32 matrix: chunk index c = 64*j + lane (16-byte chunks)
+template<bool NT> __device__ __forceinline__ void load_mat32(const float* p, int lane, f32x4 (&r)[4])
+{
+  const bool al = aligned16(p);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) r[j] = v[64 * j + lane];
-  }
-  else { // operands that are only element-aligned (arbitrary index arrays)
+  for (int j = 0; j < 4; ++j) r[j] = ld4<NT>(p + 4 * (64 * j + lane), al);
+}
+
+// A linear, B as 16-byte chunks (n, q = k/4) at position n*8 + (q ^ key(n)); key spreads the rows a wave reads
+// at once over different bank groups (KEYSHIFT = 2 for the 4x4-tile reads, 1 for the MFMA operand reads).
+template<int KEYSHIFT> __device__ __forceinline__ void park_ab(float* As, float* Bs, int lane, const f32x4 (&ra)[4], const f32x4 (&rb)[4])
+{
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float* const q = p + 4 * (64 * j + lane);
-      r[j] = f32x4{ q[0], q[1], q[2], q[3] };
-    }
+  for (int j = 0; j < 4; ++j) {
+    const int c = 64 * j + lane;
+    *reinterpret_cast<f32x4*>(As + 4 * c) = ra[j];
+    const int n = c >> 3, q = c & 7;
+    *reinterpret_cast<f32x4*>(Bs + 4 * (n * 8 + (q ^ ((n >> KEYSHIFT) & 7)))) = rb[j];
   }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // scalar-FMA variant. Lane (tx = lane & 7, ty = lane >> 3) owns C rows 4tx..4tx+3 of columns 4ty..4ty+3.
-// LDS image (floats): A linear [k][32]; B as 16-byte chunks (n, q = k/4) at position n*8 + (q ^ ty(n)), ty(n) = n>>2,
-// so the eight distinct B rows a wave touches per read fall into different bank groups.
 // ---------------------------------------------------------------------------------------------------------------
-template<bool BETA0>
-__global__ __launch_bounds__(256)
+template<bool BETA0, bool NT>
+__global__ __launch_bounds__(256, 4)
 void smm32_f32_fma_kernel(DevAddr ad, long long batch)
 {
   __shared__ __align__(16) float lds[4][2048];
@@ -55,50 +71,34 @@ void smm32_f32_fma_kernel(DevAddr ad, long long batch)
   if (w >= batch) return;
 
   f32x4 ra[4], rb[4], rc[4];
-  {
-    load_mat32(addr_a<float>(ad, w), lane, ra);
-    load_mat32(addr_b<float>(ad, w), lane, rb);
-    if (!BETA0) {
-      const float* const pc = addr_c<float>(ad, w);
-      const bool al = aligned16(pc);
+  load_mat32<NT>(addr_a<float>(ad, w), lane, ra);
+  load_mat32<NT>(addr_b<float>(ad, w), lane, rb);
+  if (!BETA0) {
+    const float* const pc = addr_c<float>(ad, w) + 4 * ty * 32 + 4 * tx;
+    const bool al = aligned16(pc);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float* const q = pc + (4 * ty + j) * 32 + 4 * tx;
-        rc[j] = al ? *reinterpret_cast<const f32x4*>(q) : f32x4{ q[0], q[1], q[2], q[3] };
-      }
-    }
+    for (int j = 0; j < 4; ++j) rc[j] = ld4<NT>(pc + j * 32, al);
   }
   for (long long item = w; item < batch; item += W) {
-    float* const pc = addr_c<float>(ad, item);
-    // park A and B in LDS
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int c = 64 * j + lane;
-      *reinterpret_cast<f32x4*>(As + 4 * c) = ra[j];
-      const int n = c >> 3, q = c & 7;
-      *reinterpret_cast<f32x4*>(Bs + 4 * (n * 8 + (q ^ (n >> 2)))) = rb[j];
-    }
+    float* const pc = addr_c<float>(ad, item) + 4 * ty * 32 + 4 * tx;
+    park_ab<2>(As, Bs, lane, ra, rb);
     f32x4 acc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j] = BETA0 ? f32x4{ 0.f, 0.f, 0.f, 0.f } : rc[j];
-    // issue the next problem's loads before computing this one
-    const long long next = item + W;
+    const long long next = item + W; // issue the next problem's loads before computing this one
     if (next < batch) {
-      load_mat32(addr_a<float>(ad, next), lane, ra);
-      load_mat32(addr_b<float>(ad, next), lane, rb);
+      load_mat32<NT>(addr_a<float>(ad, next), lane, ra);
+      load_mat32<NT>(addr_b<float>(ad, next), lane, rb);
       if (!BETA0) {
-        const float* const pn = addr_c<float>(ad, next);
+        const float* const pn = addr_c<float>(ad, next) + 4 * ty * 32 + 4 * tx;
         const bool al = aligned16(pn);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float* const q = pn + (4 * ty + j) * 32 + 4 * tx;
-          rc[j] = al ? *reinterpret_cast<const f32x4*>(q) : f32x4{ q[0], q[1], q[2], q[3] };
-        }
+        for (int j = 0; j < 4; ++j) rc[j] = ld4<NT>(pn + j * 32, al);
       }
     }
     wave_lds_sync();
-#pragma unroll
-    for (int q = 0; q < 8; ++q) { // four k per step
+#pragma unroll 2
+    for (int q = 0; q < 8; ++q) { // four k per step (limited unrolling: the tile must stay within 128 VGPRs)
       f32x4 av[4], bv[4];
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) av[kk] = *reinterpret_cast<const f32x4*>(As + (4 * q + kk) * 32 + 4 * tx);
@@ -115,25 +115,21 @@ void smm32_f32_fma_kernel(DevAddr ad, long long batch)
     }
     const bool al = aligned16(pc);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float* const q = pc + (4 * ty + j) * 32 + 4 * tx;
-      if (al) *reinterpret_cast<f32x4*>(q) = acc[j];
-      else { q[0] = acc[j][0]; q[1] = acc[j][1]; q[2] = acc[j][2]; q[3] = acc[j][3]; }
-    }
+    for (int j = 0; j < 4; ++j) st4<NT>(pc + j * 32, al, acc[j]);
     wave_lds_sync();
   }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// MFMA variant: D[i=n][j=m] += sum_kk Bt[n][kk] * A[kk][m] with v_mfma_f32_32x32x2_f32.
-//   a-operand (lane l: row i = l&31, kk = l>>5)  <- B[k][n], n = l&31, k = 16*(l>>5) + s
-//   b-operand (lane l: col j = l&31, kk = l>>5)  <- A[m][k], m = l&31, k = 16*(l>>5) + s
-//   D register r of lane l: n = (r&3) + 8*(r>>2) + 4*(l>>5), m = l&31  -> every C access is two full 128-byte rows.
-// LDS image: A linear; B chunks (n, q) at n*8 + (q ^ ((n>>1)&7)) so that the 16 lanes of a ds_read_b128 group hit
-// 16 different 16-byte slots.
+// MFMA variants with v_mfma_f32_32x32x2_f32; per instruction lane l supplies k = 16*(l>>5) + s for both operands:
+//   A[m = l&31][k] from the linear LDS image, B[k][n = l&31] as four 16-byte reads of the swizzled image.
+// CV4 == false: D[i=n][j=m] (B as a-operand). Register r of lane l is C[n = (r&3)+8(r>>2)+4(l>>5)][m = l&31]: every C
+//               access is a dword per lane, two full 128-byte rows per wave instruction.
+// CV4 == true : D[i=m][j=n] (A as a-operand). Registers 4g..4g+3 of lane l are rows m = 8g+4(l>>5)+{0..3} of column
+//               n = l&31: C moves as four 16-byte accesses per lane.
 // ---------------------------------------------------------------------------------------------------------------
-template<bool BETA0>
-__global__ __launch_bounds__(256)
+template<bool BETA0, bool NT, bool CV4>
+__global__ __launch_bounds__(256, 4)
 void smm32_f32_mfma_kernel(DevAddr ad, long long batch)
 {
   __shared__ __align__(16) float lds[4][2048];
@@ -143,37 +139,35 @@ void smm32_f32_mfma_kernel(DevAddr ad, long long batch)
   float* const Bs = lds[wave] + 1024;
   const long long w = (long long)blockIdx.x * 4 + wave, W = (long long)gridDim.x * 4;
   if (w >= batch) return;
+  const int coff = CV4 ? (lo * 32 + 4 * hi) : (4 * hi * 32 + lo); // lane's first C element
 
   f32x4 ra[4], rb[4];
   float rc[16];
-  load_mat32(addr_a<float>(ad, w), lane, ra);
-  load_mat32(addr_b<float>(ad, w), lane, rb);
-  if (!BETA0) {
-    const float* const pc = addr_c<float>(ad, w);
+  auto load_c = [&](const float* pc) {
+    if (CV4) {
+      const bool al = aligned16(pc);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) rc[r] = pc[((r & 3) + 8 * (r >> 2) + 4 * hi) * 32 + lo];
-  }
-  for (long long item = w; item < batch; item += W) {
-    float* const pc = addr_c<float>(ad, item);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int c = 64 * j + lane;
-      *reinterpret_cast<f32x4*>(As + 4 * c) = ra[j];
-      const int n = c >> 3, q = c & 7;
-      *reinterpret_cast<f32x4*>(Bs + 4 * (n * 8 + (q ^ ((n >> 1) & 7)))) = rb[j];
+      for (int g = 0; g < 4; ++g) { const f32x4 v = ld4<NT>(pc + 8 * g, al); rc[4 * g] = v[0]; rc[4 * g + 1] = v[1]; rc[4 * g + 2] = v[2]; rc[4 * g + 3] = v[3]; }
     }
+    else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) rc[r] = ld1<NT>(pc + ((r & 3) + 8 * (r >> 2)) * 32);
+    }
+  };
+  load_mat32<NT>(addr_a<float>(ad, w), lane, ra);
+  load_mat32<NT>(addr_b<float>(ad, w), lane, rb);
+  if (!BETA0) load_c(addr_c<float>(ad, w) + coff);
+  for (long long item = w; item < batch; item += W) {
+    float* const pc = addr_c<float>(ad, item) + coff;
+    park_ab<1>(As, Bs, lane, ra, rb);
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = BETA0 ? 0.f : rc[r];
     const long long next = item + W;
     if (next < batch) {
-      load_mat32(addr_a<float>(ad, next), lane, ra);
-      load_mat32(addr_b<float>(ad, next), lane, rb);
-      if (!BETA0) {
-        const float* const pn = addr_c<float>(ad, next);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) rc[r] = pn[((r & 3) + 8 * (r >> 2) + 4 * hi) * 32 + lo];
-      }
+      load_mat32<NT>(addr_a<float>(ad, next), lane, ra);
+      load_mat32<NT>(addr_b<float>(ad, next), lane, rb);
+      if (!BETA0) load_c(addr_c<float>(ad, next) + coff);
     }
     wave_lds_sync();
     f32x4 bt[4]; // B[16*hi + 4t + e][n = lo]
@@ -182,18 +176,87 @@ void smm32_f32_mfma_kernel(DevAddr ad, long long batch)
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
       const float av = As[(16 * hi + s) * 32 + lo]; // A[m = lo][k = 16*hi + s]
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bt[s >> 2][s & 3], av, acc, 0, 0, 0);
+      if (CV4) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bt[s >> 2][s & 3], acc, 0, 0, 0);
+      else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bt[s >> 2][s & 3], av, acc, 0, 0, 0);
     }
+    if (CV4) {
+      const bool al = aligned16(pc);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) pc[((r & 3) + 8 * (r >> 2) + 4 * hi) * 32 + lo] = acc[r];
+      for (int g = 0; g < 4; ++g) st4<NT>(pc + 8 * g, al, f32x4{ acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3] });
+    }
+    else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st1<NT>(pc + ((r & 3) + 8 * (r >> 2)) * 32, acc[r]);
+    }
     wave_lds_sync();
   }
+}
+
+// c[i] = a[i] + b[i] + c[i] in whole 4 KiB items per wave with the same prefetch structure as the SMM kernels: the
+// traffic mix of a beta=1 SMM batch (3 reads : 1 write) without arithmetic or LDS -- the measured ceiling the SMM
+// kernels are compared against (bench.py "stream_ceiling").
+__global__ __launch_bounds__(256)
+void stream_abc_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ b, f32x4* __restrict__ c, long long items)
+{
+  const int lane = threadIdx.x & 63;
+  const long long w = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, W = ((long long)gridDim.x * blockDim.x) >> 6;
+  if (w >= items) return;
+  f32x4 ra[4], rb[4], rc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const long long o = w * 256 + 64 * j + lane;
+    ra[j] = __builtin_nontemporal_load(a + o); rb[j] = __builtin_nontemporal_load(b + o); rc[j] = __builtin_nontemporal_load(c + o);
+  }
+  for (long long it = w; it < items; it += W) {
+    f32x4 r[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r[j] = ra[j] + rb[j] + rc[j];
+    const long long nx = it + W;
+    if (nx < items) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const long long o = nx * 256 + 64 * j + lane;
+        ra[j] = __builtin_nontemporal_load(a + o); rb[j] = __builtin_nontemporal_load(b + o); rc[j] = __builtin_nontemporal_load(c + o);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) __builtin_nontemporal_store(r[j], c + it * 256 + 64 * j + lane);
+  }
+}
+
+int env_int(const char* name, int fallback)
+{
+  const char* const v = getenv(name);
+  return (nullptr != v && 0 != *v) ? atoi(v) : fallback;
 }
 
 bool is_smm32_f32(const SmmBatch& s)
 {
   return 4 == s.typesize && 32 == s.m && 32 == s.n && 32 == s.k && 32 == s.lda && 32 == s.ldb && 32 == s.ldc
       && 0 == (s.flags & LIBXSMM_GEMM_FLAG_TRANS_B) && SYNC_NONE == s.sync && 0 == s.general;
+}
+
+template<bool NT>
+int launch_smm32(const SmmBatch& s, hipStream_t st, unsigned blocks, int variant, const char** name)
+{
+  const bool beta0 = (0 != (s.flags & LIBXSMM_GEMM_FLAG_BETA_0));
+  const DevAddr ad = make_addr(s);
+  if (0 == s.use_mfma) {
+    *name = "smm_f32_32x32x32_fma";
+    if (beta0) hipLaunchKernelGGL((smm32_f32_fma_kernel<true, NT>), dim3(blocks), dim3(256), 0, st, ad, s.batch);
+    else hipLaunchKernelGGL((smm32_f32_fma_kernel<false, NT>), dim3(blocks), dim3(256), 0, st, ad, s.batch);
+  }
+  else if (1 == variant) {
+    *name = "smm_f32_32x32x32_mfma_cv4";
+    if (beta0) hipLaunchKernelGGL((smm32_f32_mfma_kernel<true, NT, true>), dim3(blocks), dim3(256), 0, st, ad, s.batch);
+    else hipLaunchKernelGGL((smm32_f32_mfma_kernel<false, NT, true>), dim3(blocks), dim3(256), 0, st, ad, s.batch);
+  }
+  else {
+    *name = "smm_f32_32x32x32_mfma";
+    if (beta0) hipLaunchKernelGGL((smm32_f32_mfma_kernel<true, NT, false>), dim3(blocks), dim3(256), 0, st, ad, s.batch);
+    else hipLaunchKernelGGL((smm32_f32_mfma_kernel<false, NT, false>), dim3(blocks), dim3(256), 0, st, ad, s.batch);
+  }
+  return (int)hipGetLastError();
 }
 
 } // namespace
@@ -203,24 +266,24 @@ int launch_smm_special(const SmmBatch& s, void* stream, const char** name)
 {
   hipStream_t st = (hipStream_t)stream;
   if (is_smm32_f32(s)) {
-    const bool beta0 = (0 != (s.flags & LIBXSMM_GEMM_FLAG_BETA_0));
+    // tuning knobs (developer use; re-read on every launch so that one process can sweep them):
+    // work-groups per CU of the persistent grid, MFMA kernel variant, non-temporal hint
+    const int bpc = env_int("XSMM_SMM32_BPC", 3), variant = env_int("XSMM_SMM32_VARIANT", 0), nt = env_int("XSMM_SMM32_NT", 1);
     long long blocks = (s.batch + 3) / 4;
-    const long long resident = 256LL * 4; // 4 work-groups (16 waves) per CU
+    const long long resident = 256LL * (bpc > 0 ? bpc : 3);
     if (blocks > resident) blocks = resident;
-    const DevAddr ad = make_addr(s);
-    if (0 != s.use_mfma) {
-      *name = "smm_f32_32x32x32_mfma";
-      if (beta0) hipLaunchKernelGGL((smm32_f32_mfma_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, st, ad, s.batch);
-      else hipLaunchKernelGGL((smm32_f32_mfma_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, st, ad, s.batch);
-    }
-    else {
-      *name = "smm_f32_32x32x32_fma";
-      if (beta0) hipLaunchKernelGGL((smm32_f32_fma_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, st, ad, s.batch);
-      else hipLaunchKernelGGL((smm32_f32_fma_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, st, ad, s.batch);
-    }
-    return (int)hipGetLastError();
+    return (0 != nt) ? launch_smm32<true>(s, st, (unsigned)blocks, variant, name) : launch_smm32<false>(s, st, (unsigned)blocks, variant, name);
   }
   return -1;
+}
+
+int launch_stream_abc(const void* a, const void* b, void* c, long long bytes, void* stream)
+{
+  const long long items = bytes / 4096;
+  const int bpc = env_int("XSMM_STREAM_BPC", 3);
+  hipLaunchKernelGGL(stream_abc_kernel, dim3(256u * (unsigned)(bpc > 0 ? bpc : 3)), dim3(256), 0, (hipStream_t)stream,
+    (const f32x4*)a, (const f32x4*)b, (f32x4*)c, items);
+  return (int)hipGetLastError();
 }
 
 } // namespace xsmm

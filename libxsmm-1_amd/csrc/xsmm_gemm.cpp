@@ -578,3 +578,16 @@ LIBXSMM_APIEXT void libxsmm_mmbatch_end(void)
   SmmBatch s = from_descriptor(desc);
   (void)batch_execute(s, 0, 0, &ptrsize, &ptrsize, &ptrsize, pa.data(), pb.data(), pc.data(), 0, (long long)items.size(), false);
 }
+
+// ---- measurement aid -----------------------------------------------------------------------------------------------
+namespace xsmm { int launch_stream_abc(const void* a, const void* b, void* c, long long bytes, void* stream); }
+
+LIBXSMM_API int libxsmm_amd_stream_probe(const void* a, const void* b, void* c, long long bytes)
+{ // c += a + b over `bytes` bytes per operand (device memory, 16-byte aligned, a multiple of 4 KiB): pure
+  // 3-read/1-write streaming
+  if (nullptr == a || nullptr == b || nullptr == c || bytes < 0 || 0 != (bytes % 4096)) return EXIT_FAILURE;
+  if (!device_ready()) { fail_no_device("libxsmm_amd_stream_probe"); return EXIT_FAILURE; }
+  const int e = xsmm::launch_stream_abc(a, b, c, bytes, device().stream);
+  note_launch("stream_abc");
+  return 0 == e ? EXIT_SUCCESS : EXIT_FAILURE;
+}

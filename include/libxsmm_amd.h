@@ -79,4 +79,12 @@ LIBXSMM_API int libxsmm_amd_spmdm_batch_get_slice(const libxsmm_amd_spmdm_batch*
 LIBXSMM_API int libxsmm_amd_dfsspmdm_execute_batch(const libxsmm_dfsspmdm* handle, const double* B, double* C, long long batch);
 LIBXSMM_API int libxsmm_amd_sfsspmdm_execute_batch(const libxsmm_sfsspmdm* handle, const float* B, float* C, long long batch);
 
+/** Text generator: the HIP source a fixed-sparsity operator (CSR pattern + values) is specialised to -- every referenced B
+ *  row is loaded once, every non-zero is one fma with an immediate. This is what libxsmm_?fsspmdm_create compiles through
+ *  hiprtc (counterpart of the reference's libxsmm_generator_spgemm_csr_kernel text output). The source is copied into
+ *  `buffer` (truncated to buffer_size). compile == 0: returns the source length; compile != 0: additionally compiles it for
+ *  gfx950 (no device needed) and returns 0 on success, > 0 on a compile error, -1 if hiprtc is unavailable / bad arguments. */
+LIBXSMM_API int libxsmm_amd_csr_kernel_source(int typesize, int M, int K, const unsigned int* row_ptr, const unsigned int* column_idx,
+  const double* values, int beta0, int vec, char* buffer, size_t buffer_size, int compile);
+
 #endif /* LIBXSMM_AMD_H */

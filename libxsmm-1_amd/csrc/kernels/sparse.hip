@@ -156,6 +156,91 @@ void bgemm_copy_kernel(int which, const T* __restrict__ src, int ld, T* __restri
   }
 }
 
+typedef float sp_f32x4 __attribute__((ext_vector_type(4)));
+
+// Work-group-per-item form (the one used for BASELINE config 4). 256 threads = 16 row groups of 16 lanes; a lane owns
+// four adjacent columns (n = 4*(t&15)..+3), a group one row per round, so 16 rows are in flight per round.
+//  LDS: the item's B tile (K x N floats, streamed with 16-byte loads), its rowidx, and a window of CSR entries packed as
+//  {float index of the B row, value} (8 bytes) so that one ds_read_b64 feeds one ds_read_b128 + 4 fma.
+//  Per C element the chain is acc = beta*C; acc = fma(val_p, B[col_p][n], acc) in row order (compute tpl :321-371).
+template<int U>
+__device__ __forceinline__ void spw_fold(const float2* __restrict__ meta, const float* __restrict__ brow0, sp_f32x4& acc)
+{
+  float2 e[U]; sp_f32x4 bv[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) e[u] = meta[u];
+#pragma unroll
+  for (int u = 0; u < U; ++u) bv[u] = *reinterpret_cast<const sp_f32x4*>(brow0 + __float_as_int(e[u].x));
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    acc[0] = xfma(e[u].y, bv[u][0], acc[0]); acc[1] = xfma(e[u].y, bv[u][1], acc[1]);
+    acc[2] = xfma(e[u].y, bv[u][2], acc[2]); acc[3] = xfma(e[u].y, bv[u][3], acc[3]);
+  }
+}
+
+constexpr int SPW_META = 2560; // CSR entries per window (>= 16 rows * 64 columns... see host check: 16*K <= SPW_META)
+
+__global__ __launch_bounds__(256)
+void spmdm_compute_wg_kernel(long long batch, int M, int N, int K, float beta,
+                             const uint16_t* __restrict__ rowidx, const uint16_t* __restrict__ colidx, const float* __restrict__ values,
+                             int rstride, long long cap, const float* __restrict__ b, float* __restrict__ c)
+{
+  extern __shared__ __align__(16) unsigned char spw_raw[];
+  const int tile = K * N;                                   // floats, multiple of 4
+  float* const Bs = reinterpret_cast<float*>(spw_raw);      // [K][N]
+  float2* const meta = reinterpret_cast<float2*>(Bs + tile); // [SPW_META] {bitcast(int row offset), value}
+  unsigned short* const ris = reinterpret_cast<unsigned short*>(meta + SPW_META); // [M+1]
+  const int t = threadIdx.x, g = t >> 4, n0 = (t & 15) * 4;
+  const bool active_n = (n0 < N);
+  for (long long item = blockIdx.x; item < batch; item += gridDim.x) {
+    { // stage B and rowidx
+      const sp_f32x4* const src = reinterpret_cast<const sp_f32x4*>(b + item * tile);
+      for (int i = t; i < (tile >> 2); i += 256) *reinterpret_cast<sp_f32x4*>(Bs + 4 * i) = __builtin_nontemporal_load(src + i);
+      const uint16_t* const ri = rowidx + item * rstride;
+      for (int i = t; i <= M; i += 256) ris[i] = ri[i];
+    }
+    __syncthreads();
+    const uint16_t* const ci = colidx + item * cap;
+    const float* const va = values + item * cap;
+    float* const pc = c + item * (long long)M * N;
+    int m0 = 0;
+    while (m0 < M) {
+      // window: as many rounds of 16 rows as fit the metadata buffer (at least one: host guarantees 16*K <= SPW_META)
+      int m1 = m0 + 16 < M ? m0 + 16 : M;
+      const int pbase = ris[m0];
+      while (m1 < M) {
+        const int m2 = m1 + 16 < M ? m1 + 16 : M;
+        if ((int)ris[m2] - pbase > SPW_META) break;
+        m1 = m2;
+      }
+      const int cnt = (int)ris[m1] - pbase;
+      for (int e = t; e < cnt; e += 256) {
+        const int off = (int)ci[pbase + e] * N;
+        meta[e] = float2{ __int_as_float(off), va[pbase + e] };
+      }
+      __syncthreads();
+      for (int m = m0 + g; m < m1; m += 16) {
+        const int p0 = (int)ris[m] - pbase, p1 = (int)ris[m + 1] - pbase;
+        sp_f32x4 acc = sp_f32x4{ 0.f, 0.f, 0.f, 0.f };
+        if (0.f != beta && active_n) {
+          const sp_f32x4 cv = *reinterpret_cast<const sp_f32x4*>(pc + (size_t)m * N + n0);
+          acc = (1.f == beta) ? cv : beta * cv;
+        }
+        // the chain through acc is sequential, but the LDS reads are not: fetch U (entry, B row) pairs, then fold them
+        int p = p0;
+        for (; p + 8 <= p1; p += 8) spw_fold<8>(meta + p, Bs + n0, acc);
+        const int rem = p1 - p;
+        if (rem & 4) { spw_fold<4>(meta + p, Bs + n0, acc); p += 4; }
+        if (rem & 2) { spw_fold<2>(meta + p, Bs + n0, acc); p += 2; }
+        if (rem & 1) spw_fold<1>(meta + p, Bs + n0, acc);
+        if (active_n) __builtin_nontemporal_store(acc, reinterpret_cast<sp_f32x4*>(pc + (size_t)m * N + n0));
+      }
+      __syncthreads();
+      m0 = m1;
+    }
+  }
+}
+
 unsigned grid_for(long long work, int per_block)
 {
   long long blocks = (work + per_block - 1) / per_block;
@@ -192,7 +277,7 @@ int launch_spmdm_create(const SpmdmGeom& g, int transa, const float* a, uint16_t
   if (0 == g.batch) return 0;
   hipLaunchKernelGGL(spmdm_create_kernel, dim3(grid_for(g.batch, 4)), dim3(256), 0, st,
     g.batch, g.m, g.k, transa, a, (long long)g.m * g.k, transa ? g.m : g.k, 0, g.m, g.k, g.m, g.k,
-    rowidx, colidx, values, (long long)g.m + 1, (long long)g.cap);
+    rowidx, colidx, values, (long long)g.rstride, (long long)g.cap);
   return (int)hipGetLastError();
 }
 
@@ -234,8 +319,20 @@ int launch_spmdm_compute_generic(long long batch, int M, int N, int K, int bm, i
 int launch_spmdm_compute(const SpmdmGeom& g, int transb, int transc, float beta, const uint16_t* rowidx, const uint16_t* colidx,
                          const float* values, const float* b, float* c, void* stream, const char** name)
 {
+  const long long tile = (long long)g.k * g.n;
+  if (0 == transb && 0 == transc && g.n <= 64 && 0 == (g.n & 3) && 16 * g.k <= SPW_META && tile * 4 <= 49152 && 0 < g.batch) {
+    hipStream_t st = (hipStream_t)stream; // work-group-per-item LDS kernel
+    const size_t lds = (size_t)tile * 4 + (size_t)SPW_META * 8 + (((size_t)g.m + 1) * 2 + 15) / 16 * 16;
+    long long per_cu = (long long)(160 * 1024 / lds); if (per_cu > 8) per_cu = 8; if (per_cu < 1) per_cu = 1;
+    const long long want = 256 * per_cu;
+    const unsigned grid = (unsigned)(g.batch < want ? g.batch : want);
+    *name = "spmdm_compute_wg_lds";
+    hipLaunchKernelGGL(spmdm_compute_wg_kernel, dim3(grid), dim3(256), lds, st,
+      g.batch, g.m, g.n, g.k, beta, rowidx, colidx, values, g.rstride, (long long)g.cap, b, c);
+    return (int)hipGetLastError();
+  }
   return launch_spmdm_compute_generic(g.batch, g.m, g.n, g.k, g.m, g.k, 1, 1, transb, transc, beta, rowidx, colidx, values,
-    (long long)g.m + 1, (long long)g.cap, b, c, (long long)g.k * g.n, (long long)g.m * g.n, 0, g.m, 0, g.n, stream, name);
+    (long long)g.rstride, (long long)g.cap, b, c, (long long)g.k * g.n, (long long)g.m * g.n, 0, g.m, 0, g.n, stream, name);
 }
 
 int launch_bgemm_copy(const BgemmGeom& g, int which, const void* src, int ld, void* dst, void* stream)

@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 
 #include "../../include/libxsmm.h"
 
@@ -79,8 +80,21 @@ struct CsrPanels {
 };
 int launch_csr_panels(const CsrPanels& args, void* stream, const char** name);
 
+// run-time specialised operator kernels (xsmm_jit.cpp)
+struct JitKernel;
+std::string gen_csr_panels_source(int typesize, int M, int K, const unsigned* rowptr, const unsigned* colidx, const double* values,
+                                  int beta0, int skip_empty_rows, int vec, const char* fname);
+JitKernel* jit_compile(const std::string& src, const char* fname, std::string* log);
+int jit_check_source(const std::string& src, std::string* log);
+void jit_release(JitKernel* k);
+int jit_launch_panels(JitKernel* k, const void* B, void* C, long long ncols, long long ldb, long long ldc, int vec, void* stream);
+
 // spmdm batch
-struct SpmdmGeom { int m, n, k; long long batch; int cap; /* bm*bk capacity per item */ };
+struct SpmdmGeom {
+  int m, n, k; long long batch;
+  int cap;      // colidx/values capacity per item (m*k rounded up to even: slots stay dword-aligned)
+  int rstride;  // rowidx entries per item (m+1 rounded up to even)
+};
 int launch_spmdm_create(const SpmdmGeom& g, int transa, const float* a, uint16_t* rowidx, uint16_t* colidx, float* values,
                         void* stream, const char** name);
 int launch_spmdm_compute(const SpmdmGeom& g, int transb, int transc, float beta, const uint16_t* rowidx, const uint16_t* colidx,

@@ -34,6 +34,7 @@ struct libxsmm_dfsspmdm {
   libxsmm_dmmfunction kernel;         // always NULL here; execution goes through the fields below
   int typesize, beta0; unsigned nnz;
   unsigned* d_rowptr; unsigned* d_colidx; void* d_values;
+  JitKernel* jit; int jit_vec;        // operator-specific kernel compiled at create time (NULL: generic kernel)
 };
 struct libxsmm_sfsspmdm {
   int M, N, K, ldb, ldc, N_chunksize;
@@ -41,6 +42,7 @@ struct libxsmm_sfsspmdm {
   libxsmm_smmfunction kernel;
   int typesize, beta0; unsigned nnz;
   unsigned* d_rowptr; unsigned* d_colidx; void* d_values;
+  JitKernel* jit; int jit_vec;
 };
 static_assert(sizeof(libxsmm_dfsspmdm) == sizeof(libxsmm_sfsspmdm), "handles share one layout");
 
@@ -78,6 +80,23 @@ H* fsspmdm_create(libxsmm_blasint M, libxsmm_blasint N, libxsmm_blasint K, libxs
   if (0 < h->nnz) ok = ok && 0 == h2d(h->d_colidx, colidx.data(), sizeof(unsigned) * h->nnz) && 0 == h2d(h->d_values, values.data(), sizeof(T) * h->nnz);
   ok = ok && 0 == stream_sync();
   if (!ok) { dev_free(h->d_rowptr); dev_free(h->d_colidx); dev_free(h->d_values); free(h); return nullptr; }
+  // operator-specific kernel (the analogue of the reference's JIT, src/libxsmm_fsspmdm.c:119-126): pattern and values
+  // baked into HIP source, compiled by hiprtc. Limits keep the generated kernel within the register file.
+  const char* const env_jit = getenv("LIBXSMM_AMD_JIT");
+  const bool want_jit = (nullptr == env_jit || 0 != atoi(env_jit));
+  if (want_jit && 0 < h->nnz && h->nnz <= 8192 && K <= 160) {
+    const char* const env_vec = getenv("LIBXSMM_AMD_JIT_VEC");
+    int vec = (nullptr != env_vec && 0 != *env_vec) ? atoi(env_vec) : (8 == sizeof(T) ? 1 : 2);
+    while (1 < vec && (0 != (ldb % vec) || 0 != (ldc % vec) || 0 != (N % vec))) vec >>= 1;
+    if (vec < 1) vec = 1;
+    std::vector<double> dv(values.begin(), values.end());
+    const std::string src = gen_csr_panels_source((int)sizeof(T), (int)M, (int)K, rowptr.data(), colidx.data(), dv.data(),
+      h->beta0, 0/*empty rows are zeroed for beta == 0*/, vec, "xsmm_fsspmdm_op");
+    std::string log;
+    h->jit = jit_compile(src, "xsmm_fsspmdm_op", &log);
+    h->jit_vec = vec;
+    if (nullptr == h->jit && 0 != libxsmm_verbosity) fprintf(stderr, "LIBXSMM WARNING: fsspmdm JIT unavailable (%s); using the generic kernel\n", log.c_str());
+  }
   return h;
 }
 
@@ -91,19 +110,25 @@ int fsspmdm_run(const H* h, const T* B, T* C, long long batch)
   p.skip_empty_rows = 0;
   p.rowptr = h->d_rowptr; p.colidx = h->d_colidx; p.values = h->d_values; p.nnz = h->nnz; p.batch = batch;
   const char* name = "";
-  if (is_device_ptr(B) && is_device_ptr(C)) {
-    p.b = B; p.c = C;
+  auto launch = [&](const void* db, void* dc) -> int {
+    const long long ncols = (long long)h->N * batch;
+    const bool aligned = (1 == h->jit_vec) || (0 == ((reinterpret_cast<uintptr_t>(db) | reinterpret_cast<uintptr_t>(dc)) & (sizeof(T) * h->jit_vec - 1)));
+    if (nullptr != h->jit && aligned && 0 == (ncols % h->jit_vec)) {
+      const int e = jit_launch_panels(h->jit, db, dc, ncols, h->ldb, h->ldc, h->jit_vec, device().stream);
+      note_launch(8 == h->typesize ? "fsspmdm_f64_jit_operator" : "fsspmdm_f32_jit_operator");
+      return e;
+    }
+    p.b = db; p.c = dc;
     const int e = launch_csr_panels(p, device().stream, &name); note_launch(name);
-    return 0 == e ? EXIT_SUCCESS : EXIT_FAILURE;
-  }
+    return e;
+  };
+  if (is_device_ptr(B) && is_device_ptr(C)) return 0 == launch(B, C) ? EXIT_SUCCESS : EXIT_FAILURE;
   // host panels: stage rows [0,K) x columns [0, N*batch) of B and rows [0,M) of C (strided by ldb/ldc)
   const long long ncols = (long long)h->N * batch;
   const size_t eb = (size_t)(h->K - 1) * h->ldb + ncols, ec = (size_t)(h->M - 1) * h->ldc + ncols;
   char* const db = static_cast<char*>(scratch(4, eb * sizeof(T))); char* const dc = static_cast<char*>(scratch(5, ec * sizeof(T)));
   if (nullptr == db || nullptr == dc || 0 != h2d(db, B, eb * sizeof(T)) || 0 != h2d(dc, C, ec * sizeof(T))) return EXIT_FAILURE;
-  p.b = db; p.c = dc;
-  const int e = launch_csr_panels(p, device().stream, &name); note_launch(name);
-  if (0 != e) return EXIT_FAILURE;
+  if (0 != launch(db, dc)) return EXIT_FAILURE;
   return 0 == d2h(C, dc, ec * sizeof(T)) ? EXIT_SUCCESS : EXIT_FAILURE;
 }
 
@@ -111,11 +136,31 @@ template<typename H> void fsspmdm_destroy(H* h)
 {
   if (nullptr == h) return;
   if (device_ready()) (void)stream_sync();
+  jit_release(h->jit);
   dev_free(h->d_rowptr); dev_free(h->d_colidx); dev_free(h->d_values);
   free(h);
 }
 
 } // namespace
+
+LIBXSMM_API int libxsmm_amd_csr_kernel_source(int typesize, int M, int K, const unsigned int* row_ptr, const unsigned int* column_idx,
+  const double* values, int beta0, int vec, char* buffer, size_t buffer_size, int compile)
+{ // the HIP text an operator is specialised to (counterpart of the reference's text generators,
+  // libxsmm_generator_spgemm_csr_kernel, include/libxsmm_generator.h:190-197); optional hiprtc compile check (no device needed)
+  if ((4 != typesize && 8 != typesize) || M <= 0 || K <= 0 || nullptr == row_ptr || nullptr == column_idx || nullptr == values || vec < 1) return -1;
+  const std::string src = gen_csr_panels_source(typesize, M, K, row_ptr, column_idx, values, beta0, 0, vec, "xsmm_fsspmdm_op");
+  if (nullptr != buffer && 0 < buffer_size) {
+    const size_t n = (src.size() < buffer_size - 1 ? src.size() : buffer_size - 1);
+    memcpy(buffer, src.data(), n); buffer[n] = 0;
+  }
+  if (0 != compile) {
+    std::string log;
+    const int rc = jit_check_source(src, &log);
+    if (0 != rc && 0 != libxsmm_verbosity) fprintf(stderr, "LIBXSMM-AMD: hiprtc: %s\n", log.c_str());
+    return rc;
+  }
+  return (int)src.size();
+}
 
 LIBXSMM_API libxsmm_dfsspmdm* libxsmm_dfsspmdm_create(libxsmm_blasint M, libxsmm_blasint N, libxsmm_blasint K,
   libxsmm_blasint lda, libxsmm_blasint ldb, libxsmm_blasint ldc, const double alpha, const double beta, const double* a_dense)
@@ -279,9 +324,9 @@ LIBXSMM_API libxsmm_amd_spmdm_batch* libxsmm_amd_spmdm_batch_create(int M, int N
   if (!device_ready()) { fail_no_device("libxsmm_amd_spmdm_batch_create"); return nullptr; }
   libxsmm_amd_spmdm_batch* sb = static_cast<libxsmm_amd_spmdm_batch*>(calloc(1, sizeof(*sb)));
   if (nullptr == sb) return nullptr;
-  sb->g.m = M; sb->g.n = N; sb->g.k = K; sb->g.batch = batch; sb->g.cap = M * K;
+  sb->g.m = M; sb->g.n = N; sb->g.k = K; sb->g.batch = batch; sb->g.cap = (M * K + 1) & ~1; sb->g.rstride = (M + 2) & ~1;
   const size_t nb = (size_t)(batch ? batch : 1);
-  sb->rowidx = static_cast<uint16_t*>(dev_alloc(nb * ((size_t)M + 1) * sizeof(uint16_t)));
+  sb->rowidx = static_cast<uint16_t*>(dev_alloc(nb * (size_t)sb->g.rstride * sizeof(uint16_t)));
   sb->colidx = static_cast<uint16_t*>(dev_alloc(nb * (size_t)sb->g.cap * sizeof(uint16_t)));
   sb->values = static_cast<float*>(dev_alloc(nb * (size_t)sb->g.cap * sizeof(float)));
   if (nullptr == sb->rowidx || nullptr == sb->colidx || nullptr == sb->values) { libxsmm_amd_spmdm_batch_destroy(sb); return nullptr; }
@@ -320,7 +365,7 @@ LIBXSMM_API int libxsmm_amd_spmdm_batch_get_slice(const libxsmm_amd_spmdm_batch*
   uint16_t* rowidx, uint16_t* colidx, float* values, int capacity)
 {
   if (nullptr == sb || item < 0 || item >= sb->g.batch || nullptr == rowidx) return EXIT_FAILURE;
-  if (0 != d2h(rowidx, sb->rowidx + item * (sb->g.m + 1), ((size_t)sb->g.m + 1) * sizeof(uint16_t))) return EXIT_FAILURE;
+  if (0 != d2h(rowidx, sb->rowidx + item * sb->g.rstride, ((size_t)sb->g.m + 1) * sizeof(uint16_t))) return EXIT_FAILURE;
   const int nnz = rowidx[sb->g.m];
   const int ncopy = LIBXSMM_MIN(nnz, capacity);
   if (nullptr != colidx && 0 < ncopy && 0 != d2h(colidx, sb->colidx + item * sb->g.cap, (size_t)ncopy * sizeof(uint16_t))) return EXIT_FAILURE;

@@ -178,8 +178,35 @@ __device__ __forceinline__ void spw_fold(const float2* __restrict__ meta, const 
   }
 }
 
+constexpr int SPW_LDB = 64;    // LDS row stride of the B tile in floats (N <= 64)
 constexpr int SPW_META = 2560; // CSR entries per window (>= 16 rows * 64 columns... see host check: 16*K <= SPW_META)
 
+// rows [m0, m1) of one item; their CSR entries sit in meta[] starting at entry pbase
+__device__ __forceinline__ void spw_rows(int m0, int m1, int pbase, int g, int n0, bool active_n, int N, float beta,
+                                         const unsigned short* __restrict__ ris, const float2* __restrict__ meta,
+                                         const float* __restrict__ Bs, float* __restrict__ pc)
+{
+  if (!active_n) return; // lanes beyond N stay out of the LDS reads altogether (they would only add bank traffic)
+  for (int m = m0 + g; m < m1; m += 16) {
+    const int p0 = (int)ris[m] - pbase, p1 = (int)ris[m + 1] - pbase;
+    sp_f32x4 acc = sp_f32x4{ 0.f, 0.f, 0.f, 0.f };
+    if (0.f != beta && active_n) {
+      const sp_f32x4 cv = __builtin_nontemporal_load(reinterpret_cast<const sp_f32x4*>(pc + (size_t)m * N + n0));
+      acc = (1.f == beta) ? cv : beta * cv;
+    }
+    // the chain through acc is sequential, but the LDS reads are not: fetch U (entry, B row) pairs, then fold them
+    int p = p0;
+    for (; p + 8 <= p1; p += 8) spw_fold<8>(meta + p, Bs + n0, acc);
+    const int rem = p1 - p;
+    if (rem & 4) { spw_fold<4>(meta + p, Bs + n0, acc); p += 4; }
+    if (rem & 2) { spw_fold<2>(meta + p, Bs + n0, acc); p += 2; }
+    if (rem & 1) spw_fold<1>(meta + p, Bs + n0, acc);
+    if (active_n) __builtin_nontemporal_store(acc, reinterpret_cast<sp_f32x4*>(pc + (size_t)m * N + n0));
+  }
+}
+
+// NB = 16-byte pieces of the B tile per thread (tile <= NB * 1024 floats)
+template<int NB>
 __global__ __launch_bounds__(256)
 void spmdm_compute_wg_kernel(long long batch, int M, int N, int K, float beta,
                              const uint16_t* __restrict__ rowidx, const uint16_t* __restrict__ colidx, const float* __restrict__ values,
@@ -188,56 +215,96 @@ void spmdm_compute_wg_kernel(long long batch, int M, int N, int K, float beta,
   extern __shared__ __align__(16) unsigned char spw_raw[];
   const int tile = K * N;                                   // floats, multiple of 4
   float* const Bs = reinterpret_cast<float*>(spw_raw);      // [K][N]
-  float2* const meta = reinterpret_cast<float2*>(Bs + tile); // [SPW_META] {bitcast(int row offset), value}
+  // B rows are padded to SPW_LDB = 64 floats in LDS: a row then starts on a 256-byte bank row, so the 16-byte slot of a
+  // lane depends on its column group only and the row groups that share a ds_read_b128 phase never collide
+  float2* const meta = reinterpret_cast<float2*>(Bs + K * SPW_LDB); // [SPW_META] {bitcast(int row offset), value}
   unsigned short* const ris = reinterpret_cast<unsigned short*>(meta + SPW_META); // [M+1]
   const int t = threadIdx.x, g = t >> 4, n0 = (t & 15) * 4;
   const bool active_n = (n0 < N);
-  for (long long item = blockIdx.x; item < batch; item += gridDim.x) {
-    { // stage B and rowidx
-      const sp_f32x4* const src = reinterpret_cast<const sp_f32x4*>(b + item * tile);
-      for (int i = t; i < (tile >> 2); i += 256) *reinterpret_cast<sp_f32x4*>(Bs + 4 * i) = __builtin_nontemporal_load(src + i);
-      const uint16_t* const ri = rowidx + item * rstride;
-      for (int i = t; i <= M; i += 256) ris[i] = ri[i];
-    }
-    __syncthreads();
+  const int nv4 = tile >> 2;
+  long long item = blockIdx.x;
+  if (item >= batch) return;
+  int nnz = rowidx[item * rstride + M]; // every thread reads the same word; the next item's count is fetched one item ahead
+  for (; item < batch; item += gridDim.x) {
     const uint16_t* const ci = colidx + item * cap;
     const float* const va = values + item * cap;
     float* const pc = c + item * (long long)M * N;
-    int m0 = 0;
-    while (m0 < M) {
-      // window: as many rounds of 16 rows as fit the metadata buffer (at least one: host guarantees 16*K <= SPW_META)
-      int m1 = m0 + 16 < M ? m0 + 16 : M;
-      const int pbase = ris[m0];
-      while (m1 < M) {
-        const int m2 = m1 + 16 < M ? m1 + 16 : M;
-        if ((int)ris[m2] - pbase > SPW_META) break;
-        m1 = m2;
-      }
-      const int cnt = (int)ris[m1] - pbase;
-      for (int e = t; e < cnt; e += 256) {
-        const int off = (int)ci[pbase + e] * N;
-        meta[e] = float2{ __int_as_float(off), va[pbase + e] };
-      }
-      __syncthreads();
-      for (int m = m0 + g; m < m1; m += 16) {
-        const int p0 = (int)ris[m] - pbase, p1 = (int)ris[m + 1] - pbase;
-        sp_f32x4 acc = sp_f32x4{ 0.f, 0.f, 0.f, 0.f };
-        if (0.f != beta && active_n) {
-          const sp_f32x4 cv = *reinterpret_cast<const sp_f32x4*>(pc + (size_t)m * N + n0);
-          acc = (1.f == beta) ? cv : beta * cv;
-        }
-        // the chain through acc is sequential, but the LDS reads are not: fetch U (entry, B row) pairs, then fold them
-        int p = p0;
-        for (; p + 8 <= p1; p += 8) spw_fold<8>(meta + p, Bs + n0, acc);
-        const int rem = p1 - p;
-        if (rem & 4) { spw_fold<4>(meta + p, Bs + n0, acc); p += 4; }
-        if (rem & 2) { spw_fold<2>(meta + p, Bs + n0, acc); p += 2; }
-        if (rem & 1) spw_fold<1>(meta + p, Bs + n0, acc);
-        if (active_n) __builtin_nontemporal_store(acc, reinterpret_cast<sp_f32x4*>(pc + (size_t)m * N + n0));
-      }
-      __syncthreads();
-      m0 = m1;
+    const bool one_window = (nnz <= SPW_META); // the common case: the whole item's CSR fits the metadata buffer
+    // ---- issue all loads of this item (B tile, rowidx, and -- single-window case -- eight CSR entries per thread)
+    sp_f32x4 rb[NB];
+    {
+      const sp_f32x4* const src = reinterpret_cast<const sp_f32x4*>(b + item * tile);
+#pragma unroll
+      for (int j = 0; j < NB; ++j) { const int i = 256 * j + t; if (i < nv4) rb[j] = __builtin_nontemporal_load(src + i); }
     }
+    const unsigned short rix = (t <= M) ? rowidx[item * rstride + t] : (unsigned short)0; // M <= 255 on this path (host check)
+    uint4 cols[2]; sp_f32x4 vals[4];
+    const int e0 = 8 * t;
+    if (one_window) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) { // entries e0 + 2048*h .. +7 (the second pass covers 2048..SPW_META-1)
+        const int e = e0 + 2048 * h;
+        if (e < nnz) {
+          cols[h] = *reinterpret_cast<const uint4*>(ci + e);
+          vals[2 * h] = *reinterpret_cast<const sp_f32x4*>(va + e);
+          vals[2 * h + 1] = *reinterpret_cast<const sp_f32x4*>(va + e + 4);
+        }
+      }
+    }
+    const long long next = item + gridDim.x;
+    const int nnz_next = (next < batch) ? (int)rowidx[next * rstride + M] : 0;
+    // ---- park everything in LDS
+    {
+      const int n4 = N >> 2; // 16-byte pieces per B row
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const int i = 256 * j + t;
+        if (i < nv4) { const int kr = i / n4, jc = i - kr * n4; *reinterpret_cast<sp_f32x4*>(Bs + kr * SPW_LDB + 4 * jc) = rb[j]; }
+      }
+    }
+    if (t <= M) ris[t] = rix;
+    if (one_window) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int e = e0 + 2048 * h;
+        if (e < nnz) {
+          const unsigned cw[4] = { cols[h].x, cols[h].y, cols[h].z, cols[h].w };
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { // two entries per 16-byte LDS write
+            const int o0 = (int)(cw[q] & 0xFFFFu) * SPW_LDB, o1 = (int)(cw[q] >> 16) * SPW_LDB;
+            const sp_f32x4 v = vals[2 * h + (q >> 1)];
+            *reinterpret_cast<sp_f32x4*>(meta + e + 2 * q) = sp_f32x4{ __int_as_float(o0), v[2 * (q & 1)], __int_as_float(o1), v[2 * (q & 1) + 1] };
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (one_window) {
+      spw_rows(0, M, 0, g, n0, active_n, N, beta, ris, meta, Bs, pc);
+      __syncthreads();
+    }
+    else { // dense items: walk the rows in windows of as many 16-row rounds as fit the metadata buffer
+      int m0 = 0;
+      while (m0 < M) {
+        int m1 = m0 + 16 < M ? m0 + 16 : M;
+        const int pbase = ris[m0];
+        while (m1 < M) {
+          const int m2 = m1 + 16 < M ? m1 + 16 : M;
+          if ((int)ris[m2] - pbase > SPW_META) break;
+          m1 = m2;
+        }
+        const int cnt = (int)ris[m1] - pbase;
+        for (int e = t; e < cnt; e += 256) {
+          const int off = (int)ci[pbase + e] * SPW_LDB;
+          meta[e] = float2{ __int_as_float(off), va[pbase + e] };
+        }
+        __syncthreads();
+        spw_rows(m0, m1, pbase, g, n0, active_n, N, beta, ris, meta, Bs, pc);
+        __syncthreads();
+        m0 = m1;
+      }
+    }
+    nnz = nnz_next;
   }
 }
 
@@ -320,15 +387,20 @@ int launch_spmdm_compute(const SpmdmGeom& g, int transb, int transc, float beta,
                          const float* values, const float* b, float* c, void* stream, const char** name)
 {
   const long long tile = (long long)g.k * g.n;
-  if (0 == transb && 0 == transc && g.n <= 64 && 0 == (g.n & 3) && 16 * g.k <= SPW_META && tile * 4 <= 49152 && 0 < g.batch) {
+  if (0 == transb && 0 == transc && g.n <= 64 && 0 == (g.n & 3) && 16 * g.k <= SPW_META && (long long)g.k * SPW_LDB * 4 <= 49152 && 0 < g.batch
+      && g.m <= 255 && 0 == (g.cap & 7)) {
     hipStream_t st = (hipStream_t)stream; // work-group-per-item LDS kernel
-    const size_t lds = (size_t)tile * 4 + (size_t)SPW_META * 8 + (((size_t)g.m + 1) * 2 + 15) / 16 * 16;
+    const size_t lds = (size_t)g.k * SPW_LDB * 4 + (size_t)SPW_META * 8 + (((size_t)g.m + 1) * 2 + 15) / 16 * 16;
     long long per_cu = (long long)(160 * 1024 / lds); if (per_cu > 8) per_cu = 8; if (per_cu < 1) per_cu = 1;
     const long long want = 256 * per_cu;
     const unsigned grid = (unsigned)(g.batch < want ? g.batch : want);
+    const int nb = (int)((tile / 4 + 255) / 256);
     *name = "spmdm_compute_wg_lds";
-    hipLaunchKernelGGL(spmdm_compute_wg_kernel, dim3(grid), dim3(256), lds, st,
-      g.batch, g.m, g.n, g.k, beta, rowidx, colidx, values, g.rstride, (long long)g.cap, b, c);
+#define XSMM_SPW(NB) hipLaunchKernelGGL((spmdm_compute_wg_kernel<NB>), dim3(grid), dim3(256), lds, st, \
+      g.batch, g.m, g.n, g.k, beta, rowidx, colidx, values, g.rstride, (long long)g.cap, b, c)
+    if (nb <= 1) XSMM_SPW(1); else if (nb <= 2) XSMM_SPW(2); else if (nb <= 3) XSMM_SPW(3); else if (nb <= 4) XSMM_SPW(4);
+    else if (nb <= 6) XSMM_SPW(6); else if (nb <= 8) XSMM_SPW(8); else XSMM_SPW(12);
+#undef XSMM_SPW
     return (int)hipGetLastError();
   }
   return launch_spmdm_compute_generic(g.batch, g.m, g.n, g.k, g.m, g.k, 1, 1, transb, transc, beta, rowidx, colidx, values,

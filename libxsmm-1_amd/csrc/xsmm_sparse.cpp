@@ -324,11 +324,13 @@ LIBXSMM_API libxsmm_amd_spmdm_batch* libxsmm_amd_spmdm_batch_create(int M, int N
   if (!device_ready()) { fail_no_device("libxsmm_amd_spmdm_batch_create"); return nullptr; }
   libxsmm_amd_spmdm_batch* sb = static_cast<libxsmm_amd_spmdm_batch*>(calloc(1, sizeof(*sb)));
   if (nullptr == sb) return nullptr;
-  sb->g.m = M; sb->g.n = N; sb->g.k = K; sb->g.batch = batch; sb->g.cap = (M * K + 1) & ~1; sb->g.rstride = (M + 2) & ~1;
+  // slot sizes: capacity rounded up to 8 entries and rowidx to an even count, so that every item's arrays start on a
+  // 16-byte boundary (vector loads in the compute kernel); a few entries of slack follow the last slot
+  sb->g.m = M; sb->g.n = N; sb->g.k = K; sb->g.batch = batch; sb->g.cap = (M * K + 7) & ~7; sb->g.rstride = (M + 2) & ~1;
   const size_t nb = (size_t)(batch ? batch : 1);
-  sb->rowidx = static_cast<uint16_t*>(dev_alloc(nb * (size_t)sb->g.rstride * sizeof(uint16_t)));
-  sb->colidx = static_cast<uint16_t*>(dev_alloc(nb * (size_t)sb->g.cap * sizeof(uint16_t)));
-  sb->values = static_cast<float*>(dev_alloc(nb * (size_t)sb->g.cap * sizeof(float)));
+  sb->rowidx = static_cast<uint16_t*>(dev_alloc((nb * (size_t)sb->g.rstride + 64) * sizeof(uint16_t)));
+  sb->colidx = static_cast<uint16_t*>(dev_alloc((nb * (size_t)sb->g.cap + 64) * sizeof(uint16_t)));
+  sb->values = static_cast<float*>(dev_alloc((nb * (size_t)sb->g.cap + 64) * sizeof(float)));
   if (nullptr == sb->rowidx || nullptr == sb->colidx || nullptr == sb->values) { libxsmm_amd_spmdm_batch_destroy(sb); return nullptr; }
   return sb;
 }

@@ -139,6 +139,16 @@ def main():
                            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                            "launch_ms_avg": round(kms, 4), "launch_ms_min": round(min(per_step), 4),
                            "algorithmic_bytes_per_launch": float(B) * bytes_item}
+        # HBM traffic per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, gfx950
+        # correction applied) -- counters cannot be collected from inside this process, so the committed summary is used
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_summary.json")))
+            entry = pmc.get(kernel_name)
+            if entry and B == 1048576:
+                out["roofline"]["traffic"] = entry["traffic_bytes_per_launch"]
+                out["roofline"]["traffic_source"] = "profiles/r1_pmc_summary.json"
+        except (OSError, ValueError, KeyError):
+            pass
         # measured ceiling for this traffic mix: c += a + b over the same three arrays (3 reads : 1 write, no arithmetic)
         nbytes = B * M * K * 4
 

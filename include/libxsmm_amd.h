@@ -87,4 +87,9 @@ LIBXSMM_API int libxsmm_amd_sfsspmdm_execute_batch(const libxsmm_sfsspmdm* handl
 LIBXSMM_API int libxsmm_amd_csr_kernel_source(int typesize, int M, int K, const unsigned int* row_ptr, const unsigned int* column_idx,
   const double* values, int beta0, int vec, char* buffer, size_t buffer_size, int compile);
 
+/** Text generator for dense SMM: the HIP source a descriptor (tight leading dimensions) is specialised to when a large
+ *  batch is launched (one wavefront per item, shape baked in). Same buffer/compile/return conventions as
+ *  libxsmm_amd_csr_kernel_source (reference counterpart: libxsmm_generator_gemm_kernel's "noarch" C text). */
+LIBXSMM_API int libxsmm_amd_smm_kernel_source(const libxsmm_gemm_descriptor* descriptor, char* buffer, size_t buffer_size, int compile);
+
 #endif /* LIBXSMM_AMD_H */

@@ -25,8 +25,9 @@ int run_smm(const SmmBatch& s)
 {
   const char* name = "";
   int e = -1;
-  if (0 == s.general) e = launch_smm_special(s, device().stream, &name);
-  if (e < 0) e = launch_smm_generic(s, device().stream, &name);
+  if (0 == s.general) e = launch_smm_special(s, device().stream, &name);            // hand-tuned shapes
+  if (e < 0 && smm_jit_eligible(s)) e = launch_smm_jit(s, device().stream, &name);  // shape-specialised via hiprtc
+  if (e < 0) e = launch_smm_generic(s, device().stream, &name);                     // any descriptor
   note_launch(name);
   if (0 != e) fprintf(stderr, "LIBXSMM-AMD ERROR: kernel launch failed (%s, hip error %d)\n", name, e);
   return e;
@@ -577,6 +578,27 @@ LIBXSMM_APIEXT void libxsmm_mmbatch_end(void)
   const libxsmm_blasint ptrsize = (libxsmm_blasint)sizeof(void*);
   SmmBatch s = from_descriptor(desc);
   (void)batch_execute(s, 0, 0, &ptrsize, &ptrsize, &ptrsize, pa.data(), pb.data(), pc.data(), 0, (long long)items.size(), false);
+}
+
+LIBXSMM_API int libxsmm_amd_smm_kernel_source(const libxsmm_gemm_descriptor* descriptor, char* buffer, size_t buffer_size, int compile)
+{ // the HIP text a dense descriptor is specialised to (reference counterpart: libxsmm_generator_gemm_kernel's noarch
+  // text output, src/generator_gemm_noarch.c); compile != 0 additionally runs hiprtc for gfx950 (no device needed)
+  if (nullptr == descriptor) return -1;
+  const libxsmm_gemm_descriptor& d = *descriptor;
+  const int ip = LIBXSMM_GETENUM_INP(d.datatype);
+  if (LIBXSMM_GEMM_PRECISION_F64 != ip && LIBXSMM_GEMM_PRECISION_F32 != ip) return -1;
+  const std::string src = gen_smm_source(LIBXSMM_GEMM_PRECISION_F64 == ip ? 8 : 4, (int)d.m, (int)d.n, (int)d.k, d.flags);
+  if (nullptr != buffer && 0 < buffer_size) {
+    const size_t n = (src.size() < buffer_size - 1 ? src.size() : buffer_size - 1);
+    memcpy(buffer, src.data(), n); buffer[n] = 0;
+  }
+  if (0 != compile) {
+    std::string log;
+    const int rc = jit_check_source(src, &log);
+    if (0 != rc && 0 != libxsmm_verbosity) fprintf(stderr, "LIBXSMM-AMD: hiprtc: %s\n", log.c_str());
+    return rc;
+  }
+  return (int)src.size();
 }
 
 // ---- measurement aid -----------------------------------------------------------------------------------------------

@@ -13,7 +13,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libxsmm.so")
+LIB_PATH = os.environ.get("LIBXSMM_AMD_LIBRARY", os.path.join(_HERE, "lib", "libxsmm.so"))  # override: A/B builds in tools/
 CSRC = os.path.join(_HERE, "csrc")
 
 # enum values (include/libxsmm.h; reference include/libxsmm_typedefs.h:158-213)

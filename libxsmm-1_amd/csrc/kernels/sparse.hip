@@ -75,7 +75,30 @@ void spmdm_create_kernel(long long nslices, int nrows_full, int ncols_full, int 
     uint16_t* const ci = colidx + s * cap;
     float* const va = values + s * cap;
     unsigned cnt = 0; // wave-uniform running count
-    for (int r = 0; r < nrows; ++r) {
+    int r_done = 0;
+    if (ncols <= 64) { // one 64-column chunk per row: fetch eight rows at a time, then compact them in order
+      const bool in_range = (lane < ncols);
+      for (; r_done + 8 <= nrows; r_done += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int r = r_done + u;
+          v[u] = in_range ? __builtin_nontemporal_load(transa ? (in + (size_t)lane * ld + r) : (in + (size_t)r * ld + lane)) : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (0 == lane) ri[r_done + u] = (uint16_t)cnt;
+          const bool keep = in_range && !(0.f == v[u]);
+          const unsigned long long mask = __ballot(keep);
+          if (keep) {
+            const unsigned pos = cnt + __popcll(mask & ((1ULL << lane) - 1ULL));
+            ci[pos] = (uint16_t)lane; va[pos] = v[u];
+          }
+          cnt += __popcll(mask);
+        }
+      }
+    }
+    for (int r = r_done; r < nrows; ++r) {
       if (0 == lane) ri[r] = (uint16_t)cnt;
       for (int c0 = 0; c0 < ncols; c0 += 64) {
         const int c = c0 + lane;
@@ -163,25 +186,82 @@ typedef float sp_f32x4 __attribute__((ext_vector_type(4)));
 //  LDS: the item's B tile (K x N floats, streamed with 16-byte loads), its rowidx, and a window of CSR entries packed as
 //  {float index of the B row, value} (8 bytes) so that one ds_read_b64 feeds one ds_read_b128 + 4 fma.
 //  Per C element the chain is acc = beta*C; acc = fma(val_p, B[col_p][n], acc) in row order (compute tpl :321-371).
+typedef float sp_f32x2 __attribute__((ext_vector_type(2)));
+
+// CSR entries come out of LDS with hand-placed ds_read_b64: left to the compiler, neighbouring entries are paired into
+// ds_read2_b64, which the LDS array serves at half the rate of two ds_read_b64 (MI355X_MICROARCH.md, LDS table) -- the
+// entry reads were then as expensive as the B-row reads they feed. The loads are issued without a wait; spw_landed()
+// is the matching s_waitcnt (LDS operations return in order, so the compiler's own lgkmcnt bookkeeping for the
+// ds_read_b128 it issues in between stays conservative).
+__device__ __forceinline__ unsigned spw_lds_addr(const void* p)
+{
+  return (unsigned)(size_t)p; // low half of a flat LDS address is the LDS offset
+}
+template<int U> struct SpwEntries;
+template<> struct SpwEntries<8> {
+  sp_f32x2 e[8];
+  __device__ __forceinline__ void issue(const float2* p) {
+    asm volatile("ds_read_b64 %0, %8\n\tds_read_b64 %1, %8 offset:8\n\tds_read_b64 %2, %8 offset:16\n\tds_read_b64 %3, %8 offset:24\n\t"
+                 "ds_read_b64 %4, %8 offset:32\n\tds_read_b64 %5, %8 offset:40\n\tds_read_b64 %6, %8 offset:48\n\tds_read_b64 %7, %8 offset:56"
+                 : "=&v"(e[0]), "=&v"(e[1]), "=&v"(e[2]), "=&v"(e[3]), "=&v"(e[4]), "=&v"(e[5]), "=&v"(e[6]), "=&v"(e[7])
+                 : "v"(spw_lds_addr(p)) : "memory");
+  }
+  __device__ __forceinline__ void landed() {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]), "+v"(e[4]), "+v"(e[5]), "+v"(e[6]), "+v"(e[7]) : : "memory");
+  }
+};
+template<> struct SpwEntries<4> {
+  sp_f32x2 e[4];
+  __device__ __forceinline__ void issue(const float2* p) {
+    asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:8\n\tds_read_b64 %2, %4 offset:16\n\tds_read_b64 %3, %4 offset:24"
+                 : "=&v"(e[0]), "=&v"(e[1]), "=&v"(e[2]), "=&v"(e[3]) : "v"(spw_lds_addr(p)) : "memory");
+  }
+  __device__ __forceinline__ void landed() {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]) : : "memory");
+  }
+};
+template<> struct SpwEntries<2> {
+  sp_f32x2 e[2];
+  __device__ __forceinline__ void issue(const float2* p) {
+    asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %2 offset:8" : "=&v"(e[0]), "=&v"(e[1]) : "v"(spw_lds_addr(p)) : "memory");
+  }
+  __device__ __forceinline__ void landed() {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(e[0]), "+v"(e[1]) : : "memory");
+  }
+};
+template<> struct SpwEntries<1> {
+  sp_f32x2 e[1];
+  __device__ __forceinline__ void issue(const float2* p) { e[0] = sp_f32x2{ p[0].x, p[0].y }; }
+  __device__ __forceinline__ void landed() {}
+};
+
+// acc = fma(value_u, B row of entry u, acc) for the U entries in order
+template<int U>
+__device__ __forceinline__ void spw_apply(const sp_f32x2 (&e)[U], const float* __restrict__ brow0, sp_f32x4& acc)
+{
+  sp_f32x4 bv[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) bv[u] = *reinterpret_cast<const sp_f32x4*>(brow0 + __float_as_int(e[u][0]));
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    acc[0] = xfma(e[u][1], bv[u][0], acc[0]); acc[1] = xfma(e[u][1], bv[u][1], acc[1]);
+    acc[2] = xfma(e[u][1], bv[u][2], acc[2]); acc[3] = xfma(e[u][1], bv[u][3], acc[3]);
+  }
+}
+
 template<int U>
 __device__ __forceinline__ void spw_fold(const float2* __restrict__ meta, const float* __restrict__ brow0, sp_f32x4& acc)
 {
-  float2 e[U]; sp_f32x4 bv[U];
-#pragma unroll
-  for (int u = 0; u < U; ++u) e[u] = meta[u];
-#pragma unroll
-  for (int u = 0; u < U; ++u) bv[u] = *reinterpret_cast<const sp_f32x4*>(brow0 + __float_as_int(e[u].x));
-#pragma unroll
-  for (int u = 0; u < U; ++u) {
-    acc[0] = xfma(e[u].y, bv[u][0], acc[0]); acc[1] = xfma(e[u].y, bv[u][1], acc[1]);
-    acc[2] = xfma(e[u].y, bv[u][2], acc[2]); acc[3] = xfma(e[u].y, bv[u][3], acc[3]);
-  }
+  SpwEntries<U> s;
+  s.issue(meta); s.landed();
+  spw_apply<U>(s.e, brow0, acc);
 }
 
 constexpr int SPW_LDB = 64;    // LDS row stride of the B tile in floats (N <= 64)
 constexpr int SPW_META = 2560; // CSR entries per window (>= 16 rows * 64 columns... see host check: 16*K <= SPW_META)
 
 // rows [m0, m1) of one item; their CSR entries sit in meta[] starting at entry pbase
+// (handing rows out dynamically through an LDS ticket counter was measured: 5% slower than the static stride of 16)
 __device__ __forceinline__ void spw_rows(int m0, int m1, int pbase, int g, int n0, bool active_n, int N, float beta,
                                          const unsigned short* __restrict__ ris, const float2* __restrict__ meta,
                                          const float* __restrict__ Bs, float* __restrict__ pc)
@@ -194,8 +274,10 @@ __device__ __forceinline__ void spw_rows(int m0, int m1, int pbase, int g, int n
       const sp_f32x4 cv = __builtin_nontemporal_load(reinterpret_cast<const sp_f32x4*>(pc + (size_t)m * N + n0));
       acc = (1.f == beta) ? cv : beta * cv;
     }
-    // the chain through acc is sequential, but the LDS reads are not: fetch U (entry, B row) pairs, then fold them
+    // the chain through acc is sequential, but the LDS reads are not: eight (entry, B row) pairs are fetched per step
     int p = p0;
+    // no hand pipelining across steps: measured slower (register copies or spills); the other wavefronts of the CU
+    // cover the two LDS round trips of a step
     for (; p + 8 <= p1; p += 8) spw_fold<8>(meta + p, Bs + n0, acc);
     const int rem = p1 - p;
     if (rem & 4) { spw_fold<4>(meta + p, Bs + n0, acc); p += 4; }
@@ -207,7 +289,7 @@ __device__ __forceinline__ void spw_rows(int m0, int m1, int pbase, int g, int n
 
 // NB = 16-byte pieces of the B tile per thread (tile <= NB * 1024 floats)
 template<int NB>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(256, 4) // four work-groups per CU are what the LDS footprint allows: keep VGPRs <= 128
 void spmdm_compute_wg_kernel(long long batch, int M, int N, int K, float beta,
                              const uint16_t* __restrict__ rowidx, const uint16_t* __restrict__ colidx, const float* __restrict__ values,
                              int rstride, long long cap, const float* __restrict__ b, float* __restrict__ c)
@@ -224,36 +306,40 @@ void spmdm_compute_wg_kernel(long long batch, int M, int N, int K, float beta,
   const int nv4 = tile >> 2;
   long long item = blockIdx.x;
   if (item >= batch) return;
-  int nnz = rowidx[item * rstride + M]; // every thread reads the same word; the next item's count is fetched one item ahead
-  for (; item < batch; item += gridDim.x) {
-    const uint16_t* const ci = colidx + item * cap;
-    const float* const va = values + item * cap;
-    float* const pc = c + item * (long long)M * N;
-    const bool one_window = (nnz <= SPW_META); // the common case: the whole item's CSR fits the metadata buffer
-    // ---- issue all loads of this item (B tile, rowidx, and -- single-window case -- eight CSR entries per thread)
-    sp_f32x4 rb[NB];
-    {
-      const sp_f32x4* const src = reinterpret_cast<const sp_f32x4*>(b + item * tile);
+  const long long G = gridDim.x;
+  // Register-staged pipeline: while item i is being multiplied out of LDS, the loads of item i+1 (B tile, rowidx and --
+  // when its CSR fits the metadata buffer -- its CSR entries) are in flight; entry counts are fetched two
+  // items ahead because the CSR loads of item i+1 need nnz(i+1) when they are issued.
+  // CSR entries travel two per thread and pass (entries 2*(t + 256*j), +1): the 16-byte {offset, value} x 2 pieces
+  // written to LDS are then contiguous over the lanes (a thread owning eight consecutive entries wrote with a 64-byte
+  // lane stride: four-way bank conflicts on every ds_write_b128, 10% of all LDS cycles)
+  constexpr int NJ = SPW_META / 512;
+  sp_f32x4 rb[NB]; unsigned short rix = 0; unsigned cols[NJ]; sp_f32x2 vals[NJ];
+  auto fetch = [&](long long it, int nz) {
+    const sp_f32x4* const src = reinterpret_cast<const sp_f32x4*>(b + it * tile);
 #pragma unroll
-      for (int j = 0; j < NB; ++j) { const int i = 256 * j + t; if (i < nv4) rb[j] = __builtin_nontemporal_load(src + i); }
-    }
-    const unsigned short rix = (t <= M) ? rowidx[item * rstride + t] : (unsigned short)0; // M <= 255 on this path (host check)
-    uint4 cols[2]; sp_f32x4 vals[4];
-    const int e0 = 8 * t;
-    if (one_window) {
+    for (int j = 0; j < NB; ++j) { const int i = 256 * j + t; if (i < nv4) rb[j] = __builtin_nontemporal_load(src + i); }
+    if (t <= M) rix = rowidx[it * rstride + t]; // M <= 255 on this path (host check)
+    if (nz <= SPW_META) {
+      const uint16_t* const ci = colidx + it * cap;
+      const float* const va = values + it * cap;
 #pragma unroll
-      for (int h = 0; h < 2; ++h) { // entries e0 + 2048*h .. +7 (the second pass covers 2048..SPW_META-1)
-        const int e = e0 + 2048 * h;
-        if (e < nnz) {
-          cols[h] = *reinterpret_cast<const uint4*>(ci + e);
-          vals[2 * h] = *reinterpret_cast<const sp_f32x4*>(va + e);
-          vals[2 * h + 1] = *reinterpret_cast<const sp_f32x4*>(va + e + 4);
+      for (int j = 0; j < NJ; ++j) {
+        const int e = 2 * (t + 256 * j);
+        if (e < nz) {
+          cols[j] = __builtin_nontemporal_load(reinterpret_cast<const unsigned*>(ci + e));
+          vals[j] = __builtin_nontemporal_load(reinterpret_cast<const sp_f32x2*>(va + e));
         }
       }
     }
-    const long long next = item + gridDim.x;
-    const int nnz_next = (next < batch) ? (int)rowidx[next * rstride + M] : 0;
-    // ---- park everything in LDS
+  };
+  int nnz = rowidx[item * rstride + M]; // every thread reads the same word
+  int nnz_next = (item + G < batch) ? (int)rowidx[(item + G) * rstride + M] : 0;
+  fetch(item, nnz);
+  for (; item < batch; item += G) {
+    const bool one_window = (nnz <= SPW_META); // the common case: the whole item's CSR fits the metadata buffer
+    float* const pc = c + item * (long long)M * N;
+    // ---- park this item's registers in LDS
     {
       const int n4 = N >> 2; // 16-byte pieces per B row
 #pragma unroll
@@ -265,25 +351,26 @@ void spmdm_compute_wg_kernel(long long batch, int M, int N, int K, float beta,
     if (t <= M) ris[t] = rix;
     if (one_window) {
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int e = e0 + 2048 * h;
+      for (int j = 0; j < NJ; ++j) {
+        const int e = 2 * (t + 256 * j);
         if (e < nnz) {
-          const unsigned cw[4] = { cols[h].x, cols[h].y, cols[h].z, cols[h].w };
-#pragma unroll
-          for (int q = 0; q < 4; ++q) { // two entries per 16-byte LDS write
-            const int o0 = (int)(cw[q] & 0xFFFFu) * SPW_LDB, o1 = (int)(cw[q] >> 16) * SPW_LDB;
-            const sp_f32x4 v = vals[2 * h + (q >> 1)];
-            *reinterpret_cast<sp_f32x4*>(meta + e + 2 * q) = sp_f32x4{ __int_as_float(o0), v[2 * (q & 1)], __int_as_float(o1), v[2 * (q & 1) + 1] };
-          }
+          const int o0 = (int)(cols[j] & 0xFFFFu) * SPW_LDB, o1 = (int)(cols[j] >> 16) * SPW_LDB;
+          *reinterpret_cast<sp_f32x4*>(meta + e) = sp_f32x4{ __int_as_float(o0), vals[j][0], __int_as_float(o1), vals[j][1] };
         }
       }
     }
+    // ---- next item's loads go out now
+    const long long next = item + G;
+    const int nnz_next2 = (next + G < batch) ? (int)rowidx[(next + G) * rstride + M] : 0;
+    if (next < batch) fetch(next, nnz_next);
     __syncthreads();
     if (one_window) {
       spw_rows(0, M, 0, g, n0, active_n, N, beta, ris, meta, Bs, pc);
       __syncthreads();
     }
     else { // dense items: walk the rows in windows of as many 16-row rounds as fit the metadata buffer
+      const uint16_t* const ci = colidx + item * cap;
+      const float* const va = values + item * cap;
       int m0 = 0;
       while (m0 < M) {
         int m1 = m0 + 16 < M ? m0 + 16 : M;
@@ -304,7 +391,7 @@ void spmdm_compute_wg_kernel(long long batch, int M, int N, int K, float beta,
         m0 = m1;
       }
     }
-    nnz = nnz_next;
+    nnz = nnz_next; nnz_next = nnz_next2;
   }
 }
 

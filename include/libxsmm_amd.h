@@ -89,7 +89,9 @@ LIBXSMM_API int libxsmm_amd_csr_kernel_source(int typesize, int M, int K, const 
 
 /** Text generator for dense SMM: the HIP source a descriptor (tight leading dimensions) is specialised to when a large
  *  batch is launched (one wavefront per item, shape baked in). Same buffer/compile/return conventions as
- *  libxsmm_amd_csr_kernel_source (reference counterpart: libxsmm_generator_gemm_kernel's "noarch" C text). */
-LIBXSMM_API int libxsmm_amd_smm_kernel_source(const libxsmm_gemm_descriptor* descriptor, char* buffer, size_t buffer_size, int compile);
+ *  libxsmm_amd_csr_kernel_source (reference counterpart: libxsmm_generator_gemm_kernel's "noarch" C text).
+ *  variant: 0 = strided batch of 16-byte aligned items (widest loads); bit 0 = element-wide accesses (index and pointer
+ *  batches); bit 1 = consecutive items with one C accumulate in registers (CP2K stacks, batch-reduce). */
+LIBXSMM_API int libxsmm_amd_smm_kernel_source(const libxsmm_gemm_descriptor* descriptor, int variant, char* buffer, size_t buffer_size, int compile);
 
 #endif /* LIBXSMM_AMD_H */

@@ -186,7 +186,7 @@ def _declare(L):
     sig("libxsmm_amd_gemm_batch_strided", i, vp, vp, vp, vp, ll, ll, ll, ll)
     sig("libxsmm_amd_stream_probe", i, vp, vp, vp, ll)
     sig("libxsmm_amd_csr_kernel_source", i, i, i, i, vp, vp, vp, i, i, vp, C.c_size_t, i)
-    sig("libxsmm_amd_smm_kernel_source", i, vp, vp, C.c_size_t, i)
+    sig("libxsmm_amd_smm_kernel_source", i, vp, i, vp, C.c_size_t, i)
     sig("libxsmm_amd_device_malloc", vp, C.c_size_t)
     sig("libxsmm_amd_device_free", None, vp)
 

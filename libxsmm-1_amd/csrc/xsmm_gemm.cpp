@@ -580,14 +580,15 @@ LIBXSMM_APIEXT void libxsmm_mmbatch_end(void)
   (void)batch_execute(s, 0, 0, &ptrsize, &ptrsize, &ptrsize, pa.data(), pb.data(), pc.data(), 0, (long long)items.size(), false);
 }
 
-LIBXSMM_API int libxsmm_amd_smm_kernel_source(const libxsmm_gemm_descriptor* descriptor, char* buffer, size_t buffer_size, int compile)
+LIBXSMM_API int libxsmm_amd_smm_kernel_source(const libxsmm_gemm_descriptor* descriptor, int variant, char* buffer, size_t buffer_size, int compile)
 { // the HIP text a dense descriptor is specialised to (reference counterpart: libxsmm_generator_gemm_kernel's noarch
-  // text output, src/generator_gemm_noarch.c); compile != 0 additionally runs hiprtc for gfx950 (no device needed)
+  // text output, src/generator_gemm_noarch.c); compile != 0 additionally runs hiprtc for gfx950 (no device needed).
+  // variant: bit 0 = element-wide accesses (index/pointer batches), bit 1 = runs of equal C accumulate in registers
   if (nullptr == descriptor) return -1;
   const libxsmm_gemm_descriptor& d = *descriptor;
   const int ip = LIBXSMM_GETENUM_INP(d.datatype);
   if (LIBXSMM_GEMM_PRECISION_F64 != ip && LIBXSMM_GEMM_PRECISION_F32 != ip) return -1;
-  const std::string src = gen_smm_source(LIBXSMM_GEMM_PRECISION_F64 == ip ? 8 : 4, (int)d.m, (int)d.n, (int)d.k, d.flags);
+  const std::string src = gen_smm_source(LIBXSMM_GEMM_PRECISION_F64 == ip ? 8 : 4, (int)d.m, (int)d.n, (int)d.k, d.flags, variant & 3);
   if (nullptr != buffer && 0 < buffer_size) {
     const size_t n = (src.size() < buffer_size - 1 ? src.size() : buffer_size - 1);
     memcpy(buffer, src.data(), n); buffer[n] = 0;

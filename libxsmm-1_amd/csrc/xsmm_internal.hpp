@@ -90,7 +90,8 @@ void jit_release(JitKernel* k);
 int jit_launch_panels(JitKernel* k, const void* B, void* C, long long ncols, long long ldb, long long ldc, int vec, void* stream);
 int jit_launch_raw(JitKernel* k, unsigned blocks, unsigned threads, void* arg0, size_t arg0_size, void* arg1, void* stream);
 // dense SMM kernels specialised per shape (xsmm_jit_smm.cpp)
-std::string gen_smm_source(int typesize, int m, int n, int k, int flags);
+enum { SMM_JIT_SCALAR = 1, SMM_JIT_RUNS = 2 }; // variant bits of the generated dense kernel
+std::string gen_smm_source(int typesize, int m, int n, int k, int flags, int variant);
 bool smm_jit_eligible(const SmmBatch& s);
 int launch_smm_jit(const SmmBatch& s, void* stream, const char** name); // -1: not available
 

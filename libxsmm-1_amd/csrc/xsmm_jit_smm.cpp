@@ -50,7 +50,8 @@ constexpr int AE = M * K, BE = K * N, CE = M * N;                  // elements p
 constexpr int TS = (int)sizeof(T);
 // widest access (in elements) that every item of a strided batch is aligned for
 constexpr int vw(int elems) { return (0 == (elems * TS) % 16) ? 16 / TS : ((0 == (elems * TS) % 8) ? 8 / TS : 1); }
-constexpr int VA = vw(AE), VB = vw(BE), VC = vw(CE);
+// XSCALAR: index/pointer batches guarantee element alignment only
+constexpr int VA = XSCALAR ? 1 : vw(AE), VB = XSCALAR ? 1 : vw(BE), VC = XSCALAR ? 1 : vw(CE);
 constexpr int NLA = (AE + 64 * VA - 1) / (64 * VA), NLB = (BE + 64 * VB - 1) / (64 * VB), NLC = (CE + 64 * VC - 1) / (64 * VC);
 // LDS strides: A as [k][M] (lanes with equal ty read the same words, lanes with different tx adjacent ones);
 // B as [n][KP] (TRANS_B: [k][NP]) with KP chosen so that the eight column groups fall into different banks
@@ -80,6 +81,80 @@ template<int V, int NL, int E> __device__ __forceinline__ void load_flat(const T
   }
 }
 
+// registers -> wave-private LDS (A as stored, B with the padded row stride)
+__device__ __forceinline__ void park_ab(T* As, T* Bs, int lane, const T (&ra)[NLA][VA], const T (&rb)[NLB][VB])
+{
+#pragma unroll
+  for (int j = 0; j < NLA; ++j) {
+#pragma unroll
+    for (int q = 0; q < VA; ++q) { const int e = (64 * j + lane) * VA + q; if (e < AE) As[e] = ra[j][q]; }
+  }
+#pragma unroll
+  for (int j = 0; j < NLB; ++j) {
+#pragma unroll
+    for (int q = 0; q < VB; ++q) {
+      const int e = (64 * j + lane) * VB + q;
+      if (e < BE) { if (XTRANSB) Bs[e] = rb[j][q]; else Bs[(e / K) * KP + (e % K)] = rb[j][q]; }
+    }
+  }
+}
+__device__ __forceinline__ void park_c(T* Cs, int lane, const T (&rc)[NLC][VC])
+{
+#pragma unroll
+  for (int j = 0; j < NLC; ++j) {
+#pragma unroll
+    for (int q = 0; q < VC; ++q) { const int e = (64 * j + lane) * VC + q; if (e < CE) Cs[e] = rc[j][q]; }
+  }
+}
+// acc(i,j) = fma(A(m,k), B(k,n), acc(i,j)) for k ascending: the reference's per-element chain
+__device__ __forceinline__ void multiply(const T* As, const T* Bs, int tx, int ty, T (&acc)[TM][TN])
+{
+#pragma unroll 4
+  for (int k = 0; k < K; ++k) {
+    T av[TM], bv[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) av[i] = As[k * M + tx * TM + i];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bv[j] = XTRANSB ? Bs[k * N + ty * TN + j] : Bs[(ty * TN + j) * KP + k];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = xfma(av[i], bv[j], acc[i][j]);
+    }
+  }
+}
+__device__ __forceinline__ void acc_from_c(const T* Cs, int tx, int ty, T (&acc)[TM][TN], bool zero)
+{
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int m = tx * TM + i, n = ty * TN + j;
+      acc[i][j] = (!zero && m < M && n < N) ? Cs[n * M + m] : (T)0;
+    }
+  }
+}
+// C leaves through LDS so that the stores are flat and coalesced
+__device__ __forceinline__ void store_c(T* Cs, T* pc, int lane, int tx, int ty, const T (&acc)[TM][TN])
+{
+  wave_lds_sync();
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) { const int m = tx * TM + i, n = ty * TN + j; if (m < M && n < N) Cs[n * M + m] = acc[i][j]; }
+  }
+  wave_lds_sync();
+#pragma unroll
+  for (int j = 0; j < NLC; ++j) {
+    const int e = (64 * j + lane) * VC;
+    if (e < CE) {
+      if constexpr (1 == VC) __builtin_nontemporal_store(Cs[e], pc + e);
+      else __builtin_nontemporal_store(*reinterpret_cast<const typename Vec<VC>::type*>(Cs + e), reinterpret_cast<typename Vec<VC>::type*>(pc + e));
+    }
+  }
+  wave_lds_sync();
+}
+
 extern "C" __global__ __launch_bounds__(64 * XWAVES) void xsmm_smm_op(DevAddr ad, long long batch)
 {
   __shared__ __attribute__((aligned(16))) T lds[XWAVES * WAVE_LDS];
@@ -89,34 +164,61 @@ extern "C" __global__ __launch_bounds__(64 * XWAVES) void xsmm_smm_op(DevAddr ad
   T* const Bs = As + AS_SIZE;
   T* const Cs = Bs + BS_SIZE;
   const long long w = (long long)blockIdx.x * XWAVES + wave, W = (long long)gridDim.x * XWAVES;
-  if (w >= batch) return;
   T ra[NLA][VA], rb[NLB][VB], rc[NLC][VC];
+#if XRUNS
+  // Consecutive items that share one C form a run (CP2K stacks, batch-reduce): the wave that owns the run's first item
+  // keeps C in registers and adds the products in batch order -- what the reference's sequential loop does. Run heads
+  // are found 64 items at a time (one item per lane, __ballot), chunks of 64 items are dealt round-robin to the waves.
+  for (long long chunk = w * 64; chunk < batch; chunk += W * 64) {
+    const long long it = chunk + lane;
+    bool head = false;
+    if (it < batch) head = (0 == it) || (resolve<T>(ad.c, ad.ic, ad.sc, ad, it - 1) != resolve<T>(ad.c, ad.ic, ad.sc, ad, it));
+    unsigned long long mask = __ballot(head);
+    while (0 != mask) {
+      const long long h = chunk + (__ffsll((long long)mask) - 1);
+      mask &= mask - 1;
+      long long end;
+      if (0 != mask) end = chunk + (__ffsll((long long)mask) - 1);
+      else { // the run continues into the following chunks
+        end = chunk + 64;
+        while (end < batch) {
+          const long long j = end + lane;
+          const bool hd = (j < batch) && (resolve<T>(ad.c, ad.ic, ad.sc, ad, j - 1) != resolve<T>(ad.c, ad.ic, ad.sc, ad, j));
+          const unsigned long long mk = __ballot(hd);
+          if (0 != mk) { end += (__ffsll((long long)mk) - 1); break; }
+          end += 64;
+        }
+        if (end > batch) end = batch;
+      }
+      T* const pc = resolve<T>(ad.c, ad.ic, ad.sc, ad, h);
+      if (!XBETA0) load_flat<VC, NLC, CE>(pc, lane, rc);
+      load_flat<VA, NLA, AE>(resolve<const T>(ad.a, ad.ia, ad.sa, ad, h), lane, ra);
+      load_flat<VB, NLB, BE>(resolve<const T>(ad.b, ad.ib, ad.sb, ad, h), lane, rb);
+      T acc[TM][TN];
+      if (!XBETA0) { park_c(Cs, lane, rc); wave_lds_sync(); }
+      acc_from_c(Cs, tx, ty, acc, XBETA0);
+      for (long long r = h; r < end; ++r) {
+        park_ab(As, Bs, lane, ra, rb);
+        if (r + 1 < end) { // the next product's operands are in flight during this product's arithmetic
+          load_flat<VA, NLA, AE>(resolve<const T>(ad.a, ad.ia, ad.sa, ad, r + 1), lane, ra);
+          load_flat<VB, NLB, BE>(resolve<const T>(ad.b, ad.ib, ad.sb, ad, r + 1), lane, rb);
+        }
+        wave_lds_sync();
+        multiply(As, Bs, tx, ty, acc);
+        wave_lds_sync();
+      }
+      store_c(Cs, pc, lane, tx, ty, acc);
+    }
+  }
+#else
+  if (w >= batch) return;
   load_flat<VA, NLA, AE>(resolve<const T>(ad.a, ad.ia, ad.sa, ad, w), lane, ra);
   load_flat<VB, NLB, BE>(resolve<const T>(ad.b, ad.ib, ad.sb, ad, w), lane, rb);
   if (!XBETA0) load_flat<VC, NLC, CE>(resolve<const T>(ad.c, ad.ic, ad.sc, ad, w), lane, rc);
   for (long long item = w; item < batch; item += W) {
     T* const pc = resolve<T>(ad.c, ad.ic, ad.sc, ad, item);
-    // ---- park the operands
-#pragma unroll
-    for (int j = 0; j < NLA; ++j) {
-#pragma unroll
-      for (int q = 0; q < VA; ++q) { const int e = (64 * j + lane) * VA + q; if (e < AE) As[e] = ra[j][q]; }
-    }
-#pragma unroll
-    for (int j = 0; j < NLB; ++j) {
-#pragma unroll
-      for (int q = 0; q < VB; ++q) {
-        const int e = (64 * j + lane) * VB + q;
-        if (e < BE) { if (XTRANSB) Bs[e] = rb[j][q]; else Bs[(e / K) * KP + (e % K)] = rb[j][q]; }
-      }
-    }
-    if (!XBETA0) {
-#pragma unroll
-      for (int j = 0; j < NLC; ++j) {
-#pragma unroll
-        for (int q = 0; q < VC; ++q) { const int e = (64 * j + lane) * VC + q; if (e < CE) Cs[e] = rc[j][q]; }
-      }
-    }
+    park_ab(As, Bs, lane, ra, rb);
+    if (!XBETA0) park_c(Cs, lane, rc);
     // ---- next item's loads go out before this item's arithmetic
     const long long next = item + W;
     if (next < batch) {
@@ -126,53 +228,19 @@ extern "C" __global__ __launch_bounds__(64 * XWAVES) void xsmm_smm_op(DevAddr ad
     }
     wave_lds_sync();
     T acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int m = tx * TM + i, n = ty * TN + j;
-        acc[i][j] = (!XBETA0 && m < M && n < N) ? Cs[n * M + m] : (T)0;
-      }
-    }
-#pragma unroll 4
-    for (int k = 0; k < K; ++k) {
-      T av[TM], bv[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) av[i] = As[k * M + tx * TM + i];
-#pragma unroll
-      for (int j = 0; j < TN; ++j) bv[j] = XTRANSB ? Bs[k * N + ty * TN + j] : Bs[(ty * TN + j) * KP + k];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = xfma(av[i], bv[j], acc[i][j]);
-      }
-    }
-    // ---- C leaves through LDS so that the stores are flat and coalesced
-    wave_lds_sync();
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int j = 0; j < TN; ++j) { const int m = tx * TM + i, n = ty * TN + j; if (m < M && n < N) Cs[n * M + m] = acc[i][j]; }
-    }
-    wave_lds_sync();
-#pragma unroll
-    for (int j = 0; j < NLC; ++j) {
-      const int e = (64 * j + lane) * VC;
-      if (e < CE) {
-        if constexpr (1 == VC) __builtin_nontemporal_store(Cs[e], pc + e);
-        else __builtin_nontemporal_store(*reinterpret_cast<const typename Vec<VC>::type*>(Cs + e), reinterpret_cast<typename Vec<VC>::type*>(pc + e));
-      }
-    }
-    wave_lds_sync();
+    acc_from_c(Cs, tx, ty, acc, XBETA0);
+    multiply(As, Bs, tx, ty, acc);
+    store_c(Cs, pc, lane, tx, ty, acc);
   }
+#endif
 }
 )XSMM";
 
 struct SmmKey {
-  int typesize, m, n, k, flags;
-  bool operator==(const SmmKey& o) const { return typesize == o.typesize && m == o.m && n == o.n && k == o.k && flags == o.flags; }
+  int typesize, m, n, k, flags, variant;
+  bool operator==(const SmmKey& o) const { return typesize == o.typesize && m == o.m && n == o.n && k == o.k && flags == o.flags && variant == o.variant; }
 };
-struct SmmKeyHash { size_t operator()(const SmmKey& k) const { return (size_t)(((k.m * 131 + k.n) * 131 + k.k) * 8 + k.flags * 2 + (k.typesize == 8)); } };
+struct SmmKeyHash { size_t operator()(const SmmKey& k) const { return (size_t)((((k.m * 131 + k.n) * 131 + k.k) * 8 + k.flags * 2 + (k.typesize == 8)) * 4 + k.variant); } };
 
 std::mutex g_smm_lock;
 std::unordered_map<SmmKey, JitKernel*, SmmKeyHash> g_smm_cache; // nullptr value: compilation failed, do not retry
@@ -181,7 +249,7 @@ std::unordered_map<SmmKey, JitKernel*, SmmKeyHash> g_smm_cache; // nullptr value
 
 static int smm_jit_waves(int typesize, int m, int n, int k, int flags);
 
-std::string gen_smm_source(int typesize, int m, int n, int k, int flags)
+std::string gen_smm_source(int typesize, int m, int n, int k, int flags, int variant)
 {
   std::string s = "// generated by libxsmm-amd (dense SMM kernel, shape baked in)\n";
   s += std::string("typedef ") + (8 == typesize ? "double" : "float") + " T;\n";
@@ -189,6 +257,8 @@ std::string gen_smm_source(int typesize, int m, int n, int k, int flags)
   s += std::string("#define XBETA0 ") + ((flags & LIBXSMM_GEMM_FLAG_BETA_0) ? "1" : "0") + "\n";
   s += std::string("#define XTRANSB ") + ((flags & LIBXSMM_GEMM_FLAG_TRANS_B) ? "1" : "0") + "\n";
   s += "#define XWAVES " + std::to_string(smm_jit_waves(typesize, m, n, k, flags)) + "\n";
+  s += std::string("#define XSCALAR ") + ((variant & SMM_JIT_SCALAR) ? "1" : "0") + "\n"; // element-wide loads/stores only
+  s += std::string("#define XRUNS ") + ((variant & SMM_JIT_RUNS) ? "1" : "0") + "\n";     // runs of equal C accumulate in registers
   s += SMM_JIT_BODY;
   return s;
 }
@@ -215,7 +285,8 @@ bool smm_jit_eligible(const SmmBatch& s)
 {
   const char* const env_jit = getenv("LIBXSMM_AMD_JIT"); // re-read on every call: tests and tools toggle it
   const bool enabled = (nullptr == env_jit || 0 != atoi(env_jit));
-  if (!enabled || 0 != s.general || SYNC_NONE != s.sync) return false;
+  if (!enabled || 0 != s.general || SYNC_ATOMIC == s.sync) return false;
+  if (SYNC_RUNS == s.sync && 0 != (s.flags & LIBXSMM_GEMM_FLAG_BETA_0)) return false; // (never chosen: beta == 0 needs no care)
   if (s.lda != s.m || s.ldc != s.m) return false;
   if (0 != (s.flags & LIBXSMM_GEMM_FLAG_TRANS_B) ? (s.ldb != s.n) : (s.ldb != s.k)) return false;
   if (s.m > 32 || s.n > 32 || s.k > 64) return false;                       // 8x8 lanes x (<=4x4) tile
@@ -223,20 +294,29 @@ bool smm_jit_eligible(const SmmBatch& s)
   const char* const env_min = getenv("LIBXSMM_AMD_JIT_MINBATCH");
   const long long min_batch = (nullptr != env_min && 0 != *env_min) ? atoll(env_min) : 16384LL;
   if (s.batch < min_batch) return false;                                      // compile time must be worth it
-  if (ADDR_STRIDED == s.mode) { // vector accesses need 16-byte aligned bases (strides are multiples of the item size)
+  return true;
+}
+
+// Which flavour of the generated kernel a batch needs: strided batches of tightly packed items whose bases are 16-byte
+// aligned use the widest loads the item size allows; index/pointer batches (and anything else) are only known to be
+// element-aligned. Runs of equal C (SYNC_RUNS) take the accumulate-in-registers form.
+static int smm_jit_variant(const SmmBatch& s)
+{
+  int v = (SYNC_RUNS == s.sync) ? SMM_JIT_RUNS : 0;
+  bool wide = false;
+  if (ADDR_STRIDED == s.mode) {
     const uintptr_t bits = reinterpret_cast<uintptr_t>(s.a) | reinterpret_cast<uintptr_t>(s.b) | reinterpret_cast<uintptr_t>(s.c);
-    if (0 != (bits & 15)) return false;
-    if (s.sa != (long long)s.m * s.k && 0 != s.sa) return false;
-    if (s.sb != (long long)s.k * s.n && 0 != s.sb) return false;
-    if (s.sc != (long long)s.m * s.n) return false;
-    return true;
+    wide = (0 == (bits & 15))
+        && (s.sa == (long long)s.m * s.k || 0 == s.sa) && (s.sb == (long long)s.k * s.n || 0 == s.sb)
+        && (s.sc == (long long)s.m * s.n || 0 == s.sc);
   }
-  return false; // index/pointer modes give no alignment guarantee: pre-compiled kernels
+  if (!wide) v |= SMM_JIT_SCALAR;
+  return v;
 }
 
 int launch_smm_jit(const SmmBatch& s, void* stream, const char** name)
 { // returns -1 when no specialised kernel is available
-  const SmmKey key = { s.typesize, s.m, s.n, s.k, s.flags & (LIBXSMM_GEMM_FLAG_BETA_0 | LIBXSMM_GEMM_FLAG_TRANS_B) };
+  const SmmKey key = { s.typesize, s.m, s.n, s.k, s.flags & (LIBXSMM_GEMM_FLAG_BETA_0 | LIBXSMM_GEMM_FLAG_TRANS_B), smm_jit_variant(s) };
   JitKernel* k = nullptr;
   {
     std::lock_guard<std::mutex> guard(g_smm_lock);
@@ -244,7 +324,7 @@ int launch_smm_jit(const SmmBatch& s, void* stream, const char** name)
     if (it != g_smm_cache.end()) k = it->second;
     else {
       std::string log;
-      k = jit_compile(gen_smm_source(key.typesize, key.m, key.n, key.k, key.flags), "xsmm_smm_op", &log);
+      k = jit_compile(gen_smm_source(key.typesize, key.m, key.n, key.k, key.flags, key.variant), "xsmm_smm_op", &log);
       if (nullptr == k && 0 != verbosity()) fprintf(stderr, "LIBXSMM WARNING: SMM JIT failed (%s); using the pre-compiled kernel\n", log.c_str());
       g_smm_cache.emplace(key, k);
     }
@@ -261,9 +341,13 @@ int launch_smm_jit(const SmmBatch& s, void* stream, const char** name)
   if (per_cu < 1) per_cu = 1;
   static const int bpc_env = []() { const char* e = getenv("XSMM_SMMJIT_BPC"); return (nullptr != e && 0 != *e) ? atoi(e) : 0; }();
   if (0 < bpc_env) per_cu = bpc_env;
-  long long blocks = (batch + waves - 1) / waves;
+  // run form: a wave scans chunks of 64 items for run heads, so the grid is sized by chunks
+  const long long units = (0 != (key.variant & SMM_JIT_RUNS)) ? ((batch + 63) / 64) : batch;
+  long long blocks = (units + waves - 1) / waves;
   if (blocks > 256 * per_cu) blocks = 256 * per_cu;
-  *name = (8 == s.typesize) ? "smm_f64_jit_shape" : "smm_f32_jit_shape";
+  if (blocks < 1) blocks = 1;
+  *name = (0 != (key.variant & SMM_JIT_RUNS)) ? ((8 == s.typesize) ? "smm_f64_jit_shape_runs" : "smm_f32_jit_shape_runs")
+                                                : ((8 == s.typesize) ? "smm_f64_jit_shape" : "smm_f32_jit_shape");
   return jit_launch_raw(k, (unsigned)blocks, 64u * (unsigned)waves, &ad, sizeof(ad), &batch, stream);
 }
 

@@ -22,12 +22,14 @@ def test_generated_sources_compile_for_gfx950(xs):
         for (m, n, k) in [(23, 23, 23), (13, 23, 32), (32, 32, 64), (1, 1, 1)]:
             for beta, flags in ((1.0, 0), (0.0, 0), (1.0, xs.FLAG_TRANS_B)):
                 blob, d = xs.descriptor(prec, m, n, k, beta=beta, flags=flags)
-                rc = L.libxsmm_amd_smm_kernel_source(d, buf, len(buf), 1)
-                if rc == -1:
-                    pytest.skip("libhiprtc is not available here")
-                assert rc == 0, (prec, m, n, k, beta, flags)
-                src = buf.value.decode()
-                assert "#define XM %d" % m in src and "xsmm_smm_op" in src
+                for variant in ((0, 1, 3) if beta == 1.0 else (0, 1)):  # wide / element-wide / element-wide + runs
+                    rc = L.libxsmm_amd_smm_kernel_source(d, variant, buf, len(buf), 1)
+                    if rc == -1:
+                        pytest.skip("libhiprtc is not available here")
+                    assert rc == 0, (prec, m, n, k, beta, flags, variant)
+                    src = buf.value.decode()
+                    assert "#define XM %d" % m in src and "xsmm_smm_op" in src
+                    assert "#define XRUNS %d" % (variant >> 1) in src
     # fixed-sparsity operator
     rng = np.random.default_rng(0)
     M, K = 35, 35
@@ -85,3 +87,88 @@ def test_jit_dense_kernels_bitexact(xs, orc, torch_gpu, dtype, shape):
             del os.environ["LIBXSMM_AMD_JIT_MINBATCH"]
         else:
             os.environ["LIBXSMM_AMD_JIT_MINBATCH"] = old_env
+
+
+class _JitForced:
+    """Lets small test batches take the run-time specialised kernels (normally reserved for batches >= 16384)."""
+    def __init__(self, xs):
+        self.xs = xs
+    def __enter__(self):
+        self.old_env = os.environ.get("LIBXSMM_AMD_JIT_MINBATCH")
+        os.environ["LIBXSMM_AMD_JIT_MINBATCH"] = "1"
+        self.old = self.xs.lib().libxsmm_amd_set_mfma(0)
+    def __exit__(self, *exc):
+        self.xs.lib().libxsmm_amd_set_mfma(self.old)
+        if self.old_env is None:
+            del os.environ["LIBXSMM_AMD_JIT_MINBATCH"]
+        else:
+            os.environ["LIBXSMM_AMD_JIT_MINBATCH"] = self.old_env
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("shape", [(23, 23, 23), (13, 13, 13), (13, 23, 32), (32, 32, 32), (5, 7, 3)])
+def test_jit_index_batches_and_runs_bitexact(xs, orc, torch_gpu, dtype, shape):
+    """Index-array batches (src/libxsmm_gemm.c:1333-1364) on the specialised kernels: shuffled operands with distinct C
+    (element-wide accesses), then CP2K-style stacks whose consecutive products share a C (samples/cp2k/cp2k.cpp:328-360):
+    runs accumulate in registers, in batch order -- the reference's sequential chain, bit for bit."""
+    torch = torch_gpu
+    m, n, k = shape
+    batch = 777
+    rng = np.random.default_rng(m * 31 + n * 7 + k)
+    prec = xs.F64 if dtype == np.float64 else xs.F32
+    a = rng.uniform(-1, 1, batch * m * k).astype(dtype); b = rng.uniform(-1, 1, batch * k * n).astype(dtype)
+    with _JitForced(xs):
+        # (1) permuted A/B, distinct C, index_base 1
+        c = rng.uniform(-1, 1, batch * m * n).astype(dtype)
+        sa = (rng.permutation(batch) * m * k + 1).astype(np.int32); sb = (rng.permutation(batch) * k * n + 1).astype(np.int32)
+        sc = (np.arange(batch) * m * n + 1).astype(np.int32)
+        ref = c.copy()
+        assert 0 == orc.gemm_batch_idx(orc.FMA, 0, m, n, k, m, k, m, a, b, ref, 1, sa, sb, sc, batch)
+        da, db, dc = (torch.from_numpy(x).cuda() for x in (a, b, c))
+        xs.gemm_batch(prec, "N", "N", m, n, k, 1.0, da, m, db, k, 1.0, dc, m, 1, 4, sa, sb, sc, batch)
+        torch.cuda.synchronize()
+        special = (shape == (32, 32, 32) and dtype == np.float32)  # independent C: the hand-tuned kernel keeps this shape
+        assert xs.last_kernel() == ("smm_f32_32x32x32_fma" if special else ("smm_f%d_jit_shape" % (64 if dtype == np.float64 else 32))), xs.last_kernel()
+        assert np.array_equal(dc.cpu().numpy(), ref)
+        # (2) runs of very different lengths (1 .. >64 so that a run crosses the 64-item scan chunks), some C untouched
+        lens = [1, 1, 2, 3, 64, 65, 130, 1, 7, 200, 1, 1, 1, 1, 1]
+        lens = np.array(lens + [batch - sum(lens)], dtype=np.int64)
+        nc = len(lens)
+        owners = np.sort(rng.choice(np.arange(nc + 5), size=nc, replace=False))  # increasing C blocks, with gaps
+        cidx = np.repeat(owners, lens)
+        assert len(cidx) == batch
+        c2 = rng.uniform(-1, 1, (nc + 5) * m * n).astype(dtype)
+        sa0 = (np.arange(batch) * m * k).astype(np.int32); sb0 = (np.arange(batch) * k * n).astype(np.int32); sc0 = (cidx * m * n).astype(np.int32)
+        ref2 = c2.copy()
+        assert 0 == orc.gemm_batch_idx(orc.FMA, 0, m, n, k, m, k, m, a, b, ref2, 0, sa0, sb0, sc0, batch)
+        dc2 = torch.from_numpy(c2).cuda()
+        xs.gemm_batch(prec, "N", "N", m, n, k, 1.0, da, m, db, k, 1.0, dc2, m, 0, 4, sa0, sb0, sc0, batch)
+        torch.cuda.synchronize()
+        assert xs.last_kernel().endswith("_jit_shape_runs"), xs.last_kernel()
+        assert np.array_equal(dc2.cpu().numpy(), ref2)
+
+
+@pytest.mark.gpu
+def test_jit_pointer_batches_with_runs(xs, orc, torch_gpu):
+    """Arrays of pointers (src/libxsmm_gemm.c:1426-1461) with repeated consecutive C pointers."""
+    torch = torch_gpu
+    m, n, k = 23, 13, 32
+    batch, nc = 300, 9
+    rng = np.random.default_rng(77)
+    a = rng.uniform(-1, 1, batch * m * k); b = rng.uniform(-1, 1, batch * k * n); c = rng.uniform(-1, 1, nc * m * n)
+    cidx = np.sort(rng.integers(0, nc, batch))
+    ref = c.copy()
+    sa = (np.arange(batch) * m * k).astype(np.int32); sb = (np.arange(batch) * k * n).astype(np.int32); sc = (cidx * m * n).astype(np.int32)
+    assert 0 == orc.gemm_batch_idx(orc.FMA, 0, m, n, k, m, k, m, a, b, ref, 0, sa, sb, sc, batch)
+    da, db, dc = (torch.from_numpy(x).cuda() for x in (a, b, c))
+    pa = (da.data_ptr() + np.arange(batch, dtype=np.uint64) * np.uint64(m * k * 8)).astype(np.uint64)
+    pb = (db.data_ptr() + np.arange(batch, dtype=np.uint64) * np.uint64(k * n * 8)).astype(np.uint64)
+    pc = (dc.data_ptr() + cidx.astype(np.uint64) * np.uint64(m * n * 8)).astype(np.uint64)
+    dpa, dpb, dpc = (torch.from_numpy(x.view(np.int64)).cuda() for x in (pa, pb, pc))
+    ptrsize = np.array([8], dtype=np.int32)
+    with _JitForced(xs):
+        xs.gemm_batch(xs.F64, "N", "N", m, n, k, 1.0, dpa, m, dpb, k, 1.0, dpc, m, 0, 0, ptrsize, ptrsize, ptrsize, batch)
+        torch.cuda.synchronize()
+        assert xs.last_kernel().endswith("_jit_shape_runs"), xs.last_kernel()
+    assert np.array_equal(dc.cpu().numpy(), ref)

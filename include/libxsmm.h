@@ -483,6 +483,9 @@ LIBXSMM_API int libxsmm_blocked_gemm_copyin_a(const libxsmm_blocked_gemm_handle*
 LIBXSMM_API int libxsmm_blocked_gemm_copyin_b(const libxsmm_blocked_gemm_handle* handle, const void* src, const libxsmm_blasint* ld, void* dst);
 LIBXSMM_API int libxsmm_blocked_gemm_copyin_c(const libxsmm_blocked_gemm_handle* handle, const void* src, const libxsmm_blasint* ld, void* dst);
 LIBXSMM_API int libxsmm_blocked_gemm_copyout_c(const libxsmm_blocked_gemm_handle* handle, const void* src, const libxsmm_blasint* ld, void* dst);
+/* blocked -> blocked permutations (include/libxsmm_blocked_gemm.h:77-79); `ld` is ignored, as in the reference */
+LIBXSMM_API int libxsmm_blocked_gemm_convert_b_to_a(const libxsmm_blocked_gemm_handle* handle, const void* src, const libxsmm_blasint* ld, void* dst);
+LIBXSMM_API int libxsmm_blocked_gemm_transpose_b(const libxsmm_blocked_gemm_handle* handle, const void* src, const libxsmm_blasint* ld, void* dst);
 LIBXSMM_API void libxsmm_blocked_gemm_st(const libxsmm_blocked_gemm_handle* handle, const void* a, const void* b, void* c,
   /*unsigned*/int start_thread, /*unsigned*/int tid);
 LIBXSMM_APIEXT void libxsmm_blocked_gemm_omp(const libxsmm_blocked_gemm_handle* handle,
@@ -491,6 +494,17 @@ LIBXSMM_APIEXT void libxsmm_blocked_gemm_omp(const libxsmm_blocked_gemm_handle* 
 /* ---------------------------------------------------------------------------------------------
  * helpers the hot-path samples link (include/libxsmm_malloc.h, _timer.h, _rng.h, _math.h)
  * --------------------------------------------------------------------------------------------- */
+/* custom default allocator (include/libxsmm_malloc.h:36-64): malloc_fn/free_fn come as a pair, two NULLs restore the
+ * built-in allocator (pinned host memory that the GPU addresses directly); buffers are released by the allocator that
+ * made them */
+typedef void* (*libxsmm_malloc_ctx)(void* context, size_t size);
+typedef void* (*libxsmm_malloc_fun)(size_t size);
+typedef union libxsmm_malloc_function { libxsmm_malloc_ctx ctx_form; libxsmm_malloc_fun function; } libxsmm_malloc_function;
+typedef void (*libxsmm_free_ctx)(void* context, void* buffer);
+typedef void (*libxsmm_free_fun)(void* buffer);
+typedef union libxsmm_free_function { libxsmm_free_ctx ctx_form; libxsmm_free_fun function; } libxsmm_free_function;
+LIBXSMM_API int libxsmm_set_default_allocator(void* context, libxsmm_malloc_function malloc_fn, libxsmm_free_function free_fn);
+LIBXSMM_API int libxsmm_get_default_allocator(void** context, libxsmm_malloc_function* malloc_fn, libxsmm_free_function* free_fn);
 LIBXSMM_API void* libxsmm_malloc(size_t size);                                /* include/libxsmm_malloc.h:73 */
 LIBXSMM_API void* libxsmm_aligned_malloc(size_t size, size_t alignment);      /* :67 */
 LIBXSMM_API void libxsmm_free(const void* memory);                            /* :89 */
@@ -504,7 +518,39 @@ LIBXSMM_API unsigned int libxsmm_rng_u32(unsigned int n);                     /*
 LIBXSMM_API void libxsmm_rng_f32_seq(float* rngs, libxsmm_blasint count);     /* :47 */
 LIBXSMM_API size_t libxsmm_shuffle(unsigned int n);                           /* include/libxsmm_math.h:99 */
 LIBXSMM_API unsigned int libxsmm_isqrt_u64(unsigned long long x);             /* :102 */
+
+/* ---------------------------------------------------------------------------------------------
+ * text generators (include/libxsmm_generator.h:120-215, src/generator_spgemm.c, src/generator_gemm.c). On this target
+ * the text is HIP source for gfx950: the sparsity pattern (and, for the csr_reg form, the values) become code, one
+ * statement per non-zero, exactly as in the reference's C text -- but the emitted kernel walks a batch
+ * (arguments A, B, C as in the reference, then stride_dense, stride_c, batch in elements/items).
+ * Error codes are the reference's (src/generator_common.h:267-320: 90007 lda, 90008 ldb, 90009 ldc, 90010 "which operand
+ * is sparse?", 90011-90015/90035-90039 reader errors, 90049 datatype); libxsmm_strerror translates them.
+ * --------------------------------------------------------------------------------------------- */
+typedef struct libxsmm_generated_code { /* include/libxsmm_generator.h:248-265 */
+  void* generated_code;       /* malloc'ed, NUL-terminated text (the caller frees it) */
+  unsigned int buffer_size;   /* bytes allocated */
+  unsigned int code_size;     /* bytes used */
+  unsigned int code_type;     /* 0: source text (the only form generated here); > 1 is rejected */
+  unsigned int last_error;    /* 0, or an error code for libxsmm_strerror */
+} libxsmm_generated_code;
 LIBXSMM_API const char* libxsmm_strerror(unsigned int i_error_code);          /* include/libxsmm_generator.h:271 */
+/* dense kernel: complete translation unit, kernel name "xsmm_smm_op" / i_routine_name */
+LIBXSMM_API void libxsmm_generator_gemm_kernel(libxsmm_generated_code* io_generated_code, const libxsmm_gemm_descriptor* i_xgemm_desc, const char* i_arch);
+LIBXSMM_API void libxsmm_generator_gemm_inlineasm(const char* i_file_out, const char* i_routine_name, const libxsmm_gemm_descriptor* i_xgemm_desc, const char* i_arch);
+LIBXSMM_API void libxsmm_generator_gemm_directasm(const char* i_file_out, const char* i_routine_name, const libxsmm_gemm_descriptor* i_xgemm_desc, const char* i_arch);
+/* sparse kernels: lda == 0 marks A as the sparse operand, ldb == 0 marks B (src/generator_spgemm.c:55-145). The *_kernel
+ * entry points append the statements of the kernel body (csr_reg: a complete translation unit);
+ * libxsmm_generator_spgemm reads a MatrixMarket file (i_is_csr: 0 CSC, 1 CSR, 3 CSR with baked-in values), adds the
+ * signature and appends the kernel to i_file_out; like the reference it terminates the process on errors. */
+LIBXSMM_API void libxsmm_generator_spgemm(const char* i_file_out, const char* i_routine_name, const libxsmm_gemm_descriptor* i_xgemm_desc,
+  const char* i_arch, const char* i_file_in, const int i_is_csr);
+LIBXSMM_API void libxsmm_generator_spgemm_csc_kernel(libxsmm_generated_code* io_generated_code, const libxsmm_gemm_descriptor* i_xgemm_desc,
+  const char* i_arch, const unsigned int* i_row_idx, const unsigned int* i_column_idx, const double* i_values);
+LIBXSMM_API void libxsmm_generator_spgemm_csr_kernel(libxsmm_generated_code* io_generated_code, const libxsmm_gemm_descriptor* i_xgemm_desc,
+  const char* i_arch, const unsigned int* i_row_idx, const unsigned int* i_column_idx, const double* i_values);
+LIBXSMM_API void libxsmm_generator_spgemm_csr_reg_kernel(libxsmm_generated_code* io_generated_code, const libxsmm_gemm_descriptor* i_xgemm_desc,
+  const char* i_arch, const unsigned int* i_row_idx, const unsigned int* i_column_idx, const double* i_values);
 
 typedef struct libxsmm_matdiff_info { /* include/libxsmm_math.h:40-55 */
   double norm1_abs, norm1_rel;
@@ -519,6 +565,15 @@ LIBXSMM_API int libxsmm_matdiff(libxsmm_matdiff_info* info, libxsmm_datatype dat
   const void* ref, const void* tst, const libxsmm_blasint* ldref, const libxsmm_blasint* ldtst); /* :62 */
 LIBXSMM_API void libxsmm_matdiff_reduce(libxsmm_matdiff_info* output, const libxsmm_matdiff_info* input); /* :69 */
 LIBXSMM_API void libxsmm_matdiff_clear(libxsmm_matdiff_info* info);                                       /* :71 */
+/* prints a GEMM call's arguments to `ostream` (a FILE*), include/libxsmm_frontend.h:471-482; ostream == NULL (the
+ * reference's MHD image dump of the operands) is a no-op here */
+LIBXSMM_API void libxsmm_gemm_print(void* ostream, libxsmm_gemm_precision precision, const char* transa, const char* transb,
+  const libxsmm_blasint* m, const libxsmm_blasint* n, const libxsmm_blasint* k, const void* alpha, const void* a, const libxsmm_blasint* lda,
+  const void* b, const libxsmm_blasint* ldb, const void* beta, void* c, const libxsmm_blasint* ldc);
+LIBXSMM_API void libxsmm_gemm_print2(void* ostream, libxsmm_gemm_precision iprec, libxsmm_gemm_precision oprec,
+  const char* transa, const char* transb, const libxsmm_blasint* m, const libxsmm_blasint* n, const libxsmm_blasint* k,
+  const void* alpha, const void* a, const libxsmm_blasint* lda, const void* b, const libxsmm_blasint* ldb,
+  const void* beta, void* c, const libxsmm_blasint* ldc);
 
 #include "libxsmm_amd.h"
 

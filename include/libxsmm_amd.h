@@ -94,4 +94,21 @@ LIBXSMM_API int libxsmm_amd_csr_kernel_source(int typesize, int M, int K, const 
  *  batches); bit 1 = consecutive items with one C accumulate in registers (CP2K stacks, batch-reduce). */
 LIBXSMM_API int libxsmm_amd_smm_kernel_source(const libxsmm_gemm_descriptor* descriptor, int variant, char* buffer, size_t buffer_size, int compile);
 
+/** Executable form of the sparse text kernels (libxsmm_generator_spgemm_{csr,csc}_kernel): the pattern is compiled into
+ *  a kernel with hiprtc, the values of the sparse operand stay a run-time argument (as for the reference's generated C
+ *  functions, samples/generator/validation.c). descriptor: lda == 0 marks A sparse, ldb == 0 marks B sparse; is_csr != 0:
+ *  row_idx = row pointers, column_idx = column of each entry; is_csr == 0: column_idx = column pointers, row_idx = row of
+ *  each entry. fma: 1 = fused multiply-add, 0 = multiply then add (the statement as written), < 0 = default
+ *  (LIBXSMM_AMD_SPGEMM_FMA, fused). One launch processes `batch` products that share the sparse operand: the dense
+ *  operand and C advance by stride_dense / stride_c elements per item. Operands may live on the host (staged). */
+typedef struct libxsmm_amd_spgemm libxsmm_amd_spgemm;
+LIBXSMM_API libxsmm_amd_spgemm* libxsmm_amd_spgemm_create(const libxsmm_gemm_descriptor* descriptor, int is_csr,
+  const unsigned int* row_idx, const unsigned int* column_idx, int fma);
+LIBXSMM_API int libxsmm_amd_spgemm_execute_batch(const libxsmm_amd_spgemm* handle, const void* sparse_values, const void* dense, void* c,
+  long long stride_dense, long long stride_c, long long batch);
+LIBXSMM_API void libxsmm_amd_spgemm_destroy(const libxsmm_amd_spgemm* handle);
+/** The text libxsmm_amd_spgemm_create compiles (buffer/compile/return conventions of libxsmm_amd_csr_kernel_source). */
+LIBXSMM_API int libxsmm_amd_spgemm_source(const libxsmm_gemm_descriptor* descriptor, int is_csr, const unsigned int* row_idx,
+  const unsigned int* column_idx, int fma, char* buffer, size_t buffer_size, int compile);
+
 #endif /* LIBXSMM_AMD_H */

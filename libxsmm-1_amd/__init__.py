@@ -49,6 +49,19 @@ class CSRSlice(C.Structure):  # libxsmm_CSR_sparseslice
     _fields_ = [("rowidx", C.c_void_p), ("colidx", C.c_void_p), ("values", C.c_void_p)]
 
 
+class GeneratedCode(C.Structure):  # libxsmm_generated_code
+    _fields_ = [("generated_code", C.c_void_p), ("buffer_size", C.c_uint), ("code_size", C.c_uint), ("code_type", C.c_uint),
+                ("last_error", C.c_uint)]
+
+    def text(self):
+        return C.string_at(self.generated_code, self.code_size).decode() if self.generated_code else ""
+
+    def release(self):
+        if self.generated_code:
+            C.CDLL(None).free(C.c_void_p(self.generated_code))
+            self.generated_code = None
+
+
 class MatdiffInfo(C.Structure):
     _fields_ = [(n, C.c_double) for n in (
         "norm1_abs", "norm1_rel", "normi_abs", "normi_rel", "normf_rel", "linf_abs", "linf_rel", "l2_abs", "l2_rel",
@@ -156,7 +169,7 @@ def _declare(L):
     sig("libxsmm_blocked_gemm_handle_create", vp, i, i, i, i, i, i, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p,
         vp, vp, c_int_p, c_int_p, c_int_p)
     sig("libxsmm_blocked_gemm_handle_destroy", None, vp)
-    for nm in ("copyin_a", "copyin_b", "copyin_c", "copyout_c"):
+    for nm in ("copyin_a", "copyin_b", "copyin_c", "copyout_c", "convert_b_to_a", "transpose_b"):
         sig("libxsmm_blocked_gemm_" + nm, i, vp, vp, c_int_p, vp)
     sig("libxsmm_blocked_gemm_st", None, vp, vp, vp, vp, i, i)
     sig("libxsmm_blocked_gemm_omp", None, vp, vp, vp, vp, i)
@@ -186,6 +199,18 @@ def _declare(L):
     sig("libxsmm_amd_gemm_batch_strided", i, vp, vp, vp, vp, ll, ll, ll, ll)
     sig("libxsmm_amd_stream_probe", i, vp, vp, vp, ll)
     sig("libxsmm_amd_csr_kernel_source", i, i, i, i, vp, vp, vp, i, i, vp, C.c_size_t, i)
+    gc = C.POINTER(GeneratedCode)
+    sig("libxsmm_strerror", C.c_char_p, C.c_uint)
+    sig("libxsmm_generator_gemm_kernel", None, gc, vp, C.c_char_p)
+    sig("libxsmm_generator_gemm_inlineasm", None, C.c_char_p, C.c_char_p, vp, C.c_char_p)
+    sig("libxsmm_generator_gemm_directasm", None, C.c_char_p, C.c_char_p, vp, C.c_char_p)
+    sig("libxsmm_generator_spgemm", None, C.c_char_p, C.c_char_p, vp, C.c_char_p, C.c_char_p, i)
+    for nm in ("csr", "csc", "csr_reg"):
+        sig("libxsmm_generator_spgemm_%s_kernel" % nm, None, gc, vp, C.c_char_p, vp, vp, vp)
+    sig("libxsmm_amd_spgemm_create", vp, vp, i, vp, vp, i)
+    sig("libxsmm_amd_spgemm_execute_batch", i, vp, vp, vp, vp, ll, ll, ll)
+    sig("libxsmm_amd_spgemm_destroy", None, vp)
+    sig("libxsmm_amd_spgemm_source", i, vp, i, vp, vp, i, vp, C.c_size_t, i)
     sig("libxsmm_amd_smm_kernel_source", i, vp, i, vp, C.c_size_t, i)
     sig("libxsmm_amd_device_malloc", vp, C.c_size_t)
     sig("libxsmm_amd_device_free", None, vp)

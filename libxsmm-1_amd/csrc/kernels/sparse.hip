@@ -161,7 +161,7 @@ void bgemm_copy_kernel(int which, const T* __restrict__ src, int ld, T* __restri
                        int mb, int nb, int kb, int bm, int bn, int bk)
 {
   long long total;
-  if (0 == which) total = (long long)mb * kb * bk * bm; else if (1 == which) total = (long long)nb * kb * bn * bk; else total = (long long)nb * mb * bn * bm;
+  if (0 == which) total = (long long)mb * kb * bk * bm; else if (1 == which || 5 == which) total = (long long)nb * kb * bn * bk; else total = (long long)nb * mb * bn * bm;
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
     if (0 == which) { // A: dst[mb][kb][bk][bm] = src[(kb*bk+k)*ld + mb*bm+m]
       const int m = (int)(e % bm); long long r = e / bm; const int k = (int)(r % bk); r /= bk; const int ikb = (int)(r % kb); const int imb = (int)(r / kb);
@@ -170,6 +170,22 @@ void bgemm_copy_kernel(int which, const T* __restrict__ src, int ld, T* __restri
     else if (1 == which) { // B: dst[nb][kb][bn][bk] = src[(nb*bn+n)*ld + kb*bk+k]
       const int k = (int)(e % bk); long long r = e / bk; const int n = (int)(r % bn); r /= bn; const int ikb = (int)(r % kb); const int inb = (int)(r / kb);
       dst[e] = src[((size_t)inb * bn + n) * ld + (size_t)ikb * bk + k];
+    }
+    else if (4 == which) { // convert_b_to_a (template/libxsmm_blocked_gemm_convert_b_to_a.tpl.c:32-46): dst[mb][nb][bn][bm] = src[nb][mb][bn][bm]
+      const int m = (int)(e % bm); long long r = e / bm; const int n = (int)(r % bn); r /= bn; const int inb = (int)(r % nb); const int imb = (int)(r / nb);
+      dst[e] = src[(((size_t)inb * mb + imb) * bn + n) * bm + m];
+    }
+    else if (5 == which) { // transpose_b (template/libxsmm_blocked_gemm_transpose_b.tpl.c:32-65): e walks src[kb][nb][bk][bn]
+      const int n = (int)(e % bn); long long r = e / bn; const int k = (int)(r % bk); r /= bk; const int inb = (int)(r % nb); const int ikb = (int)(r / nb);
+      const int N = nb * bn, K = kb * bk;
+      size_t d;
+      if (N == K && bn == bk) d = (((size_t)inb * kb + ikb) * bn + n) * bk + k;
+      else { // the reference's generic branch: linear position -> (row, col) of a K-wide matrix -> transposed linear position
+        const long long job = ((long long)ikb * bk + k) * N + ((long long)inb * bn + n);
+        const long long ii = job / K, jj = job % K, jobt = jj * N + ii;
+        d = ((((size_t)(jobt / K) / bn) * kb + (size_t)(jobt % K) / bk) * bn + (size_t)(jobt / K) % bn) * bk + (size_t)(jobt % K) % bk;
+      }
+      dst[d] = src[e];
     }
     else { // C: blocked[nb][mb][bn][bm] <-> plain[(nb*bn+n)*ld + mb*bm+m]
       const int m = (int)(e % bm); long long r = e / bm; const int n = (int)(r % bn); r /= bn; const int imb = (int)(r % mb); const int inb = (int)(r / mb);
@@ -497,7 +513,7 @@ int launch_spmdm_compute(const SpmdmGeom& g, int transb, int transc, float beta,
 int launch_bgemm_copy(const BgemmGeom& g, int which, const void* src, int ld, void* dst, void* stream)
 {
   hipStream_t st = (hipStream_t)stream;
-  const long long total = (0 == which) ? (long long)g.m * g.k : ((1 == which) ? (long long)g.n * g.k : (long long)g.m * g.n);
+  const long long total = (0 == which) ? (long long)g.m * g.k : ((1 == which || 5 == which) ? (long long)g.n * g.k : (long long)g.m * g.n);
   if (8 == g.typesize) {
     hipLaunchKernelGGL((bgemm_copy_kernel<double>), dim3(grid_for(total, 256)), dim3(256), 0, st, which, (const double*)src, ld, (double*)dst,
       g.mb, g.nb, g.kb, g.bm, g.bn, g.bk);

@@ -123,6 +123,33 @@ int bgemm_copy(const libxsmm_blocked_gemm_handle* h, int which, const void* src,
 }
 }
 
+namespace {
+// blocked -> blocked permutations (reference src/libxsmm_blocked_gemm.c:369-466; like there, `ld` is ignored)
+int bgemm_permute(const libxsmm_blocked_gemm_handle* h, int which, const void* src, void* dst)
+{
+  static int error_once = 0;
+  if (nullptr == h) {
+    if (0 != libxsmm_verbosity && once(&error_once)) fprintf(stderr, "LIBXSMM ERROR: BGEMM-handle cannot be NULL!\n");
+    return EXIT_FAILURE;
+  }
+  if (nullptr == src || nullptr == dst) return EXIT_FAILURE;
+  if (!device_ready()) { fail_no_device("libxsmm_blocked_gemm_convert/transpose"); return EXIT_FAILURE; }
+  BgemmGeom g; g.typesize = h->typesize; g.m = h->m; g.n = h->n; g.k = h->k; g.bm = h->bm; g.bn = h->bn; g.bk = h->bk; g.mb = h->mb; g.nb = h->nb; g.kb = h->kb;
+  const size_t bytes = (size_t)(4 == which ? (size_t)h->m * h->n : (size_t)h->k * h->n) * h->typesize;
+  const void* ds = src; void* dd = dst;
+  const bool src_host = !is_device_ptr(src), dst_host = !is_device_ptr(dst);
+  if (src_host) { void* t = scratch(3, bytes); if (nullptr == t || 0 != h2d(t, src, bytes)) return EXIT_FAILURE; ds = t; }
+  if (dst_host) { void* t = scratch(4, bytes); if (nullptr == t) return EXIT_FAILURE; dd = t; }
+  const int e = launch_bgemm_copy(g, which, ds, 0, dd, device().stream); note_launch(4 == which ? "bgemm_convert_b_to_a" : "bgemm_transpose_b");
+  if (0 != e) return EXIT_FAILURE;
+  if (dst_host) return 0 == d2h(dst, dd, bytes) ? EXIT_SUCCESS : EXIT_FAILURE;
+  if (src_host) return 0 == stream_sync() ? EXIT_SUCCESS : EXIT_FAILURE;
+  return EXIT_SUCCESS;
+}
+}
+
+LIBXSMM_API int libxsmm_blocked_gemm_convert_b_to_a(const libxsmm_blocked_gemm_handle* handle, const void* src, const libxsmm_blasint* ld, void* dst) { (void)ld; return bgemm_permute(handle, 4, src, dst); }
+LIBXSMM_API int libxsmm_blocked_gemm_transpose_b(const libxsmm_blocked_gemm_handle* handle, const void* src, const libxsmm_blasint* ld, void* dst) { (void)ld; return bgemm_permute(handle, 5, src, dst); }
 LIBXSMM_API int libxsmm_blocked_gemm_copyin_a(const libxsmm_blocked_gemm_handle* handle, const void* src, const libxsmm_blasint* ld, void* dst) { return bgemm_copy(handle, 0, src, ld, dst); }
 LIBXSMM_API int libxsmm_blocked_gemm_copyin_b(const libxsmm_blocked_gemm_handle* handle, const void* src, const libxsmm_blasint* ld, void* dst) { return bgemm_copy(handle, 1, src, ld, dst); }
 LIBXSMM_API int libxsmm_blocked_gemm_copyin_c(const libxsmm_blocked_gemm_handle* handle, const void* src, const libxsmm_blasint* ld, void* dst) { return bgemm_copy(handle, 2, src, ld, dst); }

@@ -88,6 +88,7 @@ JitKernel* jit_compile(const std::string& src, const char* fname, std::string* l
 int jit_check_source(const std::string& src, std::string* log);
 void jit_release(JitKernel* k);
 int jit_launch_panels(JitKernel* k, const void* B, void* C, long long ncols, long long ldb, long long ldc, int vec, void* stream);
+int jit_launch_args(JitKernel* k, unsigned blocks, unsigned threads, void** args, void* stream);
 int jit_launch_raw(JitKernel* k, unsigned blocks, unsigned threads, void* arg0, size_t arg0_size, void* arg1, void* stream);
 // dense SMM kernels specialised per shape (xsmm_jit_smm.cpp)
 enum { SMM_JIT_SCALAR = 1, SMM_JIT_RUNS = 2 }; // variant bits of the generated dense kernel
@@ -108,7 +109,7 @@ int launch_spmdm_compute(const SpmdmGeom& g, int transb, int transc, float beta,
 
 // blocked_gemm helpers (layouts of template/libxsmm_blocked_gemm_copy*.tpl.c)
 struct BgemmGeom { int typesize, m, n, k, bm, bn, bk, mb, nb, kb; };
-int launch_bgemm_copy(const BgemmGeom& g, int which /*0:A 1:B 2:C-in 3:C-out*/, const void* src, int ld, void* dst, void* stream);
+int launch_bgemm_copy(const BgemmGeom& g, int which /*0:A 1:B 2:C-in 3:C-out 4:convert_b_to_a 5:transpose_b (blocked -> blocked)*/, const void* src, int ld, void* dst, void* stream);
 int launch_bgemm_compute(const BgemmGeom& g, int beta0, const void* a, const void* b, void* c, void* stream, const char** name);
 
 // ---- host runtime ------------------------------------------------------------------------------------

@@ -20,22 +20,57 @@ using namespace xsmm;
 // allocate their operands through the library (samples/spmdm/spmdm.c:205-209) run without staging copies.
 namespace {
 std::mutex g_alloc_lock;
-std::unordered_map<const void*, int> g_allocs; // ptr -> 1: pinned (hipHostFree), 0: aligned_alloc (free)
+struct AllocInfo { int kind; void* base; void* context; libxsmm_free_function free_fn; };
+// kind 1: pinned (hipHostFree), 0: posix_memalign (free), 2: caller's allocator (base/context/free_fn as of allocation)
+std::unordered_map<const void*, AllocInfo> g_allocs;
+// custom default allocator (reference include/libxsmm_malloc.h:53-64); both NULL: library default
+void* g_alloc_context = nullptr;
+libxsmm_malloc_function g_alloc_malloc = { nullptr };
+libxsmm_free_function g_alloc_free = { nullptr };
+}
+
+LIBXSMM_API int libxsmm_set_default_allocator(void* context, libxsmm_malloc_function malloc_fn, libxsmm_free_function free_fn)
+{ // malloc_fn and free_fn must come as a pair; two NULLs restore the built-in (pinned host memory) allocator
+  if ((nullptr == malloc_fn.function) != (nullptr == free_fn.function)) {
+    static int error_once = 0;
+    if (0 != libxsmm_verbosity && once(&error_once)) fprintf(stderr, "LIBXSMM ERROR: allocator setup without malloc or free function!\n");
+    return EXIT_FAILURE;
+  }
+  std::lock_guard<std::mutex> guard(g_alloc_lock);
+  g_alloc_context = (nullptr != malloc_fn.function ? context : nullptr);
+  g_alloc_malloc = malloc_fn; g_alloc_free = free_fn;
+  return EXIT_SUCCESS;
+}
+
+LIBXSMM_API int libxsmm_get_default_allocator(void** context, libxsmm_malloc_function* malloc_fn, libxsmm_free_function* free_fn)
+{
+  if (nullptr == context || nullptr == malloc_fn || nullptr == free_fn) return EXIT_FAILURE;
+  std::lock_guard<std::mutex> guard(g_alloc_lock);
+  *context = g_alloc_context; *malloc_fn = g_alloc_malloc; *free_fn = g_alloc_free;
+  return EXIT_SUCCESS;
 }
 
 LIBXSMM_API void* libxsmm_aligned_malloc(size_t size, size_t alignment)
 {
   if (0 == size) return nullptr;
-  void* p = nullptr; int kind = 0;
-  if (device_ready() && hipSuccess == hipHostMalloc(&p, size, hipHostMallocDefault)) kind = 1;
+  size_t al = (0 == alignment ? (size_t)LIBXSMM_ALIGNMENT : alignment);
+  if (al < sizeof(void*)) al = sizeof(void*);
+  while (0 != (al & (al - 1))) al &= (al - 1); // round down to a power of two
+  void* p = nullptr; AllocInfo info = { 0, nullptr, nullptr, { nullptr } };
+  void* ctx; libxsmm_malloc_function mfn; libxsmm_free_function ffn;
+  { std::lock_guard<std::mutex> guard(g_alloc_lock); ctx = g_alloc_context; mfn = g_alloc_malloc; ffn = g_alloc_free; }
+  if (nullptr != mfn.function) { // the caller's allocator: over-allocate and align inside the block
+    void* const base = (nullptr != ctx ? mfn.ctx_form(ctx, size + al) : mfn.function(size + al));
+    if (nullptr == base) return nullptr;
+    p = reinterpret_cast<void*>((reinterpret_cast<uintptr_t>(base) + al - 1) & ~(uintptr_t)(al - 1));
+    info.kind = 2; info.base = base; info.context = ctx; info.free_fn = ffn;
+  }
+  else if (device_ready() && hipSuccess == hipHostMalloc(&p, size, hipHostMallocDefault)) info.kind = 1;
   else {
     (void)hipGetLastError();
-    size_t al = (0 == alignment ? (size_t)LIBXSMM_ALIGNMENT : alignment);
-    if (al < sizeof(void*)) al = sizeof(void*);
-    while (0 != (al & (al - 1))) al &= (al - 1); // round down to a power of two
     if (0 != posix_memalign(&p, al, size)) p = nullptr;
   }
-  if (nullptr != p) { std::lock_guard<std::mutex> guard(g_alloc_lock); g_allocs[p] = kind; }
+  if (nullptr != p) { std::lock_guard<std::mutex> guard(g_alloc_lock); g_allocs[p] = info; }
   return p;
 }
 
@@ -44,16 +79,69 @@ LIBXSMM_API void* libxsmm_malloc(size_t size) { return libxsmm_aligned_malloc(si
 LIBXSMM_API void libxsmm_free(const void* memory)
 {
   if (nullptr == memory) return;
-  int kind = -1;
+  int kind = -1; AllocInfo info = { -1, nullptr, nullptr, { nullptr } };
   {
     std::lock_guard<std::mutex> guard(g_alloc_lock);
     auto it = g_allocs.find(memory);
-    if (it != g_allocs.end()) { kind = it->second; g_allocs.erase(it); }
+    if (it != g_allocs.end()) { info = it->second; kind = info.kind; g_allocs.erase(it); }
   }
   if (1 == kind) (void)hipHostFree(const_cast<void*>(memory));
   else if (0 == kind) free(const_cast<void*>(memory));
+  else if (2 == kind) { // released by the allocator that was active when the buffer was made ("pending buffers")
+    if (nullptr != info.context) info.free_fn.ctx_form(info.context, info.base); else info.free_fn.function(info.base);
+  }
   else if (nullptr != kernel_from_pointer(memory)) libxsmm_release_kernel(memory); // reference frees csr_reg kernels this way (src/libxsmm_fsspmdm.c:301-306)
   else if (0 != libxsmm_verbosity) fprintf(stderr, "LIBXSMM ERROR: libxsmm_free of unknown memory!\n");
+}
+
+// Prints a GEMM call's arguments (reference src/libxsmm_gemm.c:557-650). The reference dumps the operands into MHD image
+// files when ostream == NULL; that debugging aid is not part of this engine: the call is then a no-op.
+LIBXSMM_API void libxsmm_gemm_print2(void* ostream, libxsmm_gemm_precision iprec, libxsmm_gemm_precision oprec,
+  const char* transa, const char* transb, const libxsmm_blasint* m, const libxsmm_blasint* n, const libxsmm_blasint* k,
+  const void* alpha, const void* a, const libxsmm_blasint* lda, const void* b, const libxsmm_blasint* ldb,
+  const void* beta, void* c, const libxsmm_blasint* ldc)
+{
+  if (nullptr == m) return;
+  const libxsmm_blasint nn = *(nullptr != n ? n : m), kk = *(nullptr != k ? k : m);
+  const char ta = (nullptr != transa ? *transa : 'n'), tb = (nullptr != transb ? *transb : 'n');
+  const libxsmm_blasint ilda = (nullptr != lda ? *lda : (('n' == ta || 'N' == ta) ? *m : kk));
+  const libxsmm_blasint ildb = (nullptr != ldb ? *ldb : (('n' == tb || 'N' == tb) ? kk : nn));
+  const libxsmm_blasint ildc = *(nullptr != ldc ? ldc : m);
+  char sa[64], sb[64], prefix = 0;
+  if (LIBXSMM_GEMM_PRECISION_F64 == iprec && iprec == oprec) {
+    snprintf(sa, sizeof(sa), "%g", nullptr != alpha ? *static_cast<const double*>(alpha) : 1.0);
+    snprintf(sb, sizeof(sb), "%g", nullptr != beta ? *static_cast<const double*>(beta) : 1.0);
+    prefix = 'd';
+  }
+  else if (LIBXSMM_GEMM_PRECISION_F32 == iprec && iprec == oprec) {
+    snprintf(sa, sizeof(sa), "%g", nullptr != alpha ? (double)*static_cast<const float*>(alpha) : 1.0);
+    snprintf(sb, sizeof(sb), "%g", nullptr != beta ? (double)*static_cast<const float*>(beta) : 1.0);
+    prefix = 's';
+  }
+  else {
+    static int error_once = 0;
+    if (0 != libxsmm_verbosity && once(&error_once)) fprintf(stderr, "LIBXSMM ERROR: unsupported data-type requested!\n");
+    return;
+  }
+  if (nullptr == ostream) return;
+  FILE* const out = static_cast<FILE*>(ostream);
+  if (nullptr != a && nullptr != b && nullptr != c) {
+    fprintf(out, "%cgemm('%c', '%c', %llu/*m*/, %llu/*n*/, %llu/*k*/,\n  %s/*alpha*/, %p/*a*/, %llu/*lda*/,\n              %p/*b*/, %llu/*ldb*/,\n   %s/*beta*/, %p/*c*/, %llu/*ldc*/)",
+      prefix, ta, tb, (unsigned long long)*m, (unsigned long long)nn, (unsigned long long)kk, sa, a, (unsigned long long)ilda,
+      b, (unsigned long long)ildb, sb, c, (unsigned long long)ildc);
+  }
+  else {
+    fprintf(out, "%cgemm(trans=%c%c mnk=%llu,%llu,%llu ldx=%llu,%llu,%llu a,b=%s,%s)", prefix, ta, tb,
+      (unsigned long long)*m, (unsigned long long)nn, (unsigned long long)kk,
+      (unsigned long long)ilda, (unsigned long long)ildb, (unsigned long long)ildc, sa, sb);
+  }
+}
+
+LIBXSMM_API void libxsmm_gemm_print(void* ostream, libxsmm_gemm_precision precision, const char* transa, const char* transb,
+  const libxsmm_blasint* m, const libxsmm_blasint* n, const libxsmm_blasint* k, const void* alpha, const void* a, const libxsmm_blasint* lda,
+  const void* b, const libxsmm_blasint* ldb, const void* beta, void* c, const libxsmm_blasint* ldc)
+{
+  libxsmm_gemm_print2(ostream, precision, precision, transa, transb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc);
 }
 
 LIBXSMM_API unsigned char libxsmm_typesize(libxsmm_datatype datatype) { return (unsigned char)LIBXSMM_TYPESIZE(datatype); }
@@ -116,19 +204,6 @@ LIBXSMM_API size_t libxsmm_shuffle(unsigned int n)
     if (hi < n && 1 == gcd(hi, n)) return hi;
   }
   return 1;
-}
-
-LIBXSMM_API const char* libxsmm_strerror(unsigned int i_error_code)
-{ // error codes of the reference's generators (src/generator_common.h:267-320) that this back end can raise
-  switch (i_error_code) {
-    case 90002: return "LIBXSMM ERROR: lda needs to be greater than or equal to m";
-    case 90003: return "LIBXSMM ERROR: ldb needs to be greater than or equal to k";
-    case 90004: return "LIBXSMM ERROR: ldc needs to be greater than or equal to m";
-    case 90005: return "LIBXSMM ERROR: could not determine which matrix is sparse";
-    case 90020: return "LIBXSMM ERROR: unsupported architecture/precision combination";
-    case 90036: return "LIBXSMM ERROR: number of unique values exceeds the register kernel's limit";
-    default: return "LIBXSMM ERROR: unknown error code";
-  }
 }
 
 // ---- matdiff (include/libxsmm_math.h:40-71; src/template/libxsmm_matdiff.tpl.c) -----------------------------------------------

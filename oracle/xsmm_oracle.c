@@ -626,6 +626,34 @@ void xo_bgemm_copyout_c(const xo_bgemm* h, const void* src, int ld, void* dst)
   }
 }
 
+void xo_bgemm_convert_b_to_a(const xo_bgemm* h, const void* src, void* dst)
+{ /* template/libxsmm_blocked_gemm_convert_b_to_a.tpl.c:32-46: the two outer block indexes trade places */
+  int mb, nb, bn, bm; const int ts = h->typesize;
+  for (mb = 0; mb < h->mb; ++mb) for (nb = 0; nb < h->nb; ++nb) for (bn = 0; bn < h->bn; ++bn) for (bm = 0; bm < h->bm; ++bm) {
+    const size_t d = (((size_t)mb * h->nb + nb) * h->bn + bn) * h->bm + bm;
+    const size_t s = (((size_t)nb * h->mb + mb) * h->bn + bn) * h->bm + bm;
+    xo_copy_elem(ts, (char*)dst + d * ts, (const char*)src + s * ts);
+  }
+}
+
+void xo_bgemm_transpose_b(const xo_bgemm* h, const void* src, void* dst)
+{ /* template/libxsmm_blocked_gemm_transpose_b.tpl.c:32-65: src is [kb][nb][bk][bn], dst is [.][kb][bn][bk] */
+  int kb, nb, bk, bn; const int ts = h->typesize;
+  const int square = (h->n == h->k && h->bn == h->bk);
+  for (kb = 0; kb < h->kb; ++kb) for (nb = 0; nb < h->nb; ++nb) for (bk = 0; bk < h->bk; ++bk) for (bn = 0; bn < h->bn; ++bn) {
+    const size_t s = (((size_t)kb * h->nb + nb) * h->bk + bk) * h->bn + bn;
+    size_t d;
+    if (square) d = (((size_t)nb * h->kb + kb) * h->bn + bn) * h->bk + bk;
+    else { /* :51-62 */
+      const long long job = ((long long)kb * h->bk + bk) * h->n + ((long long)nb * h->bn + bn);
+      const long long ii = job / h->k, jj = job % h->k, jobt = jj * h->n + ii;
+      const long long q = jobt / h->k, r = jobt % h->k;
+      d = (((size_t)(q / h->bn) * h->kb + (size_t)(r / h->bk)) * h->bn + (size_t)(q % h->bn)) * h->bk + (size_t)(r % h->bk);
+    }
+    xo_copy_elem(ts, (char*)dst + d * ts, (const char*)src + s * ts);
+  }
+}
+
 void xo_bgemm_order(int order, int w_i, int nw_i, int nw_j, int nw_k, int* i2, int* j2, int* k2)
 { /* internal_bgemm_order, libxsmm_blocked_gemm.c:469-506 */
   switch (order) {

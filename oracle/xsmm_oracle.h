@@ -136,6 +136,8 @@ void xo_bgemm_copyin_a(const xo_bgemm* h, const void* src, int ld, void* dst);
 void xo_bgemm_copyin_b(const xo_bgemm* h, const void* src, int ld, void* dst);
 void xo_bgemm_copyin_c(const xo_bgemm* h, const void* src, int ld, void* dst);
 void xo_bgemm_copyout_c(const xo_bgemm* h, const void* src, int ld, void* dst);
+void xo_bgemm_convert_b_to_a(const xo_bgemm* h, const void* src, void* dst);
+void xo_bgemm_transpose_b(const xo_bgemm* h, const void* src, void* dst);
 void xo_bgemm_order(int order, int w_i, int nw_i, int nw_j, int nw_k, int* i2, int* j2, int* k2);
 void xo_bgemm_st(int arith, const xo_bgemm* h, const void* a, const void* b, void* c); /* nthreads = 1 */
 

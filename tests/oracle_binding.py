@@ -215,6 +215,11 @@ def bgemm_copy(h, which, src, ld, dst):
     f(C.byref(h), p(src), ld, p(dst))
 
 
+def bgemm_permute(h, which, src, dst):
+    f = {"convert_b_to_a": lib().xo_bgemm_convert_b_to_a, "transpose_b": lib().xo_bgemm_transpose_b}[which]
+    f(C.byref(h), p(src), p(dst))
+
+
 def bgemm_st(arith, h, a, b, c):
     lib().xo_bgemm_st(arith, C.byref(h), p(a), p(b), p(c))
 

@@ -85,6 +85,59 @@ int main(void) {
     assert subprocess.run([str(exe)]).returncode == 0
 
 
+def test_custom_allocator_and_gemm_print(xs, tmp_path):
+    """libxsmm_set_default_allocator (include/libxsmm_malloc.h:53-64): plain and context forms, buffers released by the
+    allocator that made them; libxsmm_gemm_print's two text forms (src/libxsmm_gemm.c:608-622)."""
+    src = tmp_path / "alloc.c"
+    src.write_text(r'''
+#include <libxsmm.h>
+#include <stdio.h>
+#include <string.h>
+#include <stdint.h>
+static int n_malloc = 0, n_free = 0, n_ctx = 0;
+static void* my_malloc(size_t size) { ++n_malloc; return malloc(size); }
+static void my_free(void* p) { ++n_free; free(p); }
+static void* ctx_malloc(void* ctx, size_t size) { ++*(int*)ctx; return malloc(size); }
+static void ctx_free(void* ctx, void* p) { --*(int*)ctx; free(p); }
+int main(int argc, char* argv[]) {
+  libxsmm_malloc_function mf; libxsmm_free_function ff; void* ctx = NULL; void *p, *q;
+  const libxsmm_blasint m = 23, n = 24, k = 25; const double alpha = 1, beta = 0; double a[1], b[1], c[1];
+  FILE* out;
+  mf.function = my_malloc; ff.function = my_free;
+  if (EXIT_SUCCESS != libxsmm_set_default_allocator(NULL, mf, ff)) return 1;
+  p = libxsmm_aligned_malloc(1000, 256);
+  if (NULL == p || 0 != ((uintptr_t)p % 256) || 1 != n_malloc) return 2;
+  memset(p, 7, 1000);
+  mf.ctx_form = ctx_malloc; ff.ctx_form = ctx_free;
+  if (EXIT_SUCCESS != libxsmm_set_default_allocator(&n_ctx, mf, ff)) return 3; /* switch while p is pending */
+  q = libxsmm_malloc(64);
+  if (NULL == q || 1 != n_ctx) return 4;
+  libxsmm_free(p); if (1 != n_free) return 5;   /* p goes back through my_free */
+  libxsmm_free(q); if (0 != n_ctx) return 6;
+  if (EXIT_SUCCESS != libxsmm_get_default_allocator(&ctx, &mf, &ff) || ctx != &n_ctx || mf.ctx_form != ctx_malloc) return 7;
+  mf.function = my_malloc; ff.function = NULL;
+  if (EXIT_SUCCESS == libxsmm_set_default_allocator(NULL, mf, ff)) return 8; /* not a pair */
+  mf.function = NULL;
+  if (EXIT_SUCCESS != libxsmm_set_default_allocator(NULL, mf, ff)) return 9; /* back to the built-in allocator */
+  p = libxsmm_malloc(128); if (NULL == p || 1 != n_malloc) return 10; libxsmm_free(p);
+  out = fopen(argv[1], "w"); if (NULL == out || argc < 2) return 11;
+  libxsmm_gemm_print(out, LIBXSMM_GEMM_PRECISION_F64, "N", "T", &m, &n, &k, &alpha, NULL, NULL, NULL, NULL, &beta, NULL, NULL);
+  fprintf(out, "\n");
+  libxsmm_gemm_print(out, LIBXSMM_GEMM_PRECISION_F64, "N", "N", &m, &n, &k, &alpha, a, NULL, b, NULL, &beta, c, NULL);
+  fclose(out);
+  return 0;
+}''')
+    exe = tmp_path / "alloc"
+    libdir = os.path.dirname(xs.LIB_PATH)
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe), "-L", libdir, "-lxsmm",
+                    "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    txt = tmp_path / "print.txt"
+    assert subprocess.run([str(exe), str(txt)]).returncode == 0
+    lines = txt.read_text().splitlines()
+    assert lines[0] == "dgemm(trans=NT mnk=23,24,25 ldx=23,24,23 a,b=1,0)"
+    assert lines[1].startswith("dgemm('N', 'N', 23/*m*/, 24/*n*/, 25/*k*/,") and "/*ldb*/" in lines[3] and lines[4].endswith("23/*ldc*/)")
+
+
 def test_descriptor_rules(xs):
     """include/libxsmm_generator.h:36-39: NULL unless alpha == 1, beta in {0,1}, no TRANS_A; beta == 0 sets FLAG_BETA_0."""
     L = xs.lib()

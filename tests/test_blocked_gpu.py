@@ -82,3 +82,41 @@ def test_blocked_gemm_host_operands_and_invalid_blocks(xs, torch_gpu):
     L.libxsmm_blocked_gemm_handle_destroy(h)
     expect = a.reshape(k, m).T @ b.reshape(n, k).T
     assert np.max(np.abs(out.reshape(n, m).T - expect)) <= 1e-12 * np.max(np.abs(expect)) * 4
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("geom", [(128, 96, 160, 32, 32, 32), (96, 96, 96, 32, 32, 32), (64, 96, 48, 16, 32, 24)])
+def test_blocked_permutations(xs, orc, torch_gpu, dtype, geom):
+    """libxsmm_blocked_gemm_convert_b_to_a / _transpose_b (src/libxsmm_blocked_gemm.c:369-466): pure index work on
+    block-major arrays => bit-exact; the second geometry takes transpose_b's square shortcut, the others its generic
+    branch. Device and host operands."""
+    torch = torch_gpu
+    m, n, k, bm, bn, bk = geom
+    ts = 8 if dtype == np.float64 else 4
+    prec = xs.F64 if dtype == np.float64 else xs.F32
+    rng = np.random.default_rng(m + n + k)
+    oh = orc.bgemm_init(ts, m, n, k, bm, bn, bk)
+    assert oh is not None
+    L = xs.lib()
+    ibm, ibn, ibk, one, iorder = (C.c_int(v) for v in (bm, bn, bk, 1, 0))
+    al = (C.c_double if ts == 8 else C.c_float)(1.0); be = (C.c_double if ts == 8 else C.c_float)(1.0)
+    h = L.libxsmm_blocked_gemm_handle_create(1, prec, prec, m, n, k, C.byref(ibm), C.byref(ibn), C.byref(ibk),
+                                             C.byref(one), C.byref(one), C.byref(one), C.byref(one),
+                                             C.byref(al), C.byref(be), None, None, C.byref(iorder))
+    assert h
+    try:
+        for which, count in (("convert_b_to_a", m * n), ("transpose_b", k * n)):
+            src = rng.uniform(-1, 1, count).astype(dtype)
+            ref = np.full_like(src, np.nan); orc.bgemm_permute(oh, which, src, ref)
+            assert not np.isnan(ref).any() and np.array_equal(np.sort(ref), np.sort(src))  # a permutation
+            f = getattr(L, "libxsmm_blocked_gemm_" + which)
+            dsrc = torch.from_numpy(src).cuda(); ddst = torch.empty_like(dsrc)
+            assert 0 == f(h, xs.dptr(dsrc), None, xs.dptr(ddst))
+            torch.cuda.synchronize()
+            assert np.array_equal(ddst.cpu().numpy(), ref), which
+            hdst = np.empty_like(src)
+            assert 0 == f(h, xs.dptr(src), None, xs.dptr(hdst))
+            assert np.array_equal(hdst, ref), which
+        assert 0 != L.libxsmm_blocked_gemm_transpose_b(None, xs.dptr(src), None, xs.dptr(hdst))
+    finally:
+        L.libxsmm_blocked_gemm_handle_destroy(h)

@@ -341,3 +341,36 @@ def test_blocked_gemm_oracle(orc):
         orc.bgemm_copy(h, "out", bc, m, out)
         assert np.max(np.abs(out.reshape(n, m).T - expect)) <= 1e-12
     assert orc.bgemm_init(8, 64, 64, 64, 24, 32, 32) is None  # 64 % 24 != 0 (libxsmm_blocked_gemm.c:65)
+
+
+def test_blocked_permutations_oracle(orc):
+    """convert_b_to_a / transpose_b restatements against their array-view meaning (reference templates
+    libxsmm_blocked_gemm_convert_b_to_a.tpl.c:32-46, libxsmm_blocked_gemm_transpose_b.tpl.c:32-65)."""
+    rng = np.random.default_rng(4)
+    m, n, k, bm, bn, bk = 64, 96, 96, 16, 32, 32
+    h = orc.bgemm_init(8, m, n, k, bm, bn, bk)
+    mb, nb, kb = m // bm, n // bn, k // bk
+    src = rng.uniform(-1, 1, m * n); dst = np.zeros_like(src)
+    orc.bgemm_permute(h, "convert_b_to_a", src, dst)
+    assert np.array_equal(dst.reshape(mb, nb, bn, bm), src.reshape(nb, mb, bn, bm).transpose(1, 0, 2, 3))
+    # n == k and bn == bk: block transpose plus transpose inside each block
+    src = rng.uniform(-1, 1, k * n); dst = np.zeros_like(src)
+    orc.bgemm_permute(h, "transpose_b", src, dst)
+    assert np.array_equal(dst.reshape(nb, kb, bn, bk), src.reshape(kb, nb, bk, bn).transpose(1, 0, 3, 2))
+    # generic branch, small enough for a Python walk of the reference's index arithmetic
+    m, n, k, bm, bn, bk = 8, 12, 6, 4, 4, 3
+    h = orc.bgemm_init(8, m, n, k, bm, bn, bk)
+    nb, kb = n // bn, k // bk
+    src = rng.uniform(-1, 1, k * n); dst = np.full_like(src, np.nan)
+    orc.bgemm_permute(h, "transpose_b", src, dst)
+    expect = np.full_like(src, np.nan)
+    s4 = src.reshape(kb, nb, bk, bn)
+    for ikb in range(kb):
+        for inb in range(nb):
+            for ik in range(bk):
+                for jn in range(bn):
+                    job = (ikb * bk + ik) * n + (inb * bn + jn)
+                    ii, jj = divmod(job, k)
+                    q, r = divmod(jj * n + ii, k)
+                    expect[(((q // bn) * kb + r // bk) * bn + q % bn) * bk + r % bk] = s4[ikb, inb, ik, jn]
+    assert np.array_equal(dst, expect) and sorted(dst) == sorted(src)

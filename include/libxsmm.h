@@ -463,6 +463,14 @@ LIBXSMM_API void libxsmm_spmdm_createSparseSlice_fp32_thread(const libxsmm_spmdm
 LIBXSMM_API void libxsmm_spmdm_compute_fp32_thread(const libxsmm_spmdm_handle* handle, char transa, char transb,
   const float* alpha, libxsmm_CSR_sparseslice* a_sparse, const float* b, char transc, const float* beta, float* c,
   int block_id, int tid, int nthreads);
+/* bfloat16 twins (include/libxsmm_spmdm.h:98-133): A resp. B hold the upper halves of IEEE floats; slices, sums and C
+ * are float. As in the reference template, `*beta` is used as a number without widening it: the 16-bit pattern is the
+ * factor (pattern 0: beta = 0, pattern 1: beta = 1; the bf16 encoding of 1.0, 0x3F80, scales C by 16256). */
+LIBXSMM_API void libxsmm_spmdm_createSparseSlice_bfloat16_thread(const libxsmm_spmdm_handle* handle, char transa,
+  const libxsmm_bfloat16* a, libxsmm_CSR_sparseslice* libxsmm_output_csr_a, int block_id, int tid, int nthreads);
+LIBXSMM_API void libxsmm_spmdm_compute_bfloat16_thread(const libxsmm_spmdm_handle* handle, char transa, char transb,
+  const libxsmm_bfloat16* alpha, libxsmm_CSR_sparseslice* a_sparse, const libxsmm_bfloat16* b, char transc,
+  const libxsmm_bfloat16* beta, float* c, int block_id, int tid, int nthreads);
 
 /* ---------------------------------------------------------------------------------------------
  * blocked_gemm (include/libxsmm_blocked_gemm.h:37-97)

@@ -154,6 +154,14 @@ void spmdm_compute_kernel(long long batch, int M, int N, int K, int bm, int bk, 
   }
 }
 
+// ---- bfloat16 -> float (the reference's EXPAND_BFLOAT16, src/libxsmm_spmdm_begin.h:69-75): bits << 16 ----------------------
+__global__ __launch_bounds__(256) void bf16_widen_kernel(const unsigned short* __restrict__ src, float* __restrict__ dst, long long count)
+{
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long long)gridDim.x * blockDim.x) {
+    dst[i] = __uint_as_float((unsigned)src[i] << 16);
+  }
+}
+
 // ---- blocked_gemm layout conversions (reference template/libxsmm_blocked_gemm_copy*.tpl.c) -----------------------------
 template<typename T>
 __global__ __launch_bounds__(256)
@@ -508,6 +516,13 @@ int launch_spmdm_compute(const SpmdmGeom& g, int transb, int transc, float beta,
   }
   return launch_spmdm_compute_generic(g.batch, g.m, g.n, g.k, g.m, g.k, 1, 1, transb, transc, beta, rowidx, colidx, values,
     (long long)g.rstride, (long long)g.cap, b, c, (long long)g.k * g.n, (long long)g.m * g.n, 0, g.m, 0, g.n, stream, name);
+}
+
+int launch_bf16_widen(const unsigned short* src, float* dst, long long count, void* stream)
+{
+  if (count <= 0) return 0;
+  hipLaunchKernelGGL(bf16_widen_kernel, dim3(grid_for(count, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, count);
+  return (int)hipGetLastError();
 }
 
 int launch_bgemm_copy(const BgemmGeom& g, int which, const void* src, int ld, void* dst, void* stream)

@@ -108,6 +108,7 @@ int launch_spmdm_compute(const SpmdmGeom& g, int transb, int transc, float beta,
                          const float* values, const float* b, float* c, void* stream, const char** name);
 
 // blocked_gemm helpers (layouts of template/libxsmm_blocked_gemm_copy*.tpl.c)
+int launch_bf16_widen(const unsigned short* src, float* dst, long long count, void* stream); // dst[i] = float(bits(src[i]) << 16)
 struct BgemmGeom { int typesize, m, n, k, bm, bn, bk, mb, nb, kb; };
 int launch_bgemm_copy(const BgemmGeom& g, int which /*0:A 1:B 2:C-in 3:C-out 4:convert_b_to_a 5:transpose_b (blocked -> blocked)*/, const void* src, int ld, void* dst, void* stream);
 int launch_bgemm_compute(const BgemmGeom& g, int beta0, const void* a, const void* b, void* c, void* stream, const char** name);

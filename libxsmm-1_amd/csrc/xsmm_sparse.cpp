@@ -246,16 +246,26 @@ const float* mirror_in(const float* p, size_t elems, int slot, bool* ok)
 }
 }
 
-LIBXSMM_API void libxsmm_spmdm_createSparseSlice_fp32_thread(const libxsmm_spmdm_handle* handle, char transa,
-  const float* a, libxsmm_CSR_sparseslice* libxsmm_output_csr_a, int block_id, int tid, int nthreads)
+namespace {
+// bfloat16 operands (reference: libxsmm_bfloat16 = the upper half of an IEEE float, src/libxsmm_spmdm_begin.h:69-75) are
+// widened to float in a device scratch buffer; from there on the fp32 kernels run unchanged -- exactly what the reference
+// templates do element by element (EXPAND_BFLOAT16 before the compare / the copy into scratch_B).
+const float* widen_bf16(const libxsmm_bfloat16* p, size_t elems, int slot_raw, int slot_wide, bool* ok)
 {
-  (void)tid; (void)nthreads;
-  if (nullptr == handle || nullptr == a || nullptr == libxsmm_output_csr_a || nullptr == handle->base_ptr_scratch_A) return;
-  if (!device_ready()) { fail_no_device("libxsmm_spmdm_createSparseSlice_fp32_thread"); return; }
-  const int ta = ('T' == transa || 't' == transa);
-  bool ok = true;
-  const float* const da = mirror_in(a, (size_t)handle->m * handle->k, 3, &ok);
-  if (!ok) return;
+  const libxsmm_bfloat16* src = p;
+  if (!is_device_ptr(p)) {
+    void* d = scratch(slot_raw, elems * sizeof(libxsmm_bfloat16));
+    if (nullptr == d || 0 != h2d(d, p, elems * sizeof(libxsmm_bfloat16))) { *ok = false; return nullptr; }
+    src = static_cast<const libxsmm_bfloat16*>(d);
+  }
+  float* const wide = static_cast<float*>(scratch(slot_wide, elems * sizeof(float)));
+  if (nullptr == wide || 0 != launch_bf16_widen(src, wide, (long long)elems, device().stream)) { *ok = false; return nullptr; }
+  note_launch("bf16_widen");
+  return wide;
+}
+
+void spmdm_create_block(const libxsmm_spmdm_handle* handle, int ta, const float* da, int block_id)
+{ // da: device-resident M x K (or K x M) fp32 matrix
   const size_t nslices = (size_t)handle->mb * handle->kb, cap = (size_t)handle->bm * handle->bk;
   float* const values = reinterpret_cast<float*>(handle->base_ptr_scratch_A);
   uint16_t* const colidx = reinterpret_cast<uint16_t*>(handle->base_ptr_scratch_A + nslices * cap * sizeof(float));
@@ -265,23 +275,14 @@ LIBXSMM_API void libxsmm_spmdm_createSparseSlice_fp32_thread(const libxsmm_spmdm
     rowidx, colidx, values, device().stream, &name);
   note_launch(name);
   if (0 != e) fprintf(stderr, "LIBXSMM-AMD ERROR: kernel launch failed (%s, hip error %d)\n", name, e);
-  if (da != a) (void)stream_sync(); // the staging buffer is reused by the next call
 }
 
-LIBXSMM_API void libxsmm_spmdm_compute_fp32_thread(const libxsmm_spmdm_handle* handle, char transa, char transb,
-  const float* alpha, libxsmm_CSR_sparseslice* a_sparse, const float* b, char transc, const float* beta, float* c,
-  int block_id, int tid, int nthreads)
-{
-  (void)transa; (void)alpha; (void)tid; (void)nthreads; // alpha is ignored by the reference (include/libxsmm_spmdm.h:104)
-  if (nullptr == handle || nullptr == a_sparse || nullptr == b || nullptr == c || nullptr == beta) return;
-  if (!device_ready()) { fail_no_device("libxsmm_spmdm_compute_fp32_thread"); return; }
-  const int tb = ('T' == transb || 't' == transb), tc = ('T' == transc || 't' == transc);
+void spmdm_compute_block(const libxsmm_spmdm_handle* handle, int tb, int tc, float beta, libxsmm_CSR_sparseslice* a_sparse,
+                         const float* db, float* c, int block_id, bool sync_inputs)
+{ // db: device-resident fp32 B; c: device or host
   const int mb = block_id / handle->nb, nb = block_id % handle->nb; // compute tpl :38-39
   const int m0 = mb * handle->bm, n0 = nb * handle->bn;
   const int m1 = LIBXSMM_MIN(m0 + handle->bm, handle->m), n1 = LIBXSMM_MIN(n0 + handle->bn, handle->n);
-  bool ok = true;
-  const float* const db = mirror_in(b, (size_t)handle->k * handle->n, 4, &ok);
-  if (!ok) return;
   float* dc = c; const bool c_host = !is_device_ptr(c);
   const size_t celems = (size_t)handle->m * handle->n;
   if (c_host) {
@@ -292,7 +293,7 @@ LIBXSMM_API void libxsmm_spmdm_compute_fp32_thread(const libxsmm_spmdm_handle* h
   const char* name = "";
   // the slice arrays are one block: slice 0's pointers are the bases
   const int e = launch_spmdm_compute_generic(1, handle->m, handle->n, handle->k, handle->bm, handle->bk, handle->mb, handle->kb,
-    tb, tc, *beta, a_sparse[0].rowidx, a_sparse[0].colidx, a_sparse[0].values, (long long)handle->bm + 1, (long long)cap,
+    tb, tc, beta, a_sparse[0].rowidx, a_sparse[0].colidx, a_sparse[0].values, (long long)handle->bm + 1, (long long)cap,
     db, dc, 0, 0, m0, m1, n0, n1, device().stream, &name);
   note_launch(name);
   if (0 != e) { fprintf(stderr, "LIBXSMM-AMD ERROR: kernel launch failed (%s, hip error %d)\n", name, e); return; }
@@ -304,7 +305,62 @@ LIBXSMM_API void libxsmm_spmdm_compute_fp32_thread(const libxsmm_spmdm_handle* h
       c[idx] = tmp[idx];
     }
   }
-  else if (db != b) (void)stream_sync();
+  else if (sync_inputs) (void)stream_sync(); // staged inputs are reused by the next call
+}
+}
+
+LIBXSMM_API void libxsmm_spmdm_createSparseSlice_fp32_thread(const libxsmm_spmdm_handle* handle, char transa,
+  const float* a, libxsmm_CSR_sparseslice* libxsmm_output_csr_a, int block_id, int tid, int nthreads)
+{
+  (void)tid; (void)nthreads;
+  if (nullptr == handle || nullptr == a || nullptr == libxsmm_output_csr_a || nullptr == handle->base_ptr_scratch_A) return;
+  if (!device_ready()) { fail_no_device("libxsmm_spmdm_createSparseSlice_fp32_thread"); return; }
+  bool ok = true;
+  const float* const da = mirror_in(a, (size_t)handle->m * handle->k, 3, &ok);
+  if (!ok) return;
+  spmdm_create_block(handle, ('T' == transa || 't' == transa), da, block_id);
+  if (da != a) (void)stream_sync(); // the staging buffer is reused by the next call
+}
+
+LIBXSMM_API void libxsmm_spmdm_createSparseSlice_bfloat16_thread(const libxsmm_spmdm_handle* handle, char transa,
+  const libxsmm_bfloat16* a, libxsmm_CSR_sparseslice* libxsmm_output_csr_a, int block_id, int tid, int nthreads)
+{ // src/template/libxsmm_spmdm_createSparseSlice_bfloat16_thread.tpl.c:47-144: widen, keep v != 0, store as float
+  (void)tid; (void)nthreads;
+  if (nullptr == handle || nullptr == a || nullptr == libxsmm_output_csr_a || nullptr == handle->base_ptr_scratch_A) return;
+  if (!device_ready()) { fail_no_device("libxsmm_spmdm_createSparseSlice_bfloat16_thread"); return; }
+  bool ok = true;
+  const float* const da = widen_bf16(a, (size_t)handle->m * handle->k, 6, 3, &ok);
+  if (!ok) return;
+  spmdm_create_block(handle, ('T' == transa || 't' == transa), da, block_id);
+  (void)stream_sync(); // the widened copy lives in a reused scratch buffer
+}
+
+LIBXSMM_API void libxsmm_spmdm_compute_fp32_thread(const libxsmm_spmdm_handle* handle, char transa, char transb,
+  const float* alpha, libxsmm_CSR_sparseslice* a_sparse, const float* b, char transc, const float* beta, float* c,
+  int block_id, int tid, int nthreads)
+{
+  (void)transa; (void)alpha; (void)tid; (void)nthreads; // alpha is ignored by the reference (include/libxsmm_spmdm.h:104)
+  if (nullptr == handle || nullptr == a_sparse || nullptr == b || nullptr == c || nullptr == beta) return;
+  if (!device_ready()) { fail_no_device("libxsmm_spmdm_compute_fp32_thread"); return; }
+  bool ok = true;
+  const float* const db = mirror_in(b, (size_t)handle->k * handle->n, 4, &ok);
+  if (!ok) return;
+  spmdm_compute_block(handle, ('T' == transb || 't' == transb), ('T' == transc || 't' == transc), *beta, a_sparse, db, c, block_id, db != b);
+}
+
+LIBXSMM_API void libxsmm_spmdm_compute_bfloat16_thread(const libxsmm_spmdm_handle* handle, char transa, char transb,
+  const libxsmm_bfloat16* alpha, libxsmm_CSR_sparseslice* a_sparse, const libxsmm_bfloat16* b, char transc,
+  const libxsmm_bfloat16* beta, float* c, int block_id, int tid, int nthreads)
+{ // src/template/libxsmm_spmdm_compute_bfloat16_thread.tpl.c: B is widened while it is copied, C and the sums are float.
+  // NOTE the reference reads `*beta` as a number without widening it (:91,113,164): the 16-bit pattern itself is the
+  // factor (pattern 0 -> beta 0, pattern 1 -> beta 1, bf16(1.0) = 0x3F80 -> 16256). Reproduced as is.
+  (void)transa; (void)alpha; (void)tid; (void)nthreads;
+  if (nullptr == handle || nullptr == a_sparse || nullptr == b || nullptr == c || nullptr == beta) return;
+  if (!device_ready()) { fail_no_device("libxsmm_spmdm_compute_bfloat16_thread"); return; }
+  bool ok = true;
+  const float* const db = widen_bf16(b, (size_t)handle->k * handle->n, 6, 4, &ok);
+  if (!ok) return;
+  spmdm_compute_block(handle, ('T' == transb || 't' == transb), ('T' == transc || 't' == transc), (float)(*beta), a_sparse, db, c, block_id, true);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

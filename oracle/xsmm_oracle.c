@@ -550,6 +550,23 @@ void xo_spmdm_exec(int arith, int M, int N, int K, int bn_isa, char transa, char
   xo_spmdm_free_slices(&h, s);
 }
 
+void xo_spmdm_exec_bf16(int arith, int M, int N, int K, int bn_isa, char transa, char transb, char transc,
+                        unsigned short beta_bits, const unsigned short* a, const unsigned short* b, float* c)
+{ /* bfloat16 twins: template/libxsmm_spmdm_createSparseSlice_bfloat16_thread.tpl.c:47-144 and
+   * template/libxsmm_spmdm_compute_bfloat16_thread.tpl.c differ from the fp32 templates only in widening every input
+   * element (bits << 16, libxsmm_spmdm_begin.h:69-75) before the compare / the copy into scratch_B. The scalar `*beta`
+   * (a libxsmm_bfloat16*, i.e. unsigned short*) is used as a number as it stands (:91,113,164,187): no widening. */
+  const size_t na = (size_t)M * K, nb = (size_t)K * N; size_t i;
+  float* const wa = (float*)malloc(sizeof(float) * (na ? na : 1));
+  float* const wb = (float*)malloc(sizeof(float) * (nb ? nb : 1));
+  if (NULL != wa && NULL != wb) {
+    for (i = 0; i < na; ++i) { union { unsigned u; float f; } v; v.u = (unsigned)a[i] << 16; wa[i] = v.f; }
+    for (i = 0; i < nb; ++i) { union { unsigned u; float f; } v; v.u = (unsigned)b[i] << 16; wb[i] = v.f; }
+    xo_spmdm_exec(arith, M, N, K, bn_isa, transa, transb, transc, (float)beta_bits, wa, wb, c);
+  }
+  free(wa); free(wb);
+}
+
 void xo_spmdm_exec_batch(int arith, int M, int N, int K, int bn_isa, char transa, char transb, char transc,
                          float beta, const float* a, const float* b, float* c, long long batch, int nthreads)
 {

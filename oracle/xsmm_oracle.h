@@ -124,6 +124,9 @@ void xo_spmdm_compute(int arith, const xo_spmdm_handle* h, char transa, char tra
 /* whole-problem convenience: init geometry (1 thread, bn_isa), create all slices, compute all blocks */
 void xo_spmdm_exec(int arith, int M, int N, int K, int bn_isa, char transa, char transb, char transc,
                    float beta, const float* a, const float* b, float* c);
+/* bfloat16 inputs (upper halves of floats), float C; beta_bits is the raw 16-bit pattern the caller stores behind `beta` */
+void xo_spmdm_exec_bf16(int arith, int M, int N, int K, int bn_isa, char transa, char transb, char transc,
+                        unsigned short beta_bits, const unsigned short* a, const unsigned short* b, float* c);
 /* batch of independent problems laid out back-to-back (A: M*K, B: K*N, C: M*N per item) */
 void xo_spmdm_exec_batch(int arith, int M, int N, int K, int bn_isa, char transa, char transb, char transc,
                          float beta, const float* a, const float* b, float* c, long long batch, int nthreads);

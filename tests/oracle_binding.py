@@ -171,6 +171,11 @@ def spmdm_exec(arith, M, N, K, bn_isa, transa, transb, transc, beta, a, b, c):
                         C.c_float(beta), p(a), p(b), p(c))
 
 
+def spmdm_exec_bf16(arith, M, N, K, bn_isa, transa, transb, transc, beta_bits, a, b, c):
+    lib().xo_spmdm_exec_bf16(arith, M, N, K, bn_isa, C.c_char(transa.encode()), C.c_char(transb.encode()), C.c_char(transc.encode()),
+                             C.c_ushort(beta_bits), p(a), p(b), p(c))
+
+
 def spmdm_exec_batch(arith, M, N, K, bn_isa, transa, transb, transc, beta, a, b, c, batch, nthreads=1):
     lib().xo_spmdm_exec_batch(arith, M, N, K, bn_isa, C.c_char(transa.encode()), C.c_char(transb.encode()),
                               C.c_char(transc.encode()), C.c_float(beta), p(a), p(b), p(c), C.c_longlong(batch), nthreads)

@@ -199,6 +199,42 @@ def test_spmdm_reference_api(xs, orc, torch_gpu, variant, beta):
         assert np.max(np.abs(got - gold)) <= 1e-4
 
 
+@pytest.mark.parametrize("variant", [("N", "N", "N"), ("T", "T", "T")])
+@pytest.mark.parametrize("beta_bits", [0, 1, 0x3F80])
+def test_spmdm_bfloat16_twins(xs, orc, torch_gpu, variant, beta_bits):
+    """libxsmm_spmdm_createSparseSlice_bfloat16_thread / compute_bfloat16_thread (include/libxsmm_spmdm.h:98-133): inputs are
+    upper halves of floats, slices/sums/C are float. `*beta` is taken as the number its 16 bits spell (pattern 1 is
+    beta = 1; the bf16 encoding of 1.0 scales C by 16256) -- the reference template's behaviour, reproduced bit for bit.
+    Device and host operands."""
+    torch = torch_gpu
+    ta, tb, tc = variant
+    M, N, K = 150, 70, 200
+    a32, b32, c = spmdm_inputs(M, N, K, 0.7, 1, orc)
+    a = (a32.view(np.uint32) >> 16).astype(np.uint16); b = (b32.view(np.uint32) >> 16).astype(np.uint16)  # truncation keeps zeros zero
+    if beta_bits == 0:
+        c[:] = np.nan
+    ref = c.copy()
+    orc.spmdm_exec_bf16(orc.FMA, M, N, K, 48, ta, tb, tc, beta_bits, a, b, ref)
+    L = xs.lib()
+    for on_device in (True, False):
+        h = xs.SpmdmHandle(); slices = C.POINTER(xs.CSRSlice)()
+        L.libxsmm_spmdm_init(M, N, K, 1, C.byref(h), C.byref(slices))
+        if on_device:
+            xa, xb, xc = torch.from_numpy(a.view(np.int16)).cuda(), torch.from_numpy(b.view(np.int16)).cuda(), torch.from_numpy(c).cuda()
+        else:
+            xa, xb, xc = a, b, c.copy()
+        alpha, be = C.c_ushort(0x3F80), C.c_ushort(beta_bits)
+        for blk in range(L.libxsmm_spmdm_get_num_createSparseSlice_blocks(C.byref(h))):
+            L.libxsmm_spmdm_createSparseSlice_bfloat16_thread(C.byref(h), ta.encode(), xs.dptr(xa), slices, blk, 0, 1)
+        for blk in range(L.libxsmm_spmdm_get_num_compute_blocks(C.byref(h))):
+            L.libxsmm_spmdm_compute_bfloat16_thread(C.byref(h), ta.encode(), tb.encode(), C.byref(alpha), slices, xs.dptr(xb), tc.encode(),
+                                                    C.byref(be), xs.dptr(xc), blk, 0, 1)
+        torch.cuda.synchronize()
+        out = xc.cpu().numpy() if on_device else xc
+        L.libxsmm_spmdm_destroy(C.byref(h))
+        assert np.array_equal(out, ref), on_device
+
+
 @pytest.mark.parametrize("keep", [0.5, 0.85])
 @pytest.mark.parametrize("variant", [("N", "N", "N"), ("T", "N", "T"), ("N", "T", "N")])
 def test_spmdm_batch_config4(xs, orc, torch_gpu, keep, variant):

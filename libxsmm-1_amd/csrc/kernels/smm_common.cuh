@@ -14,6 +14,7 @@ struct DevAddr {
   const char* ia; const char* ib; const char* ic;
   long long sa, sb, sc;
   int index_base, index_stride, mode;
+  const int* flags; // SYNC_DEVICE*: {#equal neighbouring C, #out-of-order repeats of C} from c_order_kernel, else null
 };
 
 inline DevAddr make_addr(const SmmBatch& s)
@@ -23,6 +24,7 @@ inline DevAddr make_addr(const SmmBatch& s)
   d.ia = (const char*)s.ia; d.ib = (const char*)s.ib; d.ic = (const char*)s.ic;
   d.sa = s.sa; d.sb = s.sb; d.sc = s.sc;
   d.index_base = s.index_base; d.index_stride = s.index_stride; d.mode = s.mode;
+  d.flags = ((SYNC_DEVICE == s.sync || SYNC_DEVICE_FALLBACK == s.sync) ? s.devflags : nullptr);
   return d;
 }
 

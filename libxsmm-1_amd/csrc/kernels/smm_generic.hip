@@ -23,9 +23,17 @@ template<int G> __device__ __forceinline__ void unit_sync()
 // T: element type; TM,TN: register tile; TGM x TGN = G threads per problem; GENERAL: alpha/beta/TRANS_A form
 template<typename T, int TM, int TN, int TGM, int TGN, bool GENERAL>
 __global__ __launch_bounds__(256)
-void smm_generic_kernel(DevAddr ad, int M, int N, int K, int lda, int ldb, int ldc, int flags, int sync,
+void smm_generic_kernel(DevAddr ad, int M, int N, int K, int lda, int ldb, int ldc, int flags, int sync_arg,
                         long long batch, int KC, int kshift, T alpha, T beta)
 {
+  int sync = sync_arg;
+  if (SYNC_DEVICE == sync_arg) { // how C blocks repeat was established on the device (c_order_kernel, same stream)
+    sync = (0 != ad.flags[1]) ? SYNC_ATOMIC : ((0 != ad.flags[0]) ? SYNC_RUNS : SYNC_NONE);
+  }
+  else if (SYNC_DEVICE_FALLBACK == sync_arg) { // the run kernel in front of this launch took the batch unless C repeats out of order
+    if (0 == ad.flags[1]) return;
+    sync = SYNC_ATOMIC;
+  }
   constexpr int G = TGM * TGN;
   constexpr int PPB = 256 / G;
   constexpr int MP = TGM * TM;

@@ -82,6 +82,21 @@ void note_launch(const char* name)
   g_launches.fetch_add(1, std::memory_order_relaxed);
 }
 
+int* flag_slot()
+{ // ring of int[4] slots in device memory: one per batch call whose C ordering is inspected on the device; a slot is
+  // written (memset + check kernel) and read (compute kernels) by launches of one stream, in order
+  static int* ring = nullptr;
+  static std::once_flag once;
+  static std::atomic<unsigned> next{0};
+  constexpr unsigned SLOTS = 4096;
+  std::call_once(once, []() {
+    void* p = nullptr;
+    if (hipSuccess == hipMalloc(&p, SLOTS * 4 * sizeof(int))) ring = static_cast<int*>(p); else (void)hipGetLastError();
+  });
+  if (nullptr == ring) return nullptr;
+  return ring + 4 * (next.fetch_add(1, std::memory_order_relaxed) % SLOTS);
+}
+
 void* scratch(int slot, size_t bytes)
 {
   Scratch& s = tl_scratch[slot & 7];

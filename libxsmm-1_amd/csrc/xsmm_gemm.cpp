@@ -26,7 +26,14 @@ int run_smm(const SmmBatch& s)
   const char* name = "";
   int e = -1;
   if (0 == s.general) e = launch_smm_special(s, device().stream, &name);            // hand-tuned shapes
-  if (e < 0 && smm_jit_eligible(s)) e = launch_smm_jit(s, device().stream, &name);  // shape-specialised via hiprtc
+  if (e < 0 && smm_jit_eligible(s)) {                                               // shape-specialised via hiprtc
+    e = launch_smm_jit(s, device().stream, &name);
+    if (0 == e && SYNC_DEVICE == s.sync) { // the run kernel stands down if C blocks repeat out of order; then this one works
+      SmmBatch f = s; f.sync = SYNC_DEVICE_FALLBACK;
+      const char* fallback = "";
+      e = launch_smm_generic(f, device().stream, &fallback);
+    }
+  }
   if (e < 0) e = launch_smm_generic(s, device().stream, &name);                     // any descriptor
   note_launch(name);
   if (0 != e) fprintf(stderr, "LIBXSMM-AMD ERROR: kernel launch failed (%s, hip error %d)\n", name, e);
@@ -51,14 +58,13 @@ int choose_sync(SmmBatch& s, bool nosync)
   if (ADDR_STRIDED == s.mode) { s.sync = (0 == s.sc ? SYNC_RUNS : SYNC_NONE); return 0; }
   if (ADDR_INDEX == s.mode && nullptr == s.ic) { s.sync = SYNC_RUNS; return 0; }
   if (ADDR_POINTER == s.mode && 0 == s.sc) { s.sync = SYNC_RUNS; return 0; }
-  int* d_flags = static_cast<int*>(scratch(7, 2 * sizeof(int)));
+  // The verdict stays on the device: the check kernel leaves its counts in a flag slot and the compute kernels launched
+  // behind it on the same stream read them. No host round trip, the call returns while the GPU is still working.
+  int* const d_flags = flag_slot();
   if (nullptr == d_flags) return -1;
-  int e = launch_c_order_check(s, d_flags, device().stream);
+  const int e = launch_c_order_check(s, d_flags, device().stream);
   if (0 != e) return e;
-  int h[2] = { 0, 0 };
-  e = d2h(h, d_flags, sizeof(h));
-  if (0 != e) return e;
-  s.sync = (0 != h[1]) ? SYNC_ATOMIC : (0 != h[0] ? SYNC_RUNS : SYNC_NONE);
+  s.sync = SYNC_DEVICE; s.devflags = d_flags;
   return 0;
 }
 

@@ -38,7 +38,11 @@ enum AddrMode : int {
 enum SyncMode : int {
   SYNC_NONE = 0,      // every item owns its C (or beta == 0)
   SYNC_RUNS = 1,      // equal C only in consecutive runs: one work-group walks a whole run in batch order
-  SYNC_ATOMIC = 2     // arbitrary duplicates: product from zero, then atomic add into C
+  SYNC_ATOMIC = 2,    // arbitrary duplicates: product from zero, then atomic add into C
+  // Decided on the device, without a host round trip: a check kernel leaves {#equal neighbours, #out-of-order repeats}
+  // in SmmBatch::devflags and the compute kernels read them -- the call stays asynchronous (and graph-capturable).
+  SYNC_DEVICE = 3,          // pick NONE / RUNS / ATOMIC from the flags (generic kernel); run kernel: proceed unless [1] != 0
+  SYNC_DEVICE_FALLBACK = 4  // generic kernel launched behind a run kernel: ATOMIC if [1] != 0, otherwise nothing to do
 };
 
 struct SmmBatch {
@@ -52,6 +56,7 @@ struct SmmBatch {
   long long sa, sb, sc;     // ADDR_STRIDED: element strides; ADDR_POINTER: byte distance between pointers
   long long batch;
   int sync;                 // SyncMode
+  const int* devflags;      // SYNC_DEVICE*: device int[2] written by the check kernel earlier on the same stream
   int use_mfma;             // policy bit (0: scalar FMA only)
   // general form used by the BLAS-like fallback (libxsmm_?gemm with alpha/beta/trans outside the SMM domain)
   double alpha, beta; int general;              // general != 0: C = alpha*op(A)*op(B) + beta*C, flags may hold TRANS_A
@@ -122,6 +127,7 @@ Device& device();
 bool device_ready();                      // probes once; false if no HIP device
 void fail_no_device(const char* what);    // prints a loud error (always) -- the product has no CPU compute path
 bool is_device_ptr(const void* p);
+int* flag_slot();                         // device int[4] for one batch call's C-ordering verdict (nullptr: out of memory)
 void* dev_alloc(size_t bytes);
 void dev_free(void* p);
 int h2d(void* dst, const void* src, size_t bytes);

@@ -27,6 +27,7 @@ struct DevAddr {
   const char* ia; const char* ib; const char* ic;
   long long sa, sb, sc;
   int index_base, index_stride, mode;
+  const int* flags; // device-side verdict on how C blocks repeat: [0] equal neighbours, [1] out-of-order repeats (or null)
 };
 template<typename P> __device__ __forceinline__ P* resolve(const char* base, const char* idx, long long stride, const DevAddr& ad, long long i)
 {
@@ -155,6 +156,15 @@ __device__ __forceinline__ void store_c(T* Cs, T* pc, int lane, int tx, int ty, 
   wave_lds_sync();
 }
 
+// bit l: item first + l starts a run, i.e. its C differs from its predecessor's (item 0 always does)
+__device__ __forceinline__ unsigned long long head_mask(const DevAddr& ad, long long first, int lane, long long batch)
+{
+  const long long j = first + lane;
+  bool head = false;
+  if (j < batch) head = (0 == j) || (resolve<T>(ad.c, ad.ic, ad.sc, ad, j - 1) != resolve<T>(ad.c, ad.ic, ad.sc, ad, j));
+  return __ballot(head);
+}
+
 extern "C" __global__ __launch_bounds__(64 * XWAVES) void xsmm_smm_op(DevAddr ad, long long batch)
 {
   __shared__ __attribute__((aligned(16))) T lds[XWAVES * WAVE_LDS];
@@ -167,48 +177,49 @@ extern "C" __global__ __launch_bounds__(64 * XWAVES) void xsmm_smm_op(DevAddr ad
   T ra[NLA][VA], rb[NLB][VB], rc[NLC][VC];
 #if XRUNS
   // Consecutive items that share one C form a run (CP2K stacks, batch-reduce): the wave that owns the run's first item
-  // keeps C in registers and adds the products in batch order -- what the reference's sequential loop does. Run heads
-  // are found 64 items at a time (one item per lane, __ballot), chunks of 64 items are dealt round-robin to the waves.
+  // keeps C in registers and adds the products in batch order -- what the reference's sequential loop does. Chunks of 64
+  // items are dealt round-robin to the waves; run heads are found 64 items at a time (one item per lane, __ballot). A
+  // wave starts at the first head of its chunk and walks on item by item -- through the other runs of the chunk and, past
+  // the chunk's end, to the end of the run that is still open -- with the next item's operands (and its C, if it starts a
+  // run) in flight during the current item's arithmetic. A batch of distinct C blocks is the special case "all heads".
+  if (nullptr != ad.flags && 0 != ad.flags[1]) return; // C blocks repeat out of order: the atomic kernel owns this batch
   for (long long chunk = w * 64; chunk < batch; chunk += W * 64) {
-    const long long it = chunk + lane;
-    bool head = false;
-    if (it < batch) head = (0 == it) || (resolve<T>(ad.c, ad.ic, ad.sc, ad, it - 1) != resolve<T>(ad.c, ad.ic, ad.sc, ad, it));
-    unsigned long long mask = __ballot(head);
-    while (0 != mask) {
-      const long long h = chunk + (__ffsll((long long)mask) - 1);
-      mask &= mask - 1;
-      long long end;
-      if (0 != mask) end = chunk + (__ffsll((long long)mask) - 1);
-      else { // the run continues into the following chunks
-        end = chunk + 64;
-        while (end < batch) {
-          const long long j = end + lane;
-          const bool hd = (j < batch) && (resolve<T>(ad.c, ad.ic, ad.sc, ad, j - 1) != resolve<T>(ad.c, ad.ic, ad.sc, ad, j));
-          const unsigned long long mk = __ballot(hd);
-          if (0 != mk) { end += (__ffsll((long long)mk) - 1); break; }
-          end += 64;
-        }
-        if (end > batch) end = batch;
+    unsigned long long heads = head_mask(ad, chunk, lane, batch);
+    if (0 == heads) continue; // covered by a run that started in an earlier chunk
+    long long base = chunk;   // `heads` describes the items [base, base + 64)
+    long long i = chunk + (__ffsll((long long)heads) - 1);
+    load_flat<VA, NLA, AE>(resolve<const T>(ad.a, ad.ia, ad.sa, ad, i), lane, ra);
+    load_flat<VB, NLB, BE>(resolve<const T>(ad.b, ad.ib, ad.sb, ad, i), lane, rb);
+    if (!XBETA0) load_flat<VC, NLC, CE>(resolve<const T>(ad.c, ad.ic, ad.sc, ad, i), lane, rc);
+    T acc[TM][TN];
+    T* pc = nullptr;
+    for (;;) {
+      if (0 != ((heads >> (int)(i - base)) & 1ULL)) { // item i opens a run: close the previous one, take over its C
+        if (nullptr != pc) store_c(Cs, pc, lane, tx, ty, acc);
+        pc = resolve<T>(ad.c, ad.ic, ad.sc, ad, i);
+        if (!XBETA0) { park_c(Cs, lane, rc); wave_lds_sync(); }
+        acc_from_c(Cs, tx, ty, acc, XBETA0);
       }
-      T* const pc = resolve<T>(ad.c, ad.ic, ad.sc, ad, h);
-      if (!XBETA0) load_flat<VC, NLC, CE>(pc, lane, rc);
-      load_flat<VA, NLA, AE>(resolve<const T>(ad.a, ad.ia, ad.sa, ad, h), lane, ra);
-      load_flat<VB, NLB, BE>(resolve<const T>(ad.b, ad.ib, ad.sb, ad, h), lane, rb);
-      T acc[TM][TN];
-      if (!XBETA0) { park_c(Cs, lane, rc); wave_lds_sync(); }
-      acc_from_c(Cs, tx, ty, acc, XBETA0);
-      for (long long r = h; r < end; ++r) {
-        park_ab(As, Bs, lane, ra, rb);
-        if (r + 1 < end) { // the next product's operands are in flight during this product's arithmetic
-          load_flat<VA, NLA, AE>(resolve<const T>(ad.a, ad.ia, ad.sa, ad, r + 1), lane, ra);
-          load_flat<VB, NLB, BE>(resolve<const T>(ad.b, ad.ib, ad.sb, ad, r + 1), lane, rb);
-        }
-        wave_lds_sync();
-        multiply(As, Bs, tx, ty, acc);
-        wave_lds_sync();
+      park_ab(As, Bs, lane, ra, rb);
+      const long long nx = i + 1;
+      bool more = (nx < batch), nx_head = false;
+      if (more) {
+        if (nx - base >= 64) { base += 64; heads = head_mask(ad, base, lane, batch); }
+        nx_head = (0 != ((heads >> (int)(nx - base)) & 1ULL));
+        more = (nx < chunk + 64) || !nx_head; // beyond the own chunk only the tail of the open run is taken
       }
-      store_c(Cs, pc, lane, tx, ty, acc);
+      if (more) {
+        load_flat<VA, NLA, AE>(resolve<const T>(ad.a, ad.ia, ad.sa, ad, nx), lane, ra);
+        load_flat<VB, NLB, BE>(resolve<const T>(ad.b, ad.ib, ad.sb, ad, nx), lane, rb);
+        if (nx_head && !XBETA0) load_flat<VC, NLC, CE>(resolve<const T>(ad.c, ad.ic, ad.sc, ad, nx), lane, rc);
+      }
+      wave_lds_sync();
+      multiply(As, Bs, tx, ty, acc);
+      wave_lds_sync();
+      if (!more) break;
+      i = nx;
     }
+    store_c(Cs, pc, lane, tx, ty, acc);
   }
 #else
   if (w >= batch) return;
@@ -286,7 +297,7 @@ bool smm_jit_eligible(const SmmBatch& s)
   const char* const env_jit = getenv("LIBXSMM_AMD_JIT"); // re-read on every call: tests and tools toggle it
   const bool enabled = (nullptr == env_jit || 0 != atoi(env_jit));
   if (!enabled || 0 != s.general || SYNC_ATOMIC == s.sync) return false;
-  if (SYNC_RUNS == s.sync && 0 != (s.flags & LIBXSMM_GEMM_FLAG_BETA_0)) return false; // (never chosen: beta == 0 needs no care)
+  if (SYNC_NONE != s.sync && 0 != (s.flags & LIBXSMM_GEMM_FLAG_BETA_0)) return false; // (never chosen: beta == 0 needs no care)
   if (s.lda != s.m || s.ldc != s.m) return false;
   if (0 != (s.flags & LIBXSMM_GEMM_FLAG_TRANS_B) ? (s.ldb != s.n) : (s.ldb != s.k)) return false;
   if (s.m > 32 || s.n > 32 || s.k > 64) return false;                       // 8x8 lanes x (<=4x4) tile
@@ -302,7 +313,7 @@ bool smm_jit_eligible(const SmmBatch& s)
 // element-aligned. Runs of equal C (SYNC_RUNS) take the accumulate-in-registers form.
 static int smm_jit_variant(const SmmBatch& s)
 {
-  int v = (SYNC_RUNS == s.sync) ? SMM_JIT_RUNS : 0;
+  int v = (SYNC_RUNS == s.sync || SYNC_DEVICE == s.sync) ? SMM_JIT_RUNS : 0;
   bool wide = false;
   if (ADDR_STRIDED == s.mode) {
     const uintptr_t bits = reinterpret_cast<uintptr_t>(s.a) | reinterpret_cast<uintptr_t>(s.b) | reinterpret_cast<uintptr_t>(s.c);
@@ -330,9 +341,10 @@ int launch_smm_jit(const SmmBatch& s, void* stream, const char** name)
     }
   }
   if (nullptr == k) return -1;
-  struct { const char* a; const char* b; char* c; const char* ia; const char* ib; const char* ic; long long sa, sb, sc; int index_base, index_stride, mode; } ad;
+  struct { const char* a; const char* b; char* c; const char* ia; const char* ib; const char* ic; long long sa, sb, sc; int index_base, index_stride, mode; const int* flags; } ad;
   ad.a = (const char*)s.a; ad.b = (const char*)s.b; ad.c = (char*)s.c; ad.ia = (const char*)s.ia; ad.ib = (const char*)s.ib; ad.ic = (const char*)s.ic;
   ad.sa = s.sa; ad.sb = s.sb; ad.sc = s.sc; ad.index_base = s.index_base; ad.index_stride = s.index_stride; ad.mode = s.mode;
+  ad.flags = (SYNC_DEVICE == s.sync ? s.devflags : nullptr);
   long long batch = s.batch;
   const int waves = smm_jit_waves(s.typesize, s.m, s.n, s.k, s.flags);
   const size_t lds = (size_t)waves * smm_jit_wave_lds(s.typesize, s.m, s.n, s.k, s.flags);

@@ -191,14 +191,14 @@ def secondary(torch, xs, L):
 
     def compute():
         assert 0 == L.libxsmm_amd_spmdm_batch_compute(sb, b"N", xs.dptr(b), b"N", C.byref(beta), xs.dptr(c))
-    _, t_create = time_steps(torch, create, 5, 2, None)
+    _, t_create = time_steps(torch, create, 10, 2, None)
     k_create = xs.last_kernel()
-    _, t_comp = time_steps(torch, compute, 5, 2, None)
+    _, t_comp = time_steps(torch, compute, 10, 2, None)
     k_comp = xs.last_kernel()
     nnz = float((a != 0).sum().item()) / B
     by_create = 4.0 * M * K + 6.0 * nnz + 2.0 * (M + 1)
     by_comp = 6.0 * nnz + 2.0 * (M + 1) + 4.0 * K * N + 4.0 * M * N
-    mc, mp = min(t_create) * 1e-3, min(t_comp) * 1e-3
+    mc, mp = sum(t_create) / len(t_create) * 1e-3, sum(t_comp) / len(t_comp) * 1e-3  # averages, like the headline
     res["spmdm_f32_64x48x64_nnz50"] = {
         "batch": B, "nnz_per_item": round(nnz, 1),
         "create": {"kernel": k_create, "ms": round(mc * 1e3, 4), "hbm_gbs": round(B * by_create / mc / 1e9, 1), "frac": round(B * by_create / mc / 1e9 / HBM_PEAK_GBS, 4)},
@@ -220,12 +220,38 @@ def secondary(torch, xs, L):
 
     def run():
         assert 0 == L.libxsmm_amd_dfsspmdm_execute_batch(h, xs.dptr(Bm), xs.dptr(Cm), B)
-    _, t = time_steps(torch, run, 5, 2, None)
-    mt = min(t) * 1e-3
+    _, t = time_steps(torch, run, 10, 2, None)
+    mt = sum(t) / len(t) * 1e-3
     by = 8.0 * N * (K + 2 * M)  # beta=1: B read + C read + C write = 80640 B per item
     res["fsspmdm_f64_35x96x35_nnz15"] = {"batch": B, "nnz": int((A != 0).sum()), "kernel": xs.last_kernel(), "ms": round(mt * 1e3, 4),
                                          "hbm_gbs": round(B * by / mt / 1e9, 1), "frac": round(B * by / mt / 1e9 / HBM_PEAK_GBS, 4)}
     L.libxsmm_dfsspmdm_destroy(h)
+    del Bm, Cm
+    # config 5 shape mix on one GPU: CP2K-style stacks, fp64, 27 shapes x 19418 products, runs of u products per C block
+    # (samples/cp2k/cp2k.cpp:155,328-360); one libxsmm_gemm_batch (index arrays) per shape group, one stream
+    import math
+    old_mfma = L.libxsmm_amd_set_mfma(0)
+    groups, byt, flops = [], 0.0, 0.0
+    for (m, n, k) in [(m, n, k) for m in (13, 23, 32) for n in (13, 23, 32) for k in (13, 23, 32)]:
+        s_ = 19418
+        u = max(1, math.isqrt(s_ * 160 // 240)); nc = (s_ + u - 1) // u
+        a = torch.rand(s_ * m * k, device="cuda", dtype=torch.float64, generator=g) - 0.5
+        b = torch.rand(s_ * k * n, device="cuda", dtype=torch.float64, generator=g) - 0.5
+        c = torch.zeros(nc * m * n, device="cuda", dtype=torch.float64)
+        idx = torch.arange(s_, device="cuda", dtype=torch.int64)
+        groups.append((m, n, k, s_, a, b, c, (idx * (m * k)).to(torch.int32), (idx * (k * n)).to(torch.int32), ((idx // u) * (m * n)).to(torch.int32)))
+        byt += s_ * 8.0 * (m * k + k * n) + nc * 16.0 * m * n  # the reference's bwsize (cp2k.cpp:156)
+        flops += 2.0 * m * n * k * s_
+
+    def stacks():
+        for (m, n, k, s_, a, b, c, ia, ib, ic) in groups:
+            xs.gemm_batch(xs.F64, "N", "N", m, n, k, 1.0, a, m, b, k, 1.0, c, m, 0, 4, ia, ib, ic, s_)
+    _, t = time_steps(torch, stacks, 5, 2, None)
+    mt = sum(t) / len(t) * 1e-3
+    L.libxsmm_amd_set_mfma(old_mfma)
+    res["cp2k_stacks_f64_27shapes"] = {"products": 27 * 19418, "kernel": xs.last_kernel(), "streams": 1, "ms": round(mt * 1e3, 4),
+                                       "hbm_gbs": round(byt / mt / 1e9, 1), "frac": round(byt / mt / 1e9 / HBM_PEAK_GBS, 4),
+                                       "gflops": round(flops / mt / 1e9, 1)}
     return res
 
 

@@ -311,6 +311,14 @@ __device__ __forceinline__ void spw_rows(int m0, int m1, int pbase, int g, int n
   }
 }
 
+// Work-group barrier that orders LDS traffic only. __syncthreads() carries a work-group-scope fence, and on gfx9 that
+// drains vmcnt: the next item's B tile and CSR entries, requested just before the barrier, would have to arrive before
+// this item's rows may start -- the register-staged pipeline would not overlap anything within a work-group.
+__device__ __forceinline__ void spw_lds_barrier()
+{
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // NB = 16-byte pieces of the B tile per thread (tile <= NB * 1024 floats)
 template<int NB>
 __global__ __launch_bounds__(256, 4) // four work-groups per CU are what the LDS footprint allows: keep VGPRs <= 128
@@ -387,10 +395,10 @@ void spmdm_compute_wg_kernel(long long batch, int M, int N, int K, float beta,
     const long long next = item + G;
     const int nnz_next2 = (next + G < batch) ? (int)rowidx[(next + G) * rstride + M] : 0;
     if (next < batch) fetch(next, nnz_next);
-    __syncthreads();
+    spw_lds_barrier();
     if (one_window) {
       spw_rows(0, M, 0, g, n0, active_n, N, beta, ris, meta, Bs, pc);
-      __syncthreads();
+      spw_lds_barrier();
     }
     else { // dense items: walk the rows in windows of as many 16-row rounds as fit the metadata buffer
       const uint16_t* const ci = colidx + item * cap;
@@ -409,9 +417,9 @@ void spmdm_compute_wg_kernel(long long batch, int M, int N, int K, float beta,
           const int off = (int)ci[pbase + e] * SPW_LDB;
           meta[e] = float2{ __int_as_float(off), va[pbase + e] };
         }
-        __syncthreads();
+        spw_lds_barrier();
         spw_rows(m0, m1, pbase, g, n0, active_n, N, beta, ris, meta, Bs, pc);
-        __syncthreads();
+        spw_lds_barrier();
         m0 = m1;
       }
     }

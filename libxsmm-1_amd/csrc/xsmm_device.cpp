@@ -17,7 +17,7 @@ Device g_device;
 std::atomic<unsigned long long> g_launches{0};
 thread_local const char* tl_last_kernel = "";
 
-struct Scratch { void* ptr = nullptr; size_t size = 0; };
+struct Scratch { void* ptr = nullptr; size_t size = 0; void* stream = nullptr; bool used = false; };
 thread_local Scratch tl_scratch[8];
 }
 
@@ -100,8 +100,13 @@ int* flag_slot()
 void* scratch(int slot, size_t bytes)
 {
   Scratch& s = tl_scratch[slot & 7];
+  // Launches are asynchronous: whatever was queued on the stream that used this buffer last may still be reading it.
+  // (Scratch only serves the staging of host-resident operands -- the compatibility path -- so the wait costs nothing
+  // on the device-resident path.)
+  if (s.used) (void)hipStreamSynchronize((hipStream_t)s.stream);
+  s.stream = g_device.stream; s.used = true;
   if (s.size < bytes) {
-    if (nullptr != s.ptr) { (void)hipStreamSynchronize((hipStream_t)g_device.stream); (void)hipFree(s.ptr); }
+    if (nullptr != s.ptr) (void)hipFree(s.ptr);
     s.ptr = nullptr; s.size = 0;
     const size_t want = bytes + bytes / 4 + 4096;
     if (hipSuccess == hipMalloc(&s.ptr, want)) s.size = want; else { (void)hipGetLastError(); s.ptr = nullptr; }

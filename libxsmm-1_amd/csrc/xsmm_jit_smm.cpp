@@ -21,6 +21,7 @@ namespace xsmm {
 namespace {
 
 const char* const SMM_JIT_BODY = R"XSMM(
+#define XGLOBAL __attribute__((address_space(1)))
 // ---- batch addressing (same structure and meaning as kernels/smm_common.cuh) ----
 struct DevAddr {
   const char* a; const char* b; char* c;
@@ -32,8 +33,8 @@ struct DevAddr {
 template<typename P> __device__ __forceinline__ P* resolve(const char* base, const char* idx, long long stride, const DevAddr& ad, long long i)
 {
   if (0 == ad.mode) return (P*)base + i * stride;
-  if (1 == ad.mode) { if (nullptr == idx) return (P*)base; const int v = *(const int*)(idx + i * (long long)ad.index_stride); return (P*)base + ((long long)v - ad.index_base); }
-  return *(P* const*)(base + i * stride);
+  if (1 == ad.mode) { if (nullptr == idx) return (P*)base; const int v = *(const XGLOBAL int*)(idx + i * (long long)ad.index_stride); return (P*)base + ((long long)v - ad.index_base); }
+  return *(P* const XGLOBAL*)(base + i * stride);
 }
 __device__ __forceinline__ float xfma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ double xfma(double a, double b, double c) { return __builtin_fma(a, b, c); }
@@ -45,36 +46,54 @@ __device__ __forceinline__ void wave_lds_sync()
 }
 
 constexpr int M = XM, N = XN, K = XK;
-constexpr int TGM = 8, TGN = 8;
-constexpr int TM = (M + TGM - 1) / TGM, TN = (N + TGN - 1) / TGN;
 constexpr int AE = M * K, BE = K * N, CE = M * N;                  // elements per operand (tight leading dimensions)
 constexpr int TS = (int)sizeof(T);
+#if (2 == XRUNS)
+// work-group form: 4 waves share one product; a wave owns NQ = ceil(N/4) columns of C, its 64 lanes are 16 (along m) x 4
+constexpr int UT = 256;                                            // threads that stream one item's operands
+constexpr int TGM = 16, TGN = 4;
+constexpr int NQ = (N + 3) / 4;
+constexpr int TM = (M + TGM - 1) / TGM, TN = (NQ + TGN - 1) / TGN;
+constexpr int NPAD = 3 * NQ + TGN * TN;                            // highest column index a lane may touch, plus one
+#else
+// wave form: one wave per item, 8 x 8 lanes
+constexpr int UT = 64;
+constexpr int TGM = 8, TGN = 8;
+constexpr int TM = (M + TGM - 1) / TGM, TN = (N + TGN - 1) / TGN;
+constexpr int NPAD = TGN * TN;
+#endif
 // widest access (in elements) that every item of a strided batch is aligned for
 constexpr int vw(int elems) { return (0 == (elems * TS) % 16) ? 16 / TS : ((0 == (elems * TS) % 8) ? 8 / TS : 1); }
 // XSCALAR: index/pointer batches guarantee element alignment only
 constexpr int VA = XSCALAR ? 1 : vw(AE), VB = XSCALAR ? 1 : vw(BE), VC = XSCALAR ? 1 : vw(CE);
-constexpr int NLA = (AE + 64 * VA - 1) / (64 * VA), NLB = (BE + 64 * VB - 1) / (64 * VB), NLC = (CE + 64 * VC - 1) / (64 * VC);
+constexpr int NLA = (AE + UT * VA - 1) / (UT * VA), NLB = (BE + UT * VB - 1) / (UT * VB), NLC = (CE + UT * VC - 1) / (UT * VC);
 // LDS strides: A as [k][M] (lanes with equal ty read the same words, lanes with different tx adjacent ones);
-// B as [n][KP] (TRANS_B: [k][NP]) with KP chosen so that the eight column groups fall into different banks
+// B as [n][KP] (TRANS_B: [k][N]) with KP chosen so that the column groups of one instruction fall into different banks
 constexpr int pick_kp() { int kp = K; while (0 == (TN * kp * (TS / 4)) % 16) ++kp; return kp; }
 constexpr int KP = pick_kp();
 constexpr int AS_SIZE = ((K * M + TGM * TM + 3) / 4) * 4;
-constexpr int BS_SIZE = XTRANSB ? (((K * N + TGN * TN + 3) / 4) * 4) : (((TGN * TN) * KP + 3) / 4) * 4;
+constexpr int BS_SIZE = XTRANSB ? (((K * N + NPAD + 3) / 4) * 4) : ((NPAD * KP + 3) / 4) * 4;
 constexpr int CS_SIZE = ((CE + 3) / 4) * 4;
-constexpr int WAVE_LDS = AS_SIZE + BS_SIZE + CS_SIZE;                // elements
+constexpr int WAVE_LDS = AS_SIZE + BS_SIZE + CS_SIZE;                // elements (wave form)
+constexpr int WG_BUF = AS_SIZE + BS_SIZE;                            // elements per operand buffer (work-group form)
+constexpr int WG_NBUF = (2 * WG_BUF * TS <= 65536) ? 2 : 1;          // double-buffered when 64 KiB allow
 
 template<int V> struct Vec { typedef T type __attribute__((ext_vector_type(V))); };
 template<> struct Vec<1> { typedef T type; };
 
+// Operands are in global memory, but their addresses come out of a run-time choice between three addressing modes (one of
+// them loads the pointer): left generic, every access becomes a FLAT instruction, which also counts on lgkmcnt -- each wait
+// for an LDS operation would then wait for the prefetched operands as well. Hence the explicit address space.
 template<int V, int NL, int E> __device__ __forceinline__ void load_flat(const T* p, int lane, T (&r)[NL][V])
 {
+  const XGLOBAL T* const g = (const XGLOBAL T*)p;
 #pragma unroll
   for (int j = 0; j < NL; ++j) {
-    const int e = (64 * j + lane) * V;
+    const int e = (UT * j + lane) * V;
     if (e < E) {
-      if constexpr (1 == V) r[j][0] = __builtin_nontemporal_load(p + e);
+      if constexpr (1 == V) r[j][0] = __builtin_nontemporal_load(g + e);
       else {
-        const typename Vec<V>::type v = __builtin_nontemporal_load(reinterpret_cast<const typename Vec<V>::type*>(p + e));
+        const typename Vec<V>::type v = __builtin_nontemporal_load(reinterpret_cast<const XGLOBAL typename Vec<V>::type*>(g + e));
 #pragma unroll
         for (int q = 0; q < V; ++q) r[j][q] = v[q];
       }
@@ -82,19 +101,19 @@ template<int V, int NL, int E> __device__ __forceinline__ void load_flat(const T
   }
 }
 
-// registers -> wave-private LDS (A as stored, B with the padded row stride)
+// registers -> LDS (A as stored, B with the padded row stride); `lane` is the thread's index among the UT streaming threads
 __device__ __forceinline__ void park_ab(T* As, T* Bs, int lane, const T (&ra)[NLA][VA], const T (&rb)[NLB][VB])
 {
 #pragma unroll
   for (int j = 0; j < NLA; ++j) {
 #pragma unroll
-    for (int q = 0; q < VA; ++q) { const int e = (64 * j + lane) * VA + q; if (e < AE) As[e] = ra[j][q]; }
+    for (int q = 0; q < VA; ++q) { const int e = (UT * j + lane) * VA + q; if (e < AE) As[e] = ra[j][q]; }
   }
 #pragma unroll
   for (int j = 0; j < NLB; ++j) {
 #pragma unroll
     for (int q = 0; q < VB; ++q) {
-      const int e = (64 * j + lane) * VB + q;
+      const int e = (UT * j + lane) * VB + q;
       if (e < BE) { if (XTRANSB) Bs[e] = rb[j][q]; else Bs[(e / K) * KP + (e % K)] = rb[j][q]; }
     }
   }
@@ -108,7 +127,7 @@ __device__ __forceinline__ void park_c(T* Cs, int lane, const T (&rc)[NLC][VC])
   }
 }
 // acc(i,j) = fma(A(m,k), B(k,n), acc(i,j)) for k ascending: the reference's per-element chain
-__device__ __forceinline__ void multiply(const T* As, const T* Bs, int tx, int ty, T (&acc)[TM][TN])
+__device__ __forceinline__ void multiply(const T* As, const T* Bs, int tx, int ncol0, T (&acc)[TM][TN])
 {
 #pragma unroll 4
   for (int k = 0; k < K; ++k) {
@@ -116,7 +135,7 @@ __device__ __forceinline__ void multiply(const T* As, const T* Bs, int tx, int t
 #pragma unroll
     for (int i = 0; i < TM; ++i) av[i] = As[k * M + tx * TM + i];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) bv[j] = XTRANSB ? Bs[k * N + ty * TN + j] : Bs[(ty * TN + j) * KP + k];
+    for (int j = 0; j < TN; ++j) bv[j] = XTRANSB ? Bs[k * N + ncol0 + j] : Bs[(ncol0 + j) * KP + k];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -124,6 +143,50 @@ __device__ __forceinline__ void multiply(const T* As, const T* Bs, int tx, int t
     }
   }
 }
+#if XRUNS
+// The run forms keep few waves per CU busy (a run is a sequential chain), so nothing hides the LDS round trip between an
+// operand read and its fma. Software pipeline over groups of KU k-steps: the reads of group g+1 are issued before the fmas
+// of group g (two register sets, fully unrolled: all indices are compile-time constants).
+constexpr int KU = (2 == XRUNS) ? 4 : 2;
+constexpr int NG = (K + KU - 1) / KU;
+__device__ __forceinline__ void read_group(const T* As, const T* Bs, int tx, int ncol0, int g, T (&av)[KU][TM], T (&bv)[KU][TN])
+{
+#pragma unroll
+  for (int u = 0; u < KU; ++u) {
+    const int k = g * KU + u;
+    if (k < K) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) av[u][i] = As[k * M + tx * TM + i];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bv[u][j] = XTRANSB ? Bs[k * N + ncol0 + j] : Bs[(ncol0 + j) * KP + k];
+    }
+  }
+}
+__device__ __forceinline__ void fma_group(int g, const T (&av)[KU][TM], const T (&bv)[KU][TN], T (&acc)[TM][TN])
+{
+#pragma unroll
+  for (int u = 0; u < KU; ++u) {
+    if (g * KU + u < K) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = xfma(av[u][i], bv[u][j], acc[i][j]);
+      }
+    }
+  }
+}
+__device__ __forceinline__ void multiply_pipelined(const T* As, const T* Bs, int tx, int ncol0, T (&acc)[TM][TN])
+{
+  T a0[KU][TM], b0[KU][TN], a1[KU][TM], b1[KU][TN];
+  read_group(As, Bs, tx, ncol0, 0, a0, b0);
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    if (0 == (g & 1)) { if (g + 1 < NG) read_group(As, Bs, tx, ncol0, g + 1, a1, b1); fma_group(g, a0, b0, acc); }
+    else { if (g + 1 < NG) read_group(As, Bs, tx, ncol0, g + 1, a0, b0); fma_group(g, a1, b1, acc); }
+  }
+}
+#endif
+
 __device__ __forceinline__ void acc_from_c(const T* Cs, int tx, int ty, T (&acc)[TM][TN], bool zero)
 {
 #pragma unroll
@@ -149,8 +212,8 @@ __device__ __forceinline__ void store_c(T* Cs, T* pc, int lane, int tx, int ty, 
   for (int j = 0; j < NLC; ++j) {
     const int e = (64 * j + lane) * VC;
     if (e < CE) {
-      if constexpr (1 == VC) __builtin_nontemporal_store(Cs[e], pc + e);
-      else __builtin_nontemporal_store(*reinterpret_cast<const typename Vec<VC>::type*>(Cs + e), reinterpret_cast<typename Vec<VC>::type*>(pc + e));
+      if constexpr (1 == VC) __builtin_nontemporal_store(Cs[e], (XGLOBAL T*)pc + e);
+      else __builtin_nontemporal_store(*reinterpret_cast<const typename Vec<VC>::type*>(Cs + e), reinterpret_cast<XGLOBAL typename Vec<VC>::type*>((XGLOBAL T*)pc + e));
     }
   }
   wave_lds_sync();
@@ -165,64 +228,207 @@ __device__ __forceinline__ unsigned long long head_mask(const DevAddr& ad, long 
   return __ballot(head);
 }
 
+// Items [first, end) a wave / work-group walks when it is dealt the chunk [chunk, chunk + 64): from the chunk's first run
+// head through the chunk's other runs to the end of the run that is still open at the chunk's end (the next head at or
+// beyond chunk + 64). Returns false if the chunk holds no head (an earlier chunk's walk covers it).
+__device__ __forceinline__ bool chain_of_chunk(const DevAddr& ad, long long chunk, int lane, long long batch,
+                                               unsigned long long& heads, long long& first, long long& end)
+{
+  heads = head_mask(ad, chunk, lane, batch);
+  if (0 == heads) return false;
+  first = chunk + (__ffsll((long long)heads) - 1);
+  end = chunk + 64;
+  while (end < batch) {
+    const unsigned long long mk = head_mask(ad, end, lane, batch);
+    if (0 != mk) { end += (__ffsll((long long)mk) - 1); break; }
+    end += 64;
+  }
+  if (end > batch) end = batch;
+  return true;
+}
+__device__ __forceinline__ bool is_head(unsigned long long heads, long long chunk, long long i)
+{ // beyond the chunk the walk only continues through non-heads
+  return (i < chunk + 64) && (0 != ((heads >> (int)(i - chunk)) & 1ULL));
+}
+
+constexpr int D = XDEPTH; // products whose operands are in flight (register stages)
+
+// Work-group barrier that orders LDS traffic only. __syncthreads() carries a work-group-scope fence, which on gfx9 drains
+// vmcnt -- i.e. every global load in flight, the whole register ring of prefetched products -- before each s_barrier and
+// turns the D-deep prefetch into depth one (measured: 2.2 us per 32^3 product instead of well under one).
+__device__ __forceinline__ void lds_barrier()
+{
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// Operand addresses of 64 consecutive items, one item per lane. Index and pointer batches need a load per item and operand
+// before the operand itself can be requested; done item by item that load is a full memory round trip on the critical
+// path of a run. Here 64 of them travel together and single addresses are picked with v_readlane.
+struct AddrWindow { long long base; unsigned long long a, b; };
+__device__ __forceinline__ void window_fill(AddrWindow& w, const DevAddr& ad, long long base, int lane, long long end)
+{
+  const long long j = base + lane;
+  w.base = base;
+  w.a = (j < end) ? (unsigned long long)resolve<const T>(ad.a, ad.ia, ad.sa, ad, j) : 0ULL;
+  w.b = (j < end) ? (unsigned long long)resolve<const T>(ad.b, ad.ib, ad.sb, ad, j) : 0ULL;
+  // The addresses may be load results (pointer batches). Settle that here, once per 64 items: otherwise the compiler must
+  // assume a pending load at every later v_readlane and drains vmcnt -- the prefetched operands -- before each item.
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(w.a), "+v"(w.b));
+}
+__device__ __forceinline__ const T* window_pick(unsigned long long v, int src)
+{
+  const unsigned lo = __builtin_amdgcn_readlane((unsigned)v, src), hi = __builtin_amdgcn_readlane((unsigned)(v >> 32), src);
+  return (const T*)(((unsigned long long)hi << 32) | lo);
+}
+// addresses of item i (i never decreases between calls; the window slides forward in steps that keep i inside)
+#define WINDOW_AB(W, I, PA, PB) \
+  if ((I) - (W).base >= 64) window_fill((W), ad, (I), lane, end); \
+  const int w_src_ = __builtin_amdgcn_readfirstlane((int)((I) - (W).base)); \
+  const T* const PA = window_pick((W).a, w_src_); const T* const PB = window_pick((W).b, w_src_)
+
+#if (2 == XRUNS)
+// Work-group form for long runs (CP2K stacks, batch-reduce): the four waves of a work-group share every product of a run.
+// All 256 threads stream A and B of the products D ahead into register stages while the current one is multiplied out of
+// LDS (two operand buffers when 64 KiB allow: one barrier per product); wave v owns columns [v*NQ, v*NQ + NQ) of C and
+// keeps them in registers for the whole run, each element still receiving its products in batch order, k ascending --
+// the sequential reference's chain. A long run is a latency chain (HBM round trip per product): the depth of the register
+// ring, not the thread count, is what shortens it.
+extern "C" __global__ __launch_bounds__(256) void xsmm_smm_op(DevAddr ad, long long batch)
+{
+  __shared__ __attribute__((aligned(16))) T lds[WG_NBUF * WG_BUF];
+  const int t = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
+  const int tx = lane & (TGM - 1), ty = lane >> 4;
+  const int ncol0 = wave * NQ + ty * TN;
+  if (nullptr != ad.flags) {
+    if (0 != ad.flags[1]) return;                                    // C repeats out of order: the atomic kernel owns this batch
+    if (8LL * ad.flags[0] < 7LL * batch) return;                     // runs shorter than 8 on average: the wave form owns it
+  }
+  T ra[D][NLA][VA], rb[D][NLB][VB];
+  int buf = 0;
+  for (long long chunk = (long long)blockIdx.x * 64; chunk < batch; chunk += (long long)gridDim.x * 64) {
+    unsigned long long heads; long long first, end;
+    if (!chain_of_chunk(ad, chunk, lane, batch, heads, first, end)) continue; // identical in the four waves
+    AddrWindow win; window_fill(win, ad, first, lane, end);
+#pragma unroll
+    for (int s = 0; s < D; ++s) {
+      if (first + s < end) {
+        WINDOW_AB(win, first + s, pa, pb);
+        load_flat<VA, NLA, AE>(pa, t, ra[s]);
+        load_flat<VB, NLB, BE>(pb, t, rb[s]);
+      }
+    }
+    T acc[TM][TN];
+    T* pc = nullptr;
+    for (long long i0 = first; i0 < end; i0 += D) {
+#pragma unroll
+      for (int s = 0; s < D; ++s) {
+        const long long i = i0 + s;
+        if (i < end) {
+          if (is_head(heads, chunk, i)) { // item i opens a run: C goes straight between HBM and registers
+            if (nullptr != pc) {
+#pragma unroll
+              for (int ii = 0; ii < TM; ++ii) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) { const int m = tx * TM + ii, n = ncol0 + j; if (m < M && ty * TN + j < NQ && n < N) ((XGLOBAL T*)pc)[n * M + m] = acc[ii][j]; }
+              }
+            }
+            pc = resolve<T>(ad.c, ad.ic, ad.sc, ad, i);
+#pragma unroll
+            for (int ii = 0; ii < TM; ++ii) {
+#pragma unroll
+              for (int j = 0; j < TN; ++j) {
+                const int m = tx * TM + ii, n = ncol0 + j;
+                acc[ii][j] = (!XBETA0 && m < M && ty * TN + j < NQ && n < N) ? ((const XGLOBAL T*)pc)[n * M + m] : (T)0;
+              }
+            }
+          }
+          T* const As = lds + buf * WG_BUF;
+          T* const Bs = As + AS_SIZE;
+          if (1 == WG_NBUF) lds_barrier(); // single buffer: the previous product's readers must be done
+          park_ab(As, Bs, t, ra[s], rb[s]);
+          if (i + D < end) {
+            WINDOW_AB(win, i + D, pa, pb);
+            load_flat<VA, NLA, AE>(pa, t, ra[s]);
+            load_flat<VB, NLB, BE>(pb, t, rb[s]);
+          }
+          lds_barrier();
+          multiply_pipelined(As, Bs, tx, ncol0, acc);
+          buf ^= (WG_NBUF - 1);
+        }
+      }
+    }
+#pragma unroll
+    for (int ii = 0; ii < TM; ++ii) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) { const int m = tx * TM + ii, n = ncol0 + j; if (m < M && ty * TN + j < NQ && n < N) ((XGLOBAL T*)pc)[n * M + m] = acc[ii][j]; }
+    }
+  }
+}
+#else
 extern "C" __global__ __launch_bounds__(64 * XWAVES) void xsmm_smm_op(DevAddr ad, long long batch)
 {
   __shared__ __attribute__((aligned(16))) T lds[XWAVES * WAVE_LDS];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int tx = lane & 7, ty = lane >> 3;
   T* const As = lds + wave * WAVE_LDS;
   T* const Bs = As + AS_SIZE;
   T* const Cs = Bs + BS_SIZE;
   const long long w = (long long)blockIdx.x * XWAVES + wave, W = (long long)gridDim.x * XWAVES;
-  T ra[NLA][VA], rb[NLB][VB], rc[NLC][VC];
 #if XRUNS
   // Consecutive items that share one C form a run (CP2K stacks, batch-reduce): the wave that owns the run's first item
   // keeps C in registers and adds the products in batch order -- what the reference's sequential loop does. Chunks of 64
   // items are dealt round-robin to the waves; run heads are found 64 items at a time (one item per lane, __ballot). A
-  // wave starts at the first head of its chunk and walks on item by item -- through the other runs of the chunk and, past
-  // the chunk's end, to the end of the run that is still open -- with the next item's operands (and its C, if it starts a
-  // run) in flight during the current item's arithmetic. A batch of distinct C blocks is the special case "all heads".
-  if (nullptr != ad.flags && 0 != ad.flags[1]) return; // C blocks repeat out of order: the atomic kernel owns this batch
+  // wave walks its chain (see chain_of_chunk) item by item with the operands of the next D items in flight (and the C of
+  // the next item, if it starts a run). A batch of distinct C blocks is the special case "all heads".
+  if (nullptr != ad.flags) {
+    if (0 != ad.flags[1]) return;                  // C blocks repeat out of order: the atomic kernel owns this batch
+    if (XHASWG && 8LL * ad.flags[0] >= 7LL * batch) return; // runs of 8 and more on average: the work-group form owns this batch
+  }
+  T ra[D][NLA][VA], rb[D][NLB][VB], rc[NLC][VC];
   for (long long chunk = w * 64; chunk < batch; chunk += W * 64) {
-    unsigned long long heads = head_mask(ad, chunk, lane, batch);
-    if (0 == heads) continue; // covered by a run that started in an earlier chunk
-    long long base = chunk;   // `heads` describes the items [base, base + 64)
-    long long i = chunk + (__ffsll((long long)heads) - 1);
-    load_flat<VA, NLA, AE>(resolve<const T>(ad.a, ad.ia, ad.sa, ad, i), lane, ra);
-    load_flat<VB, NLB, BE>(resolve<const T>(ad.b, ad.ib, ad.sb, ad, i), lane, rb);
-    if (!XBETA0) load_flat<VC, NLC, CE>(resolve<const T>(ad.c, ad.ic, ad.sc, ad, i), lane, rc);
+    unsigned long long heads; long long first, end;
+    if (!chain_of_chunk(ad, chunk, lane, batch, heads, first, end)) continue;
+    AddrWindow win; window_fill(win, ad, first, lane, end);
+#pragma unroll
+    for (int s = 0; s < D; ++s) {
+      if (first + s < end) {
+        WINDOW_AB(win, first + s, pa, pb);
+        load_flat<VA, NLA, AE>(pa, lane, ra[s]);
+        load_flat<VB, NLB, BE>(pb, lane, rb[s]);
+      }
+    }
+    if (!XBETA0) load_flat<VC, NLC, CE>(resolve<const T>(ad.c, ad.ic, ad.sc, ad, first), lane, rc);
     T acc[TM][TN];
     T* pc = nullptr;
-    for (;;) {
-      if (0 != ((heads >> (int)(i - base)) & 1ULL)) { // item i opens a run: close the previous one, take over its C
-        if (nullptr != pc) store_c(Cs, pc, lane, tx, ty, acc);
-        pc = resolve<T>(ad.c, ad.ic, ad.sc, ad, i);
-        if (!XBETA0) { park_c(Cs, lane, rc); wave_lds_sync(); }
-        acc_from_c(Cs, tx, ty, acc, XBETA0);
+    for (long long i0 = first; i0 < end; i0 += D) {
+#pragma unroll
+      for (int s = 0; s < D; ++s) {
+        const long long i = i0 + s;
+        if (i < end) {
+          if (is_head(heads, chunk, i)) { // item i opens a run: close the previous one, take over its C
+            if (nullptr != pc) store_c(Cs, pc, lane, tx, ty, acc);
+            pc = resolve<T>(ad.c, ad.ic, ad.sc, ad, i);
+            if (!XBETA0) { park_c(Cs, lane, rc); wave_lds_sync(); }
+            acc_from_c(Cs, tx, ty, acc, XBETA0);
+          }
+          park_ab(As, Bs, lane, ra[s], rb[s]);
+          if (i + D < end) {
+            WINDOW_AB(win, i + D, pa, pb);
+            load_flat<VA, NLA, AE>(pa, lane, ra[s]);
+            load_flat<VB, NLB, BE>(pb, lane, rb[s]);
+          }
+          if (!XBETA0 && i + 1 < end && is_head(heads, chunk, i + 1)) load_flat<VC, NLC, CE>(resolve<const T>(ad.c, ad.ic, ad.sc, ad, i + 1), lane, rc);
+          wave_lds_sync();
+          multiply_pipelined(As, Bs, tx, ty * TN, acc);
+          wave_lds_sync();
+        }
       }
-      park_ab(As, Bs, lane, ra, rb);
-      const long long nx = i + 1;
-      bool more = (nx < batch), nx_head = false;
-      if (more) {
-        if (nx - base >= 64) { base += 64; heads = head_mask(ad, base, lane, batch); }
-        nx_head = (0 != ((heads >> (int)(nx - base)) & 1ULL));
-        more = (nx < chunk + 64) || !nx_head; // beyond the own chunk only the tail of the open run is taken
-      }
-      if (more) {
-        load_flat<VA, NLA, AE>(resolve<const T>(ad.a, ad.ia, ad.sa, ad, nx), lane, ra);
-        load_flat<VB, NLB, BE>(resolve<const T>(ad.b, ad.ib, ad.sb, ad, nx), lane, rb);
-        if (nx_head && !XBETA0) load_flat<VC, NLC, CE>(resolve<const T>(ad.c, ad.ic, ad.sc, ad, nx), lane, rc);
-      }
-      wave_lds_sync();
-      multiply(As, Bs, tx, ty, acc);
-      wave_lds_sync();
-      if (!more) break;
-      i = nx;
     }
     store_c(Cs, pc, lane, tx, ty, acc);
   }
 #else
   if (w >= batch) return;
+  T ra[NLA][VA], rb[NLB][VB], rc[NLC][VC];
   load_flat<VA, NLA, AE>(resolve<const T>(ad.a, ad.ia, ad.sa, ad, w), lane, ra);
   load_flat<VB, NLB, BE>(resolve<const T>(ad.b, ad.ib, ad.sb, ad, w), lane, rb);
   if (!XBETA0) load_flat<VC, NLC, CE>(resolve<const T>(ad.c, ad.ic, ad.sc, ad, w), lane, rc);
@@ -240,18 +446,19 @@ extern "C" __global__ __launch_bounds__(64 * XWAVES) void xsmm_smm_op(DevAddr ad
     wave_lds_sync();
     T acc[TM][TN];
     acc_from_c(Cs, tx, ty, acc, XBETA0);
-    multiply(As, Bs, tx, ty, acc);
+    multiply(As, Bs, tx, ty * TN, acc);
     store_c(Cs, pc, lane, tx, ty, acc);
   }
 #endif
 }
+#endif
 )XSMM";
 
 struct SmmKey {
   int typesize, m, n, k, flags, variant;
   bool operator==(const SmmKey& o) const { return typesize == o.typesize && m == o.m && n == o.n && k == o.k && flags == o.flags && variant == o.variant; }
 };
-struct SmmKeyHash { size_t operator()(const SmmKey& k) const { return (size_t)((((k.m * 131 + k.n) * 131 + k.k) * 8 + k.flags * 2 + (k.typesize == 8)) * 4 + k.variant); } };
+struct SmmKeyHash { size_t operator()(const SmmKey& k) const { return (size_t)((((k.m * 131 + k.n) * 131 + k.k) * 8 + k.flags * 2 + (k.typesize == 8)) * 16 + k.variant); } };
 
 std::mutex g_smm_lock;
 std::unordered_map<SmmKey, JitKernel*, SmmKeyHash> g_smm_cache; // nullptr value: compilation failed, do not retry
@@ -259,6 +466,18 @@ std::unordered_map<SmmKey, JitKernel*, SmmKeyHash> g_smm_cache; // nullptr value
 } // namespace
 
 static int smm_jit_waves(int typesize, int m, int n, int k, int flags);
+
+// Products whose operands a run kernel keeps in flight (register stages). Measured on CP2K stacks (MI355X): once the
+// per-item index loads are off the critical path (address windows) a run is bound by its on-chip work per product, not by
+// the HBM round trip -- depths 2 and 4 were no faster (work-group form) or slower (wave form: register pressure).
+// The ring stays in the source as a developer knob (XSMM_SMMJIT_DEPTH).
+static int smm_jit_depth(int typesize, int m, int n, int k, int variant)
+{
+  (void)typesize; (void)m; (void)n; (void)k;
+  if (0 == (variant & (SMM_JIT_RUNS | SMM_JIT_WGRUNS))) return 1;
+  static const int env = []() { const char* e = getenv("XSMM_SMMJIT_DEPTH"); return (nullptr != e && 0 != *e) ? atoi(e) : 0; }();
+  return (0 < env && env <= 8) ? env : 1;
+}
 
 std::string gen_smm_source(int typesize, int m, int n, int k, int flags, int variant)
 {
@@ -269,7 +488,10 @@ std::string gen_smm_source(int typesize, int m, int n, int k, int flags, int var
   s += std::string("#define XTRANSB ") + ((flags & LIBXSMM_GEMM_FLAG_TRANS_B) ? "1" : "0") + "\n";
   s += "#define XWAVES " + std::to_string(smm_jit_waves(typesize, m, n, k, flags)) + "\n";
   s += std::string("#define XSCALAR ") + ((variant & SMM_JIT_SCALAR) ? "1" : "0") + "\n"; // element-wide loads/stores only
-  s += std::string("#define XRUNS ") + ((variant & SMM_JIT_RUNS) ? "1" : "0") + "\n";     // runs of equal C accumulate in registers
+  // runs of equal C accumulate in registers: 1 = a wave per run, 2 = a work-group per run (long runs)
+  s += std::string("#define XRUNS ") + ((variant & SMM_JIT_WGRUNS) ? "2" : ((variant & SMM_JIT_RUNS) ? "1" : "0")) + "\n";
+  s += "#define XDEPTH " + std::to_string(smm_jit_depth(typesize, m, n, k, variant)) + "\n";  // register stages of the run forms
+  s += std::string("#define XHASWG ") + ((variant & SMM_JIT_HASWG) ? "1" : "0") + "\n";   // wave form: leave long runs to the work-group form
   s += SMM_JIT_BODY;
   return s;
 }
@@ -308,12 +530,21 @@ bool smm_jit_eligible(const SmmBatch& s)
   return true;
 }
 
+// LDS bytes of one operand buffer of the work-group form (mirrors the constexpr arithmetic of the source)
+static size_t smm_jit_wg_buf(int typesize, int m, int n, int k, int flags)
+{
+  const int nq = (n + 3) / 4, tm = (m + 15) / 16, tn = (nq + 3) / 4, npad = 3 * nq + 4 * tn;
+  int kp = k; while (0 == (tn * kp * (typesize / 4)) % 16) ++kp;
+  const size_t as = ((size_t)(k * m + 16 * tm + 3) / 4) * 4;
+  const size_t bs = (flags & LIBXSMM_GEMM_FLAG_TRANS_B) ? (((size_t)(k * n + npad + 3) / 4) * 4) : (((size_t)npad * kp + 3) / 4) * 4;
+  return (as + bs) * typesize;
+}
+
 // Which flavour of the generated kernel a batch needs: strided batches of tightly packed items whose bases are 16-byte
 // aligned use the widest loads the item size allows; index/pointer batches (and anything else) are only known to be
-// element-aligned. Runs of equal C (SYNC_RUNS) take the accumulate-in-registers form.
-static int smm_jit_variant(const SmmBatch& s)
+// element-aligned.
+static int smm_jit_width_variant(const SmmBatch& s)
 {
-  int v = (SYNC_RUNS == s.sync || SYNC_DEVICE == s.sync) ? SMM_JIT_RUNS : 0;
   bool wide = false;
   if (ADDR_STRIDED == s.mode) {
     const uintptr_t bits = reinterpret_cast<uintptr_t>(s.a) | reinterpret_cast<uintptr_t>(s.b) | reinterpret_cast<uintptr_t>(s.c);
@@ -321,46 +552,89 @@ static int smm_jit_variant(const SmmBatch& s)
         && (s.sa == (long long)s.m * s.k || 0 == s.sa) && (s.sb == (long long)s.k * s.n || 0 == s.sb)
         && (s.sc == (long long)s.m * s.n || 0 == s.sc);
   }
-  if (!wide) v |= SMM_JIT_SCALAR;
-  return v;
+  return wide ? 0 : SMM_JIT_SCALAR;
 }
 
-int launch_smm_jit(const SmmBatch& s, void* stream, const char** name)
-{ // returns -1 when no specialised kernel is available
-  const SmmKey key = { s.typesize, s.m, s.n, s.k, s.flags & (LIBXSMM_GEMM_FLAG_BETA_0 | LIBXSMM_GEMM_FLAG_TRANS_B), smm_jit_variant(s) };
-  JitKernel* k = nullptr;
-  {
-    std::lock_guard<std::mutex> guard(g_smm_lock);
-    auto it = g_smm_cache.find(key);
-    if (it != g_smm_cache.end()) k = it->second;
-    else {
-      std::string log;
-      k = jit_compile(gen_smm_source(key.typesize, key.m, key.n, key.k, key.flags, key.variant), "xsmm_smm_op", &log);
-      if (nullptr == k && 0 != verbosity()) fprintf(stderr, "LIBXSMM WARNING: SMM JIT failed (%s); using the pre-compiled kernel\n", log.c_str());
-      g_smm_cache.emplace(key, k);
-    }
-  }
+static JitKernel* smm_jit_get(const SmmKey& key)
+{
+  std::lock_guard<std::mutex> guard(g_smm_lock);
+  auto it = g_smm_cache.find(key);
+  if (it != g_smm_cache.end()) return it->second;
+  std::string log;
+  JitKernel* const k = jit_compile(gen_smm_source(key.typesize, key.m, key.n, key.k, key.flags, key.variant), "xsmm_smm_op", &log);
+  if (nullptr == k && 0 != verbosity()) fprintf(stderr, "LIBXSMM WARNING: SMM JIT failed (%s); using the pre-compiled kernel\n", log.c_str());
+  g_smm_cache.emplace(key, k);
+  return k;
+}
+
+// one launch of one flavour; -1 when the kernel is not available
+static int smm_jit_launch_variant(const SmmBatch& s, int variant, void* stream)
+{
+  const SmmKey key = { s.typesize, s.m, s.n, s.k, s.flags & (LIBXSMM_GEMM_FLAG_BETA_0 | LIBXSMM_GEMM_FLAG_TRANS_B), variant };
+  JitKernel* const k = smm_jit_get(key);
   if (nullptr == k) return -1;
   struct { const char* a; const char* b; char* c; const char* ia; const char* ib; const char* ic; long long sa, sb, sc; int index_base, index_stride, mode; const int* flags; } ad;
   ad.a = (const char*)s.a; ad.b = (const char*)s.b; ad.c = (char*)s.c; ad.ia = (const char*)s.ia; ad.ib = (const char*)s.ib; ad.ic = (const char*)s.ic;
   ad.sa = s.sa; ad.sb = s.sb; ad.sc = s.sc; ad.index_base = s.index_base; ad.index_stride = s.index_stride; ad.mode = s.mode;
   ad.flags = (SYNC_DEVICE == s.sync ? s.devflags : nullptr);
   long long batch = s.batch;
+  static const int bpc_env = []() { const char* e = getenv("XSMM_SMMJIT_BPC"); return (nullptr != e && 0 != *e) ? atoi(e) : 0; }();
+  if (0 != (variant & SMM_JIT_WGRUNS)) { // work-groups of 256 threads, dealt chunks of 64 items
+    const size_t buf = smm_jit_wg_buf(s.typesize, s.m, s.n, s.k, s.flags);
+    const size_t lds = (2 * buf <= 65536 ? 2 : 1) * buf;
+    long long per_cu = (long long)((160 * 1024) / (lds ? lds : 1));
+    if (per_cu > 4) per_cu = 4;
+    if (per_cu < 1) per_cu = 1;
+    if (0 < bpc_env) per_cu = bpc_env;
+    long long blocks = (batch + 63) / 64;
+    if (blocks > 256 * per_cu) blocks = 256 * per_cu;
+    if (blocks < 1) blocks = 1;
+    return jit_launch_raw(k, (unsigned)blocks, 256u, &ad, sizeof(ad), &batch, stream);
+  }
   const int waves = smm_jit_waves(s.typesize, s.m, s.n, s.k, s.flags);
   const size_t lds = (size_t)waves * smm_jit_wave_lds(s.typesize, s.m, s.n, s.k, s.flags);
   long long per_cu = (long long)((160 * 1024) / (lds ? lds : 1));
   if (per_cu * waves > 16) per_cu = 16 / waves; // the streaming rate peaks around 12-16 waves per CU
   if (per_cu < 1) per_cu = 1;
-  static const int bpc_env = []() { const char* e = getenv("XSMM_SMMJIT_BPC"); return (nullptr != e && 0 != *e) ? atoi(e) : 0; }();
   if (0 < bpc_env) per_cu = bpc_env;
   // run form: a wave scans chunks of 64 items for run heads, so the grid is sized by chunks
-  const long long units = (0 != (key.variant & SMM_JIT_RUNS)) ? ((batch + 63) / 64) : batch;
+  const long long units = (0 != (variant & SMM_JIT_RUNS)) ? ((batch + 63) / 64) : batch;
   long long blocks = (units + waves - 1) / waves;
   if (blocks > 256 * per_cu) blocks = 256 * per_cu;
   if (blocks < 1) blocks = 1;
-  *name = (0 != (key.variant & SMM_JIT_RUNS)) ? ((8 == s.typesize) ? "smm_f64_jit_shape_runs" : "smm_f32_jit_shape_runs")
-                                                : ((8 == s.typesize) ? "smm_f64_jit_shape" : "smm_f32_jit_shape");
   return jit_launch_raw(k, (unsigned)blocks, 64u * (unsigned)waves, &ad, sizeof(ad), &batch, stream);
+}
+
+int launch_smm_jit(const SmmBatch& s, void* stream, const char** name)
+{ // returns -1 when no specialised kernel is available
+  const int width = smm_jit_width_variant(s);
+  const bool f64 = (8 == s.typesize);
+  if (SYNC_NONE == s.sync) { // every item owns its C
+    *name = f64 ? "smm_f64_jit_shape" : "smm_f32_jit_shape";
+    return smm_jit_launch_variant(s, width, stream);
+  }
+  static const int wg_env = []() { const char* e = getenv("XSMM_SMMJIT_WG"); return (nullptr != e && 0 != *e) ? atoi(e) : 1; }(); // developer knob
+  // the work-group form pays off once a product's operands are large (measured on CP2K stacks: 32^3 f64 yes, 23^3 no)
+  const bool wg_fits = (0 != wg_env && smm_jit_wg_buf(s.typesize, s.m, s.n, s.k, s.flags) <= 65536
+                     && (2 == wg_env || (size_t)s.typesize * ((size_t)s.m * s.k + (size_t)s.k * s.n) >= 12288));
+  if (SYNC_RUNS == s.sync) { // the host knows that C repeats in runs (one C for the whole batch, batch-reduce): long runs
+    if (wg_fits) {
+      const int e = smm_jit_launch_variant(s, width | SMM_JIT_WGRUNS, stream);
+      if (0 <= e) { *name = f64 ? "smm_f64_jit_shape_wgruns" : "smm_f32_jit_shape_wgruns"; return e; }
+    }
+    *name = f64 ? "smm_f64_jit_shape_runs" : "smm_f32_jit_shape_runs";
+    return smm_jit_launch_variant(s, width | SMM_JIT_RUNS, stream);
+  }
+  // SYNC_DEVICE: both run forms are launched; each reads the device-side verdict (average run length) and one of them works
+  *name = f64 ? "smm_f64_jit_shape_runs" : "smm_f32_jit_shape_runs";
+  int e = smm_jit_launch_variant(s, width | SMM_JIT_RUNS | (wg_fits ? SMM_JIT_HASWG : 0), stream);
+  if (0 == e && wg_fits) {
+    e = smm_jit_launch_variant(s, width | SMM_JIT_WGRUNS, stream);
+    if (e < 0) { // the companion did not compile: fall back to the wave form alone (it must then take long runs as well)
+      e = smm_jit_launch_variant(s, width | SMM_JIT_RUNS, stream);
+    }
+  }
+  return e;
 }
 
 } // namespace xsmm

@@ -22,14 +22,15 @@ def test_generated_sources_compile_for_gfx950(xs):
         for (m, n, k) in [(23, 23, 23), (13, 23, 32), (32, 32, 64), (1, 1, 1)]:
             for beta, flags in ((1.0, 0), (0.0, 0), (1.0, xs.FLAG_TRANS_B)):
                 blob, d = xs.descriptor(prec, m, n, k, beta=beta, flags=flags)
-                for variant in ((0, 1, 3) if beta == 1.0 else (0, 1)):  # wide / element-wide / element-wide + runs
+                # wide / element-wide / + wave-per-run / + work-group-per-run / wave-per-run that leaves long runs to the latter
+                for variant in ((0, 1, 3, 5, 11) if beta == 1.0 else (0, 1)):
                     rc = L.libxsmm_amd_smm_kernel_source(d, variant, buf, len(buf), 1)
                     if rc == -1:
                         pytest.skip("libhiprtc is not available here")
                     assert rc == 0, (prec, m, n, k, beta, flags, variant)
                     src = buf.value.decode()
                     assert "#define XM %d" % m in src and "xsmm_smm_op" in src
-                    assert "#define XRUNS %d" % (variant >> 1) in src
+                    assert "#define XRUNS %d" % (2 if variant & 4 else (variant >> 1) & 1) in src
     # fixed-sparsity operator
     rng = np.random.default_rng(0)
     M, K = 35, 35

@@ -21,25 +21,35 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ bool aligned16(const void* p) { return 0 == (reinterpret_cast<uintptr_t>(p) & 15); }
 
-template<bool NT> __device__ __forceinline__ f32x4 ld4(const float* p, bool al)
+// GLB: operand accesses in the global address space. The addresses come out of a run-time choice between three
+// addressing modes (one of which loads the pointer), so left to the compiler every access is a FLAT instruction (counts on
+// lgkmcnt as well as vmcnt). XSMM_SMM32_VARIANT=1 selects GLB for same-process A/B runs (tools/sweep_smm32.py).
+template<bool GLB> struct Space { typedef float* ptr; typedef const float* cptr; typedef f32x4* vptr; typedef const f32x4* cvptr; };
+template<> struct Space<true> {
+  typedef __attribute__((address_space(1))) float* ptr; typedef const __attribute__((address_space(1))) float* cptr;
+  typedef __attribute__((address_space(1))) f32x4* vptr; typedef const __attribute__((address_space(1))) f32x4* cvptr;
+};
+template<bool NT, bool GLB> __device__ __forceinline__ f32x4 ld4(const float* p, bool al)
 {
-  if (al) return NT ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p)) : *reinterpret_cast<const f32x4*>(p);
-  return f32x4{ p[0], p[1], p[2], p[3] }; // operands that are only element-aligned (arbitrary index arrays)
+  const typename Space<GLB>::cptr g = (typename Space<GLB>::cptr)p;
+  if (al) return NT ? __builtin_nontemporal_load((typename Space<GLB>::cvptr)g) : *(typename Space<GLB>::cvptr)g;
+  return f32x4{ g[0], g[1], g[2], g[3] }; // operands that are only element-aligned (arbitrary index arrays)
 }
-template<bool NT> __device__ __forceinline__ void st4(float* p, bool al, f32x4 v)
+template<bool NT, bool GLB> __device__ __forceinline__ void st4(float* p, bool al, f32x4 v)
 {
-  if (al) { if (NT) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p)); else *reinterpret_cast<f32x4*>(p) = v; }
-  else { p[0] = v[0]; p[1] = v[1]; p[2] = v[2]; p[3] = v[3]; }
+  const typename Space<GLB>::ptr g = (typename Space<GLB>::ptr)p;
+  if (al) { if (NT) __builtin_nontemporal_store(v, (typename Space<GLB>::vptr)g); else *(typename Space<GLB>::vptr)g = v; }
+  else { g[0] = v[0]; g[1] = v[1]; g[2] = v[2]; g[3] = v[3]; }
 }
-template<bool NT> __device__ __forceinline__ float ld1(const float* p) { return NT ? __builtin_nontemporal_load(p) : *p; }
-template<bool NT> __device__ __forceinline__ void st1(float* p, float v) { if (NT) __builtin_nontemporal_store(v, p); else *p = v; }
+template<bool NT, bool GLB> __device__ __forceinline__ float ld1(const float* p) { const typename Space<GLB>::cptr g = (typename Space<GLB>::cptr)p; return NT ? __builtin_nontemporal_load(g) : *g; }
+template<bool NT, bool GLB> __device__ __forceinline__ void st1(float* p, float v) { const typename Space<GLB>::ptr g = (typename Space<GLB>::ptr)p; if (NT) __builtin_nontemporal_store(v, g); else *g = v; }
 
 // 4 x float4 per lane covering a tight 32x32 fp32 matrix: chunk index c = 64*j + lane (16-byte chunks)
-template<bool NT> __device__ __forceinline__ void load_mat32(const float* p, int lane, f32x4 (&r)[4])
+template<bool NT, bool GLB> __device__ __forceinline__ void load_mat32(const float* p, int lane, f32x4 (&r)[4])
 {
   const bool al = aligned16(p);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) r[j] = ld4<NT>(p + 4 * (64 * j + lane), al);
+  for (int j = 0; j < 4; ++j) r[j] = ld4<NT, GLB>(p + 4 * (64 * j + lane), al);
 }
 
 // A linear, B as 16-byte chunks (n, q = k/4) at position n*8 + (q ^ key(n)); key spreads the rows a wave reads
@@ -58,7 +68,7 @@ template<int KEYSHIFT> __device__ __forceinline__ void park_ab(float* As, float*
 // ---------------------------------------------------------------------------------------------------------------
 // scalar-FMA variant. Lane (tx = lane & 7, ty = lane >> 3) owns C rows 4tx..4tx+3 of columns 4ty..4ty+3.
 // ---------------------------------------------------------------------------------------------------------------
-template<bool BETA0, bool NT>
+template<bool BETA0, bool NT, bool GLB>
 __global__ __launch_bounds__(256, 4)
 void smm32_f32_fma_kernel(DevAddr ad, long long batch)
 {
@@ -71,13 +81,13 @@ void smm32_f32_fma_kernel(DevAddr ad, long long batch)
   if (w >= batch) return;
 
   f32x4 ra[4], rb[4], rc[4];
-  load_mat32<NT>(addr_a<float>(ad, w), lane, ra);
-  load_mat32<NT>(addr_b<float>(ad, w), lane, rb);
+  load_mat32<NT, GLB>(addr_a<float>(ad, w), lane, ra);
+  load_mat32<NT, GLB>(addr_b<float>(ad, w), lane, rb);
   if (!BETA0) {
     const float* const pc = addr_c<float>(ad, w) + 4 * ty * 32 + 4 * tx;
     const bool al = aligned16(pc);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) rc[j] = ld4<NT>(pc + j * 32, al);
+    for (int j = 0; j < 4; ++j) rc[j] = ld4<NT, GLB>(pc + j * 32, al);
   }
   for (long long item = w; item < batch; item += W) {
     float* const pc = addr_c<float>(ad, item) + 4 * ty * 32 + 4 * tx;
@@ -87,13 +97,13 @@ void smm32_f32_fma_kernel(DevAddr ad, long long batch)
     for (int j = 0; j < 4; ++j) acc[j] = BETA0 ? f32x4{ 0.f, 0.f, 0.f, 0.f } : rc[j];
     const long long next = item + W; // issue the next problem's loads before computing this one
     if (next < batch) {
-      load_mat32<NT>(addr_a<float>(ad, next), lane, ra);
-      load_mat32<NT>(addr_b<float>(ad, next), lane, rb);
+      load_mat32<NT, GLB>(addr_a<float>(ad, next), lane, ra);
+      load_mat32<NT, GLB>(addr_b<float>(ad, next), lane, rb);
       if (!BETA0) {
         const float* const pn = addr_c<float>(ad, next) + 4 * ty * 32 + 4 * tx;
         const bool al = aligned16(pn);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) rc[j] = ld4<NT>(pn + j * 32, al);
+        for (int j = 0; j < 4; ++j) rc[j] = ld4<NT, GLB>(pn + j * 32, al);
       }
     }
     wave_lds_sync();
@@ -115,20 +125,19 @@ void smm32_f32_fma_kernel(DevAddr ad, long long batch)
     }
     const bool al = aligned16(pc);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) st4<NT>(pc + j * 32, al, acc[j]);
+    for (int j = 0; j < 4; ++j) st4<NT, GLB>(pc + j * 32, al, acc[j]);
     wave_lds_sync();
   }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// MFMA variants with v_mfma_f32_32x32x2_f32; per instruction lane l supplies k = 16*(l>>5) + s for both operands:
+// MFMA variant with v_mfma_f32_32x32x2_f32; per instruction lane l supplies k = 16*(l>>5) + s for both operands:
 //   A[m = l&31][k] from the linear LDS image, B[k][n = l&31] as four 16-byte reads of the swizzled image.
-// CV4 == false: D[i=n][j=m] (B as a-operand). Register r of lane l is C[n = (r&3)+8(r>>2)+4(l>>5)][m = l&31]: every C
-//               access is a dword per lane, two full 128-byte rows per wave instruction.
-// CV4 == true : D[i=m][j=n] (A as a-operand). Registers 4g..4g+3 of lane l are rows m = 8g+4(l>>5)+{0..3} of column
-//               n = l&31: C moves as four 16-byte accesses per lane.
+// D[i=n][j=m] (B as a-operand): register r of lane l is C[n = (r&3)+8(r>>2)+4(l>>5)][m = l&31], so every C access is a
+// dword per lane, two full 128-byte rows per wave instruction. (The transposed operand order, where C moves as four
+// 16-byte pieces per lane, was measured 15-40 % slower and has been removed.)
 // ---------------------------------------------------------------------------------------------------------------
-template<bool BETA0, bool NT, bool CV4>
+template<bool BETA0, bool NT, bool GLB>
 __global__ __launch_bounds__(256, 4)
 void smm32_f32_mfma_kernel(DevAddr ad, long long batch)
 {
@@ -139,23 +148,16 @@ void smm32_f32_mfma_kernel(DevAddr ad, long long batch)
   float* const Bs = lds[wave] + 1024;
   const long long w = (long long)blockIdx.x * 4 + wave, W = (long long)gridDim.x * 4;
   if (w >= batch) return;
-  const int coff = CV4 ? (lo * 32 + 4 * hi) : (4 * hi * 32 + lo); // lane's first C element
+  const int coff = 4 * hi * 32 + lo; // lane's first C element
 
   f32x4 ra[4], rb[4];
   float rc[16];
   auto load_c = [&](const float* pc) {
-    if (CV4) {
-      const bool al = aligned16(pc);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) { const f32x4 v = ld4<NT>(pc + 8 * g, al); rc[4 * g] = v[0]; rc[4 * g + 1] = v[1]; rc[4 * g + 2] = v[2]; rc[4 * g + 3] = v[3]; }
-    }
-    else {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) rc[r] = ld1<NT>(pc + ((r & 3) + 8 * (r >> 2)) * 32);
-    }
+    for (int r = 0; r < 16; ++r) rc[r] = ld1<NT, GLB>(pc + ((r & 3) + 8 * (r >> 2)) * 32);
   };
-  load_mat32<NT>(addr_a<float>(ad, w), lane, ra);
-  load_mat32<NT>(addr_b<float>(ad, w), lane, rb);
+  load_mat32<NT, GLB>(addr_a<float>(ad, w), lane, ra);
+  load_mat32<NT, GLB>(addr_b<float>(ad, w), lane, rb);
   if (!BETA0) load_c(addr_c<float>(ad, w) + coff);
   for (long long item = w; item < batch; item += W) {
     float* const pc = addr_c<float>(ad, item) + coff;
@@ -165,8 +167,8 @@ void smm32_f32_mfma_kernel(DevAddr ad, long long batch)
     for (int r = 0; r < 16; ++r) acc[r] = BETA0 ? 0.f : rc[r];
     const long long next = item + W;
     if (next < batch) {
-      load_mat32<NT>(addr_a<float>(ad, next), lane, ra);
-      load_mat32<NT>(addr_b<float>(ad, next), lane, rb);
+      load_mat32<NT, GLB>(addr_a<float>(ad, next), lane, ra);
+      load_mat32<NT, GLB>(addr_b<float>(ad, next), lane, rb);
       if (!BETA0) load_c(addr_c<float>(ad, next) + coff);
     }
     wave_lds_sync();
@@ -176,18 +178,10 @@ void smm32_f32_mfma_kernel(DevAddr ad, long long batch)
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
       const float av = As[(16 * hi + s) * 32 + lo]; // A[m = lo][k = 16*hi + s]
-      if (CV4) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bt[s >> 2][s & 3], acc, 0, 0, 0);
-      else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bt[s >> 2][s & 3], av, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bt[s >> 2][s & 3], av, acc, 0, 0, 0);
     }
-    if (CV4) {
-      const bool al = aligned16(pc);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) st4<NT>(pc + 8 * g, al, f32x4{ acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3] });
-    }
-    else {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) st1<NT>(pc + ((r & 3) + 8 * (r >> 2)) * 32, acc[r]);
-    }
+    for (int r = 0; r < 16; ++r) st1<NT, GLB>(pc + ((r & 3) + 8 * (r >> 2)) * 32, acc[r]);
     wave_lds_sync();
   }
 }
@@ -236,43 +230,41 @@ bool is_smm32_f32(const SmmBatch& s)
       && 0 == (s.flags & LIBXSMM_GEMM_FLAG_TRANS_B) && SYNC_NONE == s.sync && 0 == s.general;
 }
 
-template<bool NT>
-int launch_smm32(const SmmBatch& s, hipStream_t st, unsigned blocks, int variant, const char** name)
+template<bool NT, bool GLB>
+int launch_smm32(const SmmBatch& s, hipStream_t st, unsigned blocks, const char** name)
 {
   const bool beta0 = (0 != (s.flags & LIBXSMM_GEMM_FLAG_BETA_0));
   const DevAddr ad = make_addr(s);
   if (0 == s.use_mfma) {
     *name = "smm_f32_32x32x32_fma";
-    if (beta0) hipLaunchKernelGGL((smm32_f32_fma_kernel<true, NT>), dim3(blocks), dim3(256), 0, st, ad, s.batch);
-    else hipLaunchKernelGGL((smm32_f32_fma_kernel<false, NT>), dim3(blocks), dim3(256), 0, st, ad, s.batch);
-  }
-  else if (1 == variant) {
-    *name = "smm_f32_32x32x32_mfma_cv4";
-    if (beta0) hipLaunchKernelGGL((smm32_f32_mfma_kernel<true, NT, true>), dim3(blocks), dim3(256), 0, st, ad, s.batch);
-    else hipLaunchKernelGGL((smm32_f32_mfma_kernel<false, NT, true>), dim3(blocks), dim3(256), 0, st, ad, s.batch);
+    if (beta0) hipLaunchKernelGGL((smm32_f32_fma_kernel<true, NT, GLB>), dim3(blocks), dim3(256), 0, st, ad, s.batch);
+    else hipLaunchKernelGGL((smm32_f32_fma_kernel<false, NT, GLB>), dim3(blocks), dim3(256), 0, st, ad, s.batch);
   }
   else {
     *name = "smm_f32_32x32x32_mfma";
-    if (beta0) hipLaunchKernelGGL((smm32_f32_mfma_kernel<true, NT, false>), dim3(blocks), dim3(256), 0, st, ad, s.batch);
-    else hipLaunchKernelGGL((smm32_f32_mfma_kernel<false, NT, false>), dim3(blocks), dim3(256), 0, st, ad, s.batch);
+    if (beta0) hipLaunchKernelGGL((smm32_f32_mfma_kernel<true, NT, GLB>), dim3(blocks), dim3(256), 0, st, ad, s.batch);
+    else hipLaunchKernelGGL((smm32_f32_mfma_kernel<false, NT, GLB>), dim3(blocks), dim3(256), 0, st, ad, s.batch);
   }
   return (int)hipGetLastError();
 }
 
 } // namespace
 
-// returns -1 when no specialised kernel applies (caller falls back to the generic family)
 int launch_smm_special(const SmmBatch& s, void* stream, const char** name)
 {
   hipStream_t st = (hipStream_t)stream;
   if (is_smm32_f32(s)) {
     // tuning knobs (developer use; re-read on every launch so that one process can sweep them):
-    // work-groups per CU of the persistent grid, MFMA kernel variant, non-temporal hint
-    const int bpc = env_int("XSMM_SMM32_BPC", 3), variant = env_int("XSMM_SMM32_VARIANT", 0), nt = env_int("XSMM_SMM32_NT", 1);
+    // work-groups per CU of the persistent grid, address space of the operand accesses (1 = global), non-temporal hint
+    // Defaults from same-process sweeps (profiles/r1_smm32_variant_sweep.txt): 3 work-groups per CU for both kernels; the
+    // MFMA kernel is 4 % faster with generic pointers (FLAT accesses), the scalar-FMA kernel 10 % faster with global ones.
+    const int bpc = env_int("XSMM_SMM32_BPC", 3), nt = env_int("XSMM_SMM32_NT", 1);
+    const int variant = env_int("XSMM_SMM32_VARIANT", 0 != s.use_mfma ? 0 : 1);
     long long blocks = (s.batch + 3) / 4;
     const long long resident = 256LL * (bpc > 0 ? bpc : 3);
     if (blocks > resident) blocks = resident;
-    return (0 != nt) ? launch_smm32<true>(s, st, (unsigned)blocks, variant, name) : launch_smm32<false>(s, st, (unsigned)blocks, variant, name);
+    if (1 == variant) return (0 != nt) ? launch_smm32<true, true>(s, st, (unsigned)blocks, name) : launch_smm32<false, true>(s, st, (unsigned)blocks, name);
+    return (0 != nt) ? launch_smm32<true, false>(s, st, (unsigned)blocks, name) : launch_smm32<false, false>(s, st, (unsigned)blocks, name);
   }
   return -1;
 }

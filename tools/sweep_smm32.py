@@ -22,14 +22,13 @@ c = torch.rand(B * 1024, device="cuda") - 0.5
 blob, desc = xs.descriptor(xs.F32, M, N, K, M, K, M, 1.0, 1.0)
 blob0, desc0 = xs.descriptor(xs.F32, M, N, K, M, K, M, 1.0, 0.0)
 
-configs = []
-for bpc in (2, 3, 4, 5):
+configs = []  # variant 0: generic pointers (FLAT accesses), variant 1: global address space
+for bpc in (2, 3, 4):
     for variant in (0, 1):
-        for nt in (0, 1):
-            configs.append(("mfma v%d nt%d bpc%d" % (variant, nt, bpc), dict(XSMM_SMM32_BPC=bpc, XSMM_SMM32_VARIANT=variant, XSMM_SMM32_NT=nt), 1, desc))
-    for nt in (0, 1):
-        configs.append(("fma     nt%d bpc%d" % (nt, bpc), dict(XSMM_SMM32_BPC=bpc, XSMM_SMM32_NT=nt), 0, desc))
-configs.append(("mfma v0 nt1 bpc3 beta0", dict(XSMM_SMM32_BPC=3, XSMM_SMM32_VARIANT=0, XSMM_SMM32_NT=1), 1, desc0))
+        for nt in ((0, 1) if bpc == 3 else (1,)):
+            configs.append(("mfma %s nt%d bpc%d" % ("global" if variant else "flat  ", nt, bpc), dict(XSMM_SMM32_BPC=bpc, XSMM_SMM32_VARIANT=variant, XSMM_SMM32_NT=nt), 1, desc))
+            configs.append(("fma  %s nt%d bpc%d" % ("global" if variant else "flat  ", nt, bpc), dict(XSMM_SMM32_BPC=bpc, XSMM_SMM32_VARIANT=variant, XSMM_SMM32_NT=nt), 0, desc))
+configs.append(("mfma flat   nt1 bpc3 beta0", dict(XSMM_SMM32_BPC=3, XSMM_SMM32_VARIANT=0, XSMM_SMM32_NT=1), 1, desc0))
 for bpc in (2, 3, 4, 6):
     configs.append(("stream probe bpc%d" % bpc, dict(XSMM_STREAM_BPC=bpc), -1, None))
 

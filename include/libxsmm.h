@@ -339,6 +339,20 @@ LIBXSMM_API libxsmm_dmmfunction libxsmm_create_dcsr_reg(const libxsmm_gemm_descr
   const unsigned int* row_ptr, const unsigned int* column_idx, const double* values);
 LIBXSMM_API libxsmm_smmfunction libxsmm_create_scsr_reg(const libxsmm_gemm_descriptor* descriptor,
   const unsigned int* row_ptr, const unsigned int* column_idx, const float* values);
+/* SOA kernels for fused runs (EDGE/SeisSol; src/template/libxsmm.h:386-414, src/libxsmm_main.c:2423-2520): sparse or dense
+ * operator times operands stored [row][col][v] with the run index v innermost; v = 8 (fp64) / 16 (fp32), the widths of
+ * the reference's AVX-512 kernels (libxsmm_amd_soa_width). Caller-owned: release with libxsmm_release_kernel.
+ *   xcsr_soa, lda == 0: C[m][n][v] (+)= A_csr(m,k) * B[k][n][v]      call kernel(values of A, B, C); rows without entries
+ *                                                                    are not touched (also for beta == 0)
+ *   xcsr_soa/xcsc_soa, ldb == 0: C[m][n][v] (+)= A[m][k][v] * B(k,n) call kernel(A, values of B, C)
+ *   rm_ac_soa: C[m][n][v] (+)= A[m][k][v] * B[k*ldb+n]               rm_bc_soa: C[m][n][v] (+)= A[m*lda+k] * B[k][n][v]
+ * One call is one small product; many products that share the operator go through libxsmm_amd_kernel_execute_batch. */
+LIBXSMM_API libxsmm_xmmfunction libxsmm_create_xcsr_soa(const libxsmm_gemm_descriptor* descriptor,
+  const unsigned int* row_ptr, const unsigned int* column_idx, const void* values);
+LIBXSMM_API libxsmm_xmmfunction libxsmm_create_xcsc_soa(const libxsmm_gemm_descriptor* descriptor,
+  const unsigned int* column_ptr, const unsigned int* row_idx, const void* values);
+LIBXSMM_API libxsmm_xmmfunction libxsmm_create_rm_ac_soa(const libxsmm_gemm_descriptor* descriptor);
+LIBXSMM_API libxsmm_xmmfunction libxsmm_create_rm_bc_soa(const libxsmm_gemm_descriptor* descriptor);
 LIBXSMM_API void libxsmm_release_kernel(const void* jit_kernel);   /* src/template/libxsmm.h:325 */
 
 /* introspection (src/template/libxsmm.h:107-121) */
@@ -559,6 +573,11 @@ LIBXSMM_API void libxsmm_generator_spgemm_csr_kernel(libxsmm_generated_code* io_
   const char* i_arch, const unsigned int* i_row_idx, const unsigned int* i_column_idx, const double* i_values);
 LIBXSMM_API void libxsmm_generator_spgemm_csr_reg_kernel(libxsmm_generated_code* io_generated_code, const libxsmm_gemm_descriptor* i_xgemm_desc,
   const char* i_arch, const unsigned int* i_row_idx, const unsigned int* i_column_idx, const double* i_values);
+/* SOA forms (operands [row][col][v], v = libxsmm_amd_soa_width innermost): CSR with A or B sparse, CSC with B sparse */
+LIBXSMM_API void libxsmm_generator_spgemm_csr_soa_kernel(libxsmm_generated_code* io_generated_code, const libxsmm_gemm_descriptor* i_xgemm_desc,
+  const char* i_arch, const unsigned int* i_row_idx, const unsigned int* i_column_idx, const void* i_values);
+LIBXSMM_API void libxsmm_generator_spgemm_csc_soa_kernel(libxsmm_generated_code* io_generated_code, const libxsmm_gemm_descriptor* i_xgemm_desc,
+  const char* i_arch, const unsigned int* i_row_idx, const unsigned int* i_column_idx, const void* i_values);
 
 typedef struct libxsmm_matdiff_info { /* include/libxsmm_math.h:40-55 */
   double norm1_abs, norm1_rel;

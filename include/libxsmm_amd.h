@@ -111,4 +111,12 @@ LIBXSMM_API void libxsmm_amd_spgemm_destroy(const libxsmm_amd_spgemm* handle);
 LIBXSMM_API int libxsmm_amd_spgemm_source(const libxsmm_gemm_descriptor* descriptor, int is_csr, const unsigned int* row_idx,
   const unsigned int* column_idx, int fma, char* buffer, size_t buffer_size, int compile);
 
+/** SOA width v of the libxsmm_create_*_soa kernels for a precision (8 for fp64, 16 for fp32; 0 if unsupported). */
+LIBXSMM_API int libxsmm_amd_soa_width(libxsmm_gemm_precision precision);
+/** Batch form of a kernel made by libxsmm_create_{xcsr,xcsc,rm_ac,rm_bc}_soa: `batch` products that share the operator
+ *  (the sparse values / the plain dense matrix). a, b, c as in the kernel call; the SOA input and C advance by
+ *  stride_dense / stride_c elements per item. */
+LIBXSMM_API int libxsmm_amd_kernel_execute_batch(const void* kernel, const void* a, const void* b, void* c,
+  long long stride_dense, long long stride_c, long long batch);
+
 #endif /* LIBXSMM_AMD_H */

@@ -210,6 +210,14 @@ def _declare(L):
     sig("libxsmm_generator_spgemm", None, C.c_char_p, C.c_char_p, vp, C.c_char_p, C.c_char_p, i)
     for nm in ("csr", "csc", "csr_reg"):
         sig("libxsmm_generator_spgemm_%s_kernel" % nm, None, gc, vp, C.c_char_p, vp, vp, vp)
+    for nm in ("csr_soa", "csc_soa"):
+        sig("libxsmm_generator_spgemm_%s_kernel" % nm, None, gc, vp, C.c_char_p, vp, vp, vp)
+    sig("libxsmm_create_xcsr_soa", vp, vp, vp, vp, vp)
+    sig("libxsmm_create_xcsc_soa", vp, vp, vp, vp, vp)
+    sig("libxsmm_create_rm_ac_soa", vp, vp)
+    sig("libxsmm_create_rm_bc_soa", vp, vp)
+    sig("libxsmm_amd_soa_width", i, i)
+    sig("libxsmm_amd_kernel_execute_batch", i, vp, vp, vp, vp, ll, ll, ll)
     sig("libxsmm_amd_spgemm_create", vp, vp, i, vp, vp, i)
     sig("libxsmm_amd_spgemm_execute_batch", i, vp, vp, vp, vp, ll, ll, ll)
     sig("libxsmm_amd_spgemm_destroy", None, vp)

@@ -310,6 +310,9 @@ void call_kernel(Kernel* k, const void* a, const void* b, void* c, const void* x
     // one run: every product lands in the same C (stride_c == NULL), accumulated in batch order
     (void)batch_execute(s, 0, 0, &ptrsize, &ptrsize, nullptr, a, b, &cc, 0, (long long)count, false);
   }
+  else if (KC_TEXT == k->kclass) { // kernel(a, b, c) of the SOA family: one product (batch form: libxsmm_amd_kernel_execute_batch)
+    (void)text_kernel_execute(k->text, a, b, c, 0, 0, 1);
+  }
   else if (KC_CSR_REG == k->kclass) { // kernel(ignored, B, C) -- reference fsspmdm call site src/libxsmm_fsspmdm.c:267
     if (!device_ready()) { fail_no_device("a csr_reg kernel"); return; }
     const int ts = (LIBXSMM_GEMM_PRECISION_F64 == LIBXSMM_GETENUM_INP(k->desc.datatype)) ? 8 : 4;
@@ -345,7 +348,7 @@ LIBXSMM_API int libxsmm_mmbatch_kernel(libxsmm_xmmfunction kernel, libxsmm_blasi
 { // reference src/libxsmm_gemm.c:1315-1324: task `tid` of `ntasks` owns the slice [tid*tasksize, min(...))
   (void)itypesize; (void)otypesize; (void)flags;
   Kernel* const k = kernel_from_pointer(reinterpret_cast<const void*>(kernel.xmm));
-  if (nullptr == k || KC_CSR_REG == k->kclass || nullptr == a || nullptr == b || nullptr == c || ntasks < 1 || tid < 0 || tid >= ntasks) return EXIT_FAILURE;
+  if (nullptr == k || KC_CSR_REG == k->kclass || KC_TEXT == k->kclass || nullptr == a || nullptr == b || nullptr == c || ntasks < 1 || tid < 0 || tid >= ntasks) return EXIT_FAILURE;
   const long long size = (batchsize < 0 ? -(long long)batchsize : batchsize);
   const long long tasksize = (size + ntasks - 1) / ntasks;
   const long long begin = (long long)tid * tasksize, span = begin + tasksize, end = (span < size ? span : size);

@@ -99,9 +99,10 @@ unsigned read_coordinate_file(const char* path, bool csr, std::vector<unsigned>&
 }
 
 // ---- kernel text -------------------------------------------------------------------------------------------------------
-enum SpKind { SP_CSR_ASPARSE = 0, SP_CSC_BSPARSE = 1, SP_CSC_ASPARSE = 2 };
+enum SpKind { SP_CSR_ASPARSE = 0, SP_CSC_BSPARSE = 1, SP_CSC_ASPARSE = 2,
+              SP_SOA_ASPARSE = 3, SP_SOA_BSPARSE = 4, SP_SOA_RM_AC = 5, SP_SOA_RM_BC = 6 }; // SOA: [row][col][v] operands
 
-struct SpShape { int typesize, m, n, k, lda, ldb, ldc, beta0; };
+struct SpShape { int typesize, m, n, k, lda, ldb, ldc, beta0, v; }; // v: SOA width (0: plain matrices)
 
 const char* tname(int typesize) { return 8 == typesize ? "double" : "float"; }
 
@@ -111,8 +112,69 @@ int sp_lanes(SpKind kind, const SpShape& s)
   switch (kind) {
     case SP_CSR_ASPARSE: return (0 != s.beta0 ? s.ldc : s.n); // beta == 0 clears ldc (not n) entries per row (:79)
     case SP_CSC_BSPARSE: return s.m;
-    default: return s.n;
+    case SP_CSC_ASPARSE: return s.n;
+    case SP_SOA_ASPARSE: case SP_SOA_RM_BC: return s.n * s.v; // one thread per (column, run)
+    default: return s.m * s.v;                                 // SP_SOA_BSPARSE, SP_SOA_RM_AC: one thread per (row, run)
   }
+}
+
+// ---- SOA kernels (EDGE/SeisSol fused runs): element-wise in the innermost index v ---------------------------------------
+// reference: src/generator_spgemm_csr_asparse_soa.c:212-330 (rows of A without non-zeros are left alone),
+// src/generator_spgemm_csc_bsparse_soa.c:177-420 and src/generator_spgemm_csr_bsparse_soa.c:160-330 (every C column is
+// loaded or zeroed and stored; per k the first pattern entry (k, n) contributes), src/generator_gemm_rm_{ac,bc}_soa.c.
+// All of them: register accumulator seeded with C (or 0), fused multiply-add, k ascending.
+struct SoaEntry { unsigned k, p; }; // contribution of B(k, n): p indexes the shared operand (values array / plain matrix)
+
+std::string soa_body(SpKind kind, const SpShape& s, const unsigned* ptr, const unsigned* idx, bool csr)
+{
+  std::string t;
+  const int lanes = sp_lanes(kind, s), V = s.v;
+  t += "  const long long xs_gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;\n";
+  t += fmt("  const long long xs_item = xs_gid / %d;\n  const int xs_l = (int)(xs_gid - xs_item * %d);\n", lanes, lanes);
+  t += "  if (xs_item >= batch) return;\n";
+  if (SP_SOA_ASPARSE == kind || SP_SOA_RM_BC == kind) { // C[m][n][v] (+)= A(m,k) * B[k][n][v]; thread = (n, v)
+    t += "  const T* const b = B + xs_item * stride_dense + xs_l;\n  T* const c = C + xs_item * stride_c + xs_l;\n";
+    std::vector<char> used(s.k > 0 ? s.k : 1, 0);
+    if (SP_SOA_RM_BC == kind) used.assign(used.size(), 1);
+    else for (int m = 0; m < s.m; ++m) for (unsigned p = ptr[m]; p < ptr[m + 1]; ++p) used[idx[p]] = 1;
+    for (int k = 0; k < s.k; ++k) if (used[k]) t += fmt("  const T b%d = b[%d];\n", k, k * s.ldb * V);
+    for (int m = 0; m < s.m; ++m) {
+      if (SP_SOA_ASPARSE == kind && ptr[m] == ptr[m + 1]) continue; // untouched, also for beta == 0
+      t += fmt("  { T acc = %s;\n", 0 != s.beta0 ? "(T)0" : fmt("c[%d]", m * s.ldc * V).c_str());
+      if (SP_SOA_ASPARSE == kind) for (unsigned p = ptr[m]; p < ptr[m + 1]; ++p) t += fmt("    acc = XACC(A[%u], b%u, acc);\n", p, idx[p]);
+      else for (int k = 0; k < s.k; ++k) t += fmt("    acc = XACC(A[%d], b%d, acc);\n", m * s.lda + k, k);
+      t += fmt("    c[%d] = acc; }\n", m * s.ldc * V);
+    }
+  }
+  else { // C[m][n][v] (+)= A[m][k][v] * B(k,n); thread = (m, v)
+    t += fmt("  const int xs_m = xs_l / %d, xs_v = xs_l - xs_m * %d;\n", V, V);
+    t += fmt("  const T* const a = A + xs_item * stride_dense + (long long)xs_m * %d + xs_v;\n", s.lda * V);
+    t += fmt("  T* const c = C + xs_item * stride_c + (long long)xs_m * %d + xs_v;\n", s.ldc * V);
+    std::vector<std::vector<SoaEntry>> cols(s.n > 0 ? s.n : 1);
+    if (SP_SOA_RM_AC == kind) {
+      for (int n = 0; n < s.n; ++n) for (int k = 0; k < s.k; ++k) cols[n].push_back(SoaEntry{ (unsigned)k, (unsigned)(k * s.ldb + n) });
+    }
+    else if (csr) { // rows of B are k: entries arrive k-ascending per column by construction
+      for (int k = 0; k < s.k; ++k) for (unsigned p = ptr[k]; p < ptr[k + 1]; ++p) {
+        const unsigned n = idx[p];
+        if (n < (unsigned)s.n && (cols[n].empty() || cols[n].back().k != (unsigned)k)) cols[n].push_back(SoaEntry{ (unsigned)k, p });
+      }
+    }
+    else { // columns of B: per k the first entry with that row index
+      for (int n = 0; n < s.n; ++n) for (int k = 0; k < s.k; ++k) {
+        for (unsigned p = ptr[n]; p < ptr[n + 1]; ++p) if (idx[p] == (unsigned)k) { cols[n].push_back(SoaEntry{ (unsigned)k, p }); break; }
+      }
+    }
+    std::vector<char> used(s.k > 0 ? s.k : 1, 0);
+    for (int n = 0; n < s.n; ++n) for (const SoaEntry& e : cols[n]) used[e.k] = 1;
+    for (int k = 0; k < s.k; ++k) if (used[k]) t += fmt("  const T a%d = a[%d];\n", k, k * V);
+    for (int n = 0; n < s.n; ++n) {
+      t += fmt("  { T acc = %s;\n", 0 != s.beta0 ? "(T)0" : fmt("c[%d]", n * V).c_str());
+      for (const SoaEntry& e : cols[n]) t += fmt("    acc = XACC(a%u, B[%u], acc);\n", e.k, e.p);
+      t += fmt("    c[%d] = acc; }\n", n * V);
+    }
+  }
+  return t;
 }
 
 // The statements between the signature and the closing brace. A, B, C, stride_dense, stride_c and batch are the kernel's
@@ -216,6 +278,7 @@ SpShape shape_of(const libxsmm_gemm_descriptor& d)
   s.typesize = (LIBXSMM_GEMM_PRECISION_F64 == LIBXSMM_GETENUM_INP(d.datatype)) ? 8 : 4;
   s.m = (int)d.m; s.n = (int)d.n; s.k = (int)d.k; s.lda = (int)d.lda; s.ldb = (int)d.ldb; s.ldc = (int)d.ldc;
   s.beta0 = (0 != (d.flags & LIBXSMM_GEMM_FLAG_BETA_0)) ? 1 : 0;
+  s.v = 0;
   return s;
 }
 
@@ -399,15 +462,19 @@ LIBXSMM_API void libxsmm_generator_spgemm(const char* i_file_out, const char* i_
   std::vector<unsigned> ptr, idx; std::vector<double> values;
   unsigned rows = 0, cols = 0, nnz = 0, err = 0;
   if (nullptr == i_xgemm_desc || nullptr == i_routine_name) err = ERR_SPGEMM_GEN;
-  else if (0 != i_is_csr && 1 != i_is_csr && 3 != i_is_csr) err = ERR_SPGEMM_GEN; // SOA forms (2, > 9): not generated here
-  if (0 == err) err = read_coordinate_file(i_file_in, 0 != i_is_csr, ptr, idx, values, rows, cols, nnz);
+  // i_is_csr: 0 CSC text, 1 CSR text, 2 CSR SOA, 3 CSR with baked-in values, > 9 CSC SOA (src/generator_spgemm.c:271,400-409)
+  else if (0 > i_is_csr || (3 < i_is_csr && 10 > i_is_csr)) err = ERR_SPGEMM_GEN;
+  const bool file_is_csr = (1 <= i_is_csr && i_is_csr <= 3);
+  if (0 == err) err = read_coordinate_file(i_file_in, file_is_csr, ptr, idx, values, rows, cols, nnz);
   if (0 == err) {
     if (3 == i_is_csr) libxsmm_generator_spgemm_csr_reg_kernel(&code, i_xgemm_desc, i_arch, ptr.data(), idx.data(), values.data());
     else {
       const int ts = (LIBXSMM_GEMM_PRECISION_F64 == LIBXSMM_GETENUM_INP(i_xgemm_desc->datatype)) ? 8 : 4;
-      append(&code, spgemm_prologue(ts, fma_default()) + spgemm_signature(i_routine_name));
+      append(&code, spgemm_prologue(ts, (2 == i_is_csr || 9 < i_is_csr) ? 1 : fma_default()) + spgemm_signature(i_routine_name));
       if (1 == i_is_csr) libxsmm_generator_spgemm_csr_kernel(&code, i_xgemm_desc, i_arch, ptr.data(), idx.data(), values.data());
-      else libxsmm_generator_spgemm_csc_kernel(&code, i_xgemm_desc, i_arch, idx.data(), ptr.data(), values.data());
+      else if (2 == i_is_csr) libxsmm_generator_spgemm_csr_soa_kernel(&code, i_xgemm_desc, i_arch, ptr.data(), idx.data(), values.data());
+      else if (0 == i_is_csr) libxsmm_generator_spgemm_csc_kernel(&code, i_xgemm_desc, i_arch, idx.data(), ptr.data(), values.data());
+      else libxsmm_generator_spgemm_csc_soa_kernel(&code, i_xgemm_desc, i_arch, idx.data(), ptr.data(), values.data());
       append(&code, "}\n\n");
     }
     err = code.last_error;
@@ -478,6 +545,8 @@ LIBXSMM_API int libxsmm_amd_spgemm_execute_batch(const libxsmm_amd_spgemm* handl
   switch (handle->kind) {
     case SP_CSR_ASPARSE: ext_dense = (size_t)(s.k - 1) * s.ldb + s.n; ext_c = (size_t)(s.m - 1) * s.ldc + (0 != s.beta0 ? s.ldc : s.n); break;
     case SP_CSC_BSPARSE: ext_dense = (size_t)(s.k - 1) * s.lda + s.m; ext_c = (size_t)(s.n - 1) * s.ldc + s.m; break;
+    case SP_SOA_ASPARSE: case SP_SOA_RM_BC: ext_dense = ((size_t)(s.k - 1) * s.ldb + s.n) * s.v; ext_c = ((size_t)(s.m - 1) * s.ldc + s.n) * s.v; break;
+    case SP_SOA_BSPARSE: case SP_SOA_RM_AC: ext_dense = ((size_t)(s.m - 1) * s.lda + s.k) * s.v; ext_c = ((size_t)(s.m - 1) * s.ldc + s.n) * s.v; break;
     default: ext_dense = (size_t)(s.n - 1) * s.ldb + s.k; ext_c = (size_t)(s.n - 1) * s.ldc + s.m; break;
   }
   const size_t bytes_dense = ((size_t)(batch - 1) * (size_t)stride_dense + ext_dense) * ts;
@@ -488,14 +557,17 @@ LIBXSMM_API int libxsmm_amd_spgemm_execute_batch(const libxsmm_amd_spgemm* handl
   if (!is_device_ptr(dense)) { void* t = scratch(3, bytes_dense); if (nullptr == t || 0 != h2d(t, dense, bytes_dense)) return EXIT_FAILURE; dd = t; }
   if (c_host) { void* t = scratch(5, bytes_c); if (nullptr == t || 0 != h2d(t, c, bytes_c)) return EXIT_FAILURE; dc = t; }
   // argument order of the emitted kernel: (A, B, C, ...) with the sparse operand's values in A (A sparse) or B (B sparse)
-  const void* pa = (SP_CSC_BSPARSE == handle->kind ? dd : dv);
-  const void* pb = (SP_CSC_BSPARSE == handle->kind ? dv : dd);
+  const bool dense_is_a = (SP_CSC_BSPARSE == handle->kind || SP_SOA_BSPARSE == handle->kind || SP_SOA_RM_AC == handle->kind);
+  const void* pa = (dense_is_a ? dd : dv);
+  const void* pb = (dense_is_a ? dv : dd);
   const long long threads = batch * handle->lanes;
   const long long blocks = (threads + 255) / 256;
   if (blocks > 0x7fffffffLL) return EXIT_FAILURE;
   void* args[] = { (void*)&pa, (void*)&pb, (void*)&dc, (void*)&stride_dense, (void*)&stride_c, (void*)&batch };
   const int e = jit_launch_args(handle->kernel, (unsigned)blocks, 256u, args, device().stream);
-  note_launch(SP_CSR_ASPARSE == handle->kind ? "spgemm_csr_asparse_text" : (SP_CSC_BSPARSE == handle->kind ? "spgemm_csc_bsparse_text" : "spgemm_csc_asparse_text"));
+  static const char* const names[] = { "spgemm_csr_asparse_text", "spgemm_csc_bsparse_text", "spgemm_csc_asparse_text",
+                                       "soa_asparse_text", "soa_bsparse_text", "soa_rm_ac_text", "soa_rm_bc_text" };
+  note_launch(names[handle->kind]);
   if (0 != e) return EXIT_FAILURE;
   if (c_host) return 0 == d2h(c, dc, bytes_c) ? EXIT_SUCCESS : EXIT_FAILURE;
   if (dv != sparse_values || dd != dense) return 0 == stream_sync() ? EXIT_SUCCESS : EXIT_FAILURE; // staged inputs must have landed
@@ -522,4 +594,171 @@ LIBXSMM_API int libxsmm_amd_spgemm_source(const libxsmm_gemm_descriptor* descrip
     return rc;
   }
   return (int)src.size();
+}
+
+// ---- SOA family ------------------------------------------------------------------------------------------------------
+namespace {
+
+// descriptor -> SOA kernel kind with the reference's checks (src/generator_spgemm.c:179-238); form: 0 CSR, 1 CSC, 2 rm_ac, 3 rm_bc
+unsigned classify_soa(const libxsmm_gemm_descriptor& d, int form, SpKind& kind)
+{
+  if (2 == form || 3 == form) {
+    if (d.lda < d.k) return ERR_LDA;
+    if (d.ldb < d.n) return ERR_LDB;
+    if (d.ldc < d.n) return ERR_LDC;
+    kind = (2 == form ? SP_SOA_RM_AC : SP_SOA_RM_BC);
+    return 0;
+  }
+  if (0 == form && 0 == d.lda && 0 < d.ldb && 0 < d.ldc) { // A sparse (CSR only)
+    if (d.ldb < d.n) return ERR_LDB;
+    if (d.ldc < d.n) return ERR_LDC;
+    kind = SP_SOA_ASPARSE;
+    return 0;
+  }
+  if (0 < d.lda && 0 == d.ldb && 0 < d.ldc) { // B sparse (CSR or CSC)
+    if (d.lda < d.k) return ERR_LDA;
+    if (d.ldc < d.n) return ERR_LDC;
+    kind = SP_SOA_BSPARSE;
+    return 0;
+  }
+  return ERR_SPGEMM_GEN;
+}
+
+int soa_width(int typesize) { return 8 == typesize ? 8 : 16; }
+
+// indexes must address the operator: the generated statements are unconditional
+bool soa_pattern_ok(SpKind kind, const SpShape& s, const unsigned* ptr, const unsigned* idx, bool csr)
+{
+  if (SP_SOA_RM_AC == kind || SP_SOA_RM_BC == kind) return true;
+  if (nullptr == ptr || nullptr == idx) return false;
+  const int nmajor = (SP_SOA_ASPARSE == kind) ? s.m : (csr ? s.k : s.n);
+  const unsigned limit = (unsigned)((SP_SOA_ASPARSE == kind) ? s.k : (csr ? s.n : s.k));
+  for (int i = 0; i < nmajor; ++i) if (ptr[i] > ptr[i + 1]) return false;
+  if (SP_SOA_ASPARSE == kind) for (unsigned p = ptr[0]; p < ptr[nmajor]; ++p) if (idx[p] >= limit) return false;
+  return true;
+}
+
+std::string soa_source(SpKind kind, const SpShape& s, const unsigned* ptr, const unsigned* idx, bool csr, const char* name)
+{
+  return spgemm_prologue(s.typesize, 1/*fma*/) + spgemm_signature(name) + soa_body(kind, s, ptr, idx, csr) + "}\n";
+}
+
+libxsmm_amd_spgemm* soa_create(const libxsmm_gemm_descriptor* descriptor, int form, const unsigned* ptr, const unsigned* idx)
+{
+  if (nullptr == descriptor || !supported_precision(*descriptor)) return nullptr;
+  SpKind kind = SP_SOA_ASPARSE;
+  if (0 != classify_soa(*descriptor, form, kind)) return nullptr;
+  SpShape s = shape_of(*descriptor);
+  s.v = soa_width(s.typesize);
+  const bool csr = (0 == form);
+  if (0 == s.m || 0 == s.n || 0 == s.k || !soa_pattern_ok(kind, s, ptr, idx, csr)) return nullptr;
+  if (!device_ready()) { fail_no_device("libxsmm_create_*_soa"); return nullptr; }
+  std::string log;
+  JitKernel* const k = jit_compile(soa_source(kind, s, ptr, idx, csr, "xsmm_spgemm_op"), "xsmm_spgemm_op", &log);
+  if (nullptr == k) {
+    if (0 != libxsmm_verbosity) fprintf(stderr, "LIBXSMM-AMD ERROR: SOA kernel did not compile (%s)\n", log.c_str());
+    return nullptr;
+  }
+  libxsmm_amd_spgemm* const h = new libxsmm_amd_spgemm;
+  h->kernel = k; h->kind = kind; h->shape = s; h->lanes = sp_lanes(kind, s);
+  switch (kind) { // elements of the shared operand (staged when it lives on the host)
+    case SP_SOA_ASPARSE: h->nnz = ptr[s.m]; break;
+    case SP_SOA_BSPARSE: h->nnz = ptr[csr ? s.k : s.n]; break;
+    case SP_SOA_RM_AC: h->nnz = (unsigned)((s.k - 1) * s.ldb + s.n); break;
+    default: h->nnz = (unsigned)((s.m - 1) * s.lda + s.k); break;
+  }
+  return h;
+}
+
+libxsmm_xmmfunction soa_kernel(const libxsmm_gemm_descriptor* descriptor, int form, const unsigned* ptr, const unsigned* idx)
+{
+  libxsmm_xmmfunction result; result.xmm = nullptr;
+  libxsmm_init();
+  libxsmm_amd_spgemm* const h = soa_create(descriptor, form, ptr, idx);
+  if (nullptr == h) return result;
+  Kernel* const k = new Kernel();
+  k->desc = *descriptor; k->kclass = KC_TEXT; k->text = h;
+  void* const fn = adopt_kernel(k);
+  if (nullptr == fn) { libxsmm_amd_spgemm_destroy(h); delete k; return result; }
+  result.xmm = reinterpret_cast<decltype(result.xmm)>(fn);
+  return result;
+}
+
+void emit_soa(libxsmm_generated_code* io, const libxsmm_gemm_descriptor* d, int form, const unsigned* ptr, const unsigned* idx)
+{
+  if (nullptr == io) return;
+  if (nullptr == d || nullptr == ptr || nullptr == idx) { fail(io, ERR_SPGEMM_GEN); return; }
+  if (!supported_precision(*d)) { fail(io, ERR_UNSUP_DATATYPE); return; }
+  SpKind kind = SP_SOA_ASPARSE;
+  const unsigned e = classify_soa(*d, form, kind);
+  if (0 != e) { fail(io, e); return; }
+  SpShape s = shape_of(*d); s.v = soa_width(s.typesize);
+  if (!soa_pattern_ok(kind, s, ptr, idx, 0 == form)) { fail(io, ERR_SPGEMM_GEN); return; }
+  append(io, soa_body(kind, s, ptr, idx, 0 == form));
+}
+
+} // namespace
+
+namespace xsmm {
+int text_kernel_execute(void* text, const void* a, const void* b, void* c, long long stride_dense, long long stride_c, long long batch)
+{ // kernel(a, b, c): which of a/b is the shared operand follows from the kind
+  const libxsmm_amd_spgemm* const h = static_cast<const libxsmm_amd_spgemm*>(text);
+  if (nullptr == h) return EXIT_FAILURE;
+  const bool dense_is_a = (SP_CSC_BSPARSE == h->kind || SP_SOA_BSPARSE == h->kind || SP_SOA_RM_AC == h->kind);
+  return libxsmm_amd_spgemm_execute_batch(h, dense_is_a ? b : a, dense_is_a ? a : b, c, stride_dense, stride_c, batch);
+}
+void text_kernel_destroy(void* text) { libxsmm_amd_spgemm_destroy(static_cast<const libxsmm_amd_spgemm*>(text)); }
+}
+
+LIBXSMM_API libxsmm_xmmfunction libxsmm_create_xcsr_soa(const libxsmm_gemm_descriptor* descriptor,
+  const unsigned int* row_ptr, const unsigned int* column_idx, const void* values)
+{ // src/libxsmm_main.c:2423-2447; `values` only has to be non-NULL (the kernel takes the values at call time)
+  libxsmm_xmmfunction none; none.xmm = nullptr;
+  if (nullptr == descriptor || nullptr == row_ptr || nullptr == column_idx || nullptr == values) return none;
+  return soa_kernel(descriptor, 0, row_ptr, column_idx);
+}
+
+LIBXSMM_API libxsmm_xmmfunction libxsmm_create_xcsc_soa(const libxsmm_gemm_descriptor* descriptor,
+  const unsigned int* column_ptr, const unsigned int* row_idx, const void* values)
+{ // src/libxsmm_main.c:2450-2474
+  libxsmm_xmmfunction none; none.xmm = nullptr;
+  if (nullptr == descriptor || nullptr == column_ptr || nullptr == row_idx || nullptr == values) return none;
+  return soa_kernel(descriptor, 1, column_ptr, row_idx);
+}
+
+LIBXSMM_API libxsmm_xmmfunction libxsmm_create_rm_ac_soa(const libxsmm_gemm_descriptor* descriptor)
+{ // src/libxsmm_main.c:2477-2497
+  return soa_kernel(descriptor, 2, nullptr, nullptr);
+}
+
+LIBXSMM_API libxsmm_xmmfunction libxsmm_create_rm_bc_soa(const libxsmm_gemm_descriptor* descriptor)
+{ // src/libxsmm_main.c:2500-2520
+  return soa_kernel(descriptor, 3, nullptr, nullptr);
+}
+
+LIBXSMM_API void libxsmm_generator_spgemm_csr_soa_kernel(libxsmm_generated_code* io_generated_code, const libxsmm_gemm_descriptor* i_xgemm_desc,
+  const char* i_arch, const unsigned int* i_row_idx, const unsigned int* i_column_idx, const void* i_values)
+{
+  (void)i_arch; (void)i_values;
+  emit_soa(io_generated_code, i_xgemm_desc, 0, i_row_idx, i_column_idx);
+}
+
+LIBXSMM_API void libxsmm_generator_spgemm_csc_soa_kernel(libxsmm_generated_code* io_generated_code, const libxsmm_gemm_descriptor* i_xgemm_desc,
+  const char* i_arch, const unsigned int* i_row_idx, const unsigned int* i_column_idx, const void* i_values)
+{ // argument naming of the reference: i_row_idx = row of each entry, i_column_idx = column pointers
+  (void)i_arch; (void)i_values;
+  emit_soa(io_generated_code, i_xgemm_desc, 1, i_column_idx, i_row_idx);
+}
+
+LIBXSMM_API int libxsmm_amd_soa_width(libxsmm_gemm_precision precision)
+{
+  return LIBXSMM_GEMM_PRECISION_F64 == precision ? 8 : (LIBXSMM_GEMM_PRECISION_F32 == precision ? 16 : 0);
+}
+
+LIBXSMM_API int libxsmm_amd_kernel_execute_batch(const void* kernel, const void* a, const void* b, void* c,
+  long long stride_dense, long long stride_c, long long batch)
+{
+  Kernel* const k = kernel_from_pointer(kernel);
+  if (nullptr == k || KC_TEXT != k->kclass) return EXIT_FAILURE;
+  return text_kernel_execute(k->text, a, b, c, stride_dense, stride_c, batch);
 }

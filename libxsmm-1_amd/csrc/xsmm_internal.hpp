@@ -138,7 +138,7 @@ void note_launch(const char* name);
 // grow-only device scratch, one per thread-local slot id
 void* scratch(int slot, size_t bytes);
 
-enum KernelClass : int { KC_DENSE = 0, KC_REDUCE = 1, KC_CSR_REG = 2 };
+enum KernelClass : int { KC_DENSE = 0, KC_REDUCE = 1, KC_CSR_REG = 2, KC_TEXT = 3 /* pattern kernel compiled from generated text (SOA family) */ };
 
 struct Kernel {                 // what a dispatched function pointer stands for
   libxsmm_gemm_descriptor desc;
@@ -148,9 +148,14 @@ struct Kernel {                 // what a dispatched function pointer stands for
   // KC_CSR_REG payload
   unsigned nnz = 0;
   unsigned* d_rowptr = nullptr; unsigned* d_colidx = nullptr; void* d_values = nullptr;
+  // KC_TEXT payload: libxsmm_amd_spgemm* (xsmm_generator.cpp)
+  void* text = nullptr;
 };
 
 Kernel* kernel_from_pointer(const void* fn);           // NULL if fn is not one of ours
+void* adopt_kernel(Kernel* k);                         // caller-owned kernel: make its thunk and index it; NULL on failure
+int text_kernel_execute(void* text, const void* a, const void* b, void* c, long long stride_dense, long long stride_c, long long batch);
+void text_kernel_destroy(void* text);
 void* make_thunk(Kernel* k);                           // executable stub carrying k
 void free_thunk(void* thunk);
 void call_kernel(Kernel* k, const void* a, const void* b, void* c, const void* x3); // what a thunk does

@@ -515,6 +515,20 @@ void* create_csr_reg(const libxsmm_gemm_descriptor* descriptor, const unsigned* 
 
 } // namespace
 
+namespace xsmm {
+void* adopt_kernel(Kernel* k)
+{
+  if (nullptr == k) return nullptr;
+  k->registered = false;
+  k->thunk = make_thunk(k);
+  if (nullptr == k->thunk) return nullptr;
+  Registry& r = registry();
+  std::unique_lock<std::shared_mutex> guard(r.lock);
+  r.by_thunk.emplace(k->thunk, k);
+  return k->thunk;
+}
+}
+
 LIBXSMM_API libxsmm_dmmfunction libxsmm_create_dcsr_reg(const libxsmm_gemm_descriptor* descriptor,
   const unsigned int* row_ptr, const unsigned int* column_idx, const double* values)
 {
@@ -557,6 +571,7 @@ LIBXSMM_API void libxsmm_release_kernel(const void* jit_kernel)
   }
   if (device_ready()) (void)stream_sync();
   dev_free(k->d_rowptr); dev_free(k->d_colidx); dev_free(k->d_values);
+  if (nullptr != k->text) text_kernel_destroy(k->text);
   free_thunk(k->thunk);
   delete k;
 }

@@ -765,3 +765,65 @@ void xo_matdiff(int typesize, int m, int n, const void* ref, const void* tst, in
   if (NULL != linf_abs) *linf_abs = linf;
   if (NULL != normf_rel) *normf_rel = (0 < nr ? sqrt(l2 / nr) : sqrt(l2));
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * SOA kernels (EDGE/SeisSol "fused runs"): B and/or A and C are [row][col][v] with v = soa width innermost.
+ * Every kernel is element-wise in v. Arithmetic: fused multiply-add, accumulator seeded with C (or 0 for beta == 0),
+ * products in ascending k -- what the AVX2/AVX-512 generators emit (vfmadd231 on a register accumulator):
+ *  - generator_spgemm_csr_asparse_soa.c:212-330: rows of A without non-zeros are not touched (not even for beta == 0);
+ *  - generator_spgemm_csc_bsparse_soa.c:177-420, generator_spgemm_csr_bsparse_soa.c:160-330: every C column of the
+ *    block is loaded/zeroed and stored; for k ascending the first entry (k, n) of the pattern contributes;
+ *  - generator_gemm_rm_ac_soa.c / generator_gemm_rm_bc_soa.c: dense counterparts (gold loops of
+ *    samples/edge/dense_rmacsoa.c:60-80, dense_rmbcsoa.c).
+ * ------------------------------------------------------------------------------------------------ */
+#define XO_DEFINE_SOA(SUFFIX, T, FMAF)                                                                  \
+void xo_soa_csr_asparse_##SUFFIX(int flags, int m, int n, int k, int ldb, int ldc, int v,               \
+  const unsigned* rowptr, const unsigned* colidx, const T* a_vals, const T* b, T* c)                     \
+{                                                                                                       \
+  int im, in, iv; unsigned p; (void)k;                                                                  \
+  for (im = 0; im < m; ++im) {                                                                          \
+    if (rowptr[im] == rowptr[im + 1]) continue;                                                         \
+    for (in = 0; in < n; ++in) for (iv = 0; iv < v; ++iv) {                                             \
+      T acc = (0 != (flags & XO_FLAG_BETA_0)) ? (T)0 : c[((size_t)im * ldc + in) * v + iv];             \
+      for (p = rowptr[im]; p < rowptr[im + 1]; ++p) acc = FMAF(a_vals[p], b[((size_t)colidx[p] * ldb + in) * v + iv], acc); \
+      c[((size_t)im * ldc + in) * v + iv] = acc;                                                        \
+    }                                                                                                   \
+  }                                                                                                     \
+}                                                                                                       \
+void xo_soa_bsparse_##SUFFIX(int flags, int csr, int m, int n, int k, int lda, int ldc, int v,          \
+  const unsigned* ptr, const unsigned* idx, const T* a, const T* b_vals, T* c)                           \
+{                                                                                                       \
+  int im, in, iv, ik; unsigned p;                                                                       \
+  for (im = 0; im < m; ++im) for (in = 0; in < n; ++in) for (iv = 0; iv < v; ++iv) {                    \
+    T acc = (0 != (flags & XO_FLAG_BETA_0)) ? (T)0 : c[((size_t)im * ldc + in) * v + iv];               \
+    for (ik = 0; ik < k; ++ik) {                                                                        \
+      if (0 != csr) { /* row ik of B: first entry in column `in` */                                     \
+        for (p = ptr[ik]; p < ptr[ik + 1]; ++p) if (idx[p] == (unsigned)in) { acc = FMAF(a[((size_t)im * lda + ik) * v + iv], b_vals[p], acc); break; } \
+      }                                                                                                 \
+      else { /* column `in` of B: first entry in row ik */                                              \
+        for (p = ptr[in]; p < ptr[in + 1]; ++p) if (idx[p] == (unsigned)ik) { acc = FMAF(a[((size_t)im * lda + ik) * v + iv], b_vals[p], acc); break; } \
+      }                                                                                                 \
+    }                                                                                                   \
+    c[((size_t)im * ldc + in) * v + iv] = acc;                                                          \
+  }                                                                                                     \
+}                                                                                                       \
+void xo_soa_rm_ac_##SUFFIX(int flags, int m, int n, int k, int lda, int ldb, int ldc, int v, const T* a, const T* b, T* c) \
+{                                                                                                       \
+  int im, in, iv, ik;                                                                                   \
+  for (im = 0; im < m; ++im) for (in = 0; in < n; ++in) for (iv = 0; iv < v; ++iv) {                    \
+    T acc = (0 != (flags & XO_FLAG_BETA_0)) ? (T)0 : c[((size_t)im * ldc + in) * v + iv];               \
+    for (ik = 0; ik < k; ++ik) acc = FMAF(a[((size_t)im * lda + ik) * v + iv], b[(size_t)ik * ldb + in], acc); \
+    c[((size_t)im * ldc + in) * v + iv] = acc;                                                          \
+  }                                                                                                     \
+}                                                                                                       \
+void xo_soa_rm_bc_##SUFFIX(int flags, int m, int n, int k, int lda, int ldb, int ldc, int v, const T* a, const T* b, T* c) \
+{                                                                                                       \
+  int im, in, iv, ik;                                                                                   \
+  for (im = 0; im < m; ++im) for (in = 0; in < n; ++in) for (iv = 0; iv < v; ++iv) {                    \
+    T acc = (0 != (flags & XO_FLAG_BETA_0)) ? (T)0 : c[((size_t)im * ldc + in) * v + iv];               \
+    for (ik = 0; ik < k; ++ik) acc = FMAF(a[(size_t)im * lda + ik], b[((size_t)ik * ldb + in) * v + iv], acc); \
+    c[((size_t)im * ldc + in) * v + iv] = acc;                                                          \
+  }                                                                                                     \
+}
+XO_DEFINE_SOA(f64, double, fma)
+XO_DEFINE_SOA(f32, float, fmaf)

@@ -131,6 +131,17 @@ void xo_spmdm_exec_bf16(int arith, int M, int N, int K, int bn_isa, char transa,
 void xo_spmdm_exec_batch(int arith, int M, int N, int K, int bn_isa, char transa, char transb, char transc,
                          float beta, const float* a, const float* b, float* c, long long batch, int nthreads);
 
+/* ---- SOA kernels (libxsmm_create_xcsr_soa/xcsc_soa/rm_ac_soa/rm_bc_soa, src/libxsmm_main.c:2423-2520): [row][col][v] ---- */
+#define XO_DECLARE_SOA(SUFFIX, T) \
+void xo_soa_csr_asparse_##SUFFIX(int flags, int m, int n, int k, int ldb, int ldc, int v, \
+  const unsigned* rowptr, const unsigned* colidx, const T* a_vals, const T* b, T* c); \
+void xo_soa_bsparse_##SUFFIX(int flags, int csr, int m, int n, int k, int lda, int ldc, int v, \
+  const unsigned* ptr, const unsigned* idx, const T* a, const T* b_vals, T* c); \
+void xo_soa_rm_ac_##SUFFIX(int flags, int m, int n, int k, int lda, int ldb, int ldc, int v, const T* a, const T* b, T* c); \
+void xo_soa_rm_bc_##SUFFIX(int flags, int m, int n, int k, int lda, int ldb, int ldc, int v, const T* a, const T* b, T* c);
+XO_DECLARE_SOA(f64, double)
+XO_DECLARE_SOA(f32, float)
+
 /* ---- blocked_gemm (libxsmm_blocked_gemm.c:47-568, template/libxsmm_blocked_gemm*.tpl.c) ---- */
 typedef struct xo_bgemm { int typesize, m, n, k, bm, bn, bk, mb, nb, kb, b_m1, b_n1, b_k1, b_k2, order, flags; } xo_bgemm;
 int xo_bgemm_init(xo_bgemm* h, int typesize, int m, int n, int k, int bm, int bn, int bk,

@@ -131,6 +131,26 @@ def csc_asparse(arith, flags, m, n, k, ldb, ldc, colptr, rowidx, a_vals, b, c):
     f(arith, flags, m, n, k, ldb, ldc, p(colptr), p(rowidx), p(a_vals), p(b), p(c))
 
 
+def _sfx(a):
+    return "f64" if a.dtype == np.float64 else "f32"
+
+
+def soa_csr_asparse(flags, m, n, k, ldb, ldc, v, rowptr, colidx, a_vals, b, c):
+    getattr(lib(), "xo_soa_csr_asparse_" + _sfx(c))(flags, m, n, k, ldb, ldc, v, p(rowptr), p(colidx), p(a_vals), p(b), p(c))
+
+
+def soa_bsparse(flags, csr, m, n, k, lda, ldc, v, ptr, idx, a, b_vals, c):
+    getattr(lib(), "xo_soa_bsparse_" + _sfx(c))(flags, 1 if csr else 0, m, n, k, lda, ldc, v, p(ptr), p(idx), p(a), p(b_vals), p(c))
+
+
+def soa_rm_ac(flags, m, n, k, lda, ldb, ldc, v, a, b, c):
+    getattr(lib(), "xo_soa_rm_ac_" + _sfx(c))(flags, m, n, k, lda, ldb, ldc, v, p(a), p(b), p(c))
+
+
+def soa_rm_bc(flags, m, n, k, lda, ldb, ldc, v, a, b, c):
+    getattr(lib(), "xo_soa_rm_bc_" + _sfx(c))(flags, m, n, k, lda, ldb, ldc, v, p(a), p(b), p(c))
+
+
 def csr_reg(flags, m, n, k, ldb, ldc, rowptr, colidx, values, b, c):
     f = lib().xo_dcsr_reg if b.dtype == np.float64 else lib().xo_scsr_reg
     return f(flags, m, n, k, ldb, ldc, p(rowptr), p(colidx), p(values), p(b), p(c))

@@ -117,6 +117,77 @@ void spmdm_create_kernel(long long nslices, int nrows_full, int ncols_full, int 
   }
 }
 
+// Batch form for slices of at most 64 columns whose slots are 16-byte aligned (cap % 8 == 0): the compacted entries are
+// collected in wave-private LDS and leave as 16-byte vector stores, 1 KiB per wave instruction, instead of the per-row
+// 2- and 4-byte scatter of the kernel above (partial lines). Same scan order, same output.
+constexpr int SPC_CAP = 1024;  // entries buffered per wave before a flush (+ one row of slack)
+__global__ __launch_bounds__(256)
+void spmdm_create_staged_kernel(long long nslices, int nrows, int ncols, int transa,
+                                const float* __restrict__ a, long long a_slice_stride, int ld,
+                                uint16_t* __restrict__ rowidx, uint16_t* __restrict__ colidx, float* __restrict__ values,
+                                long long rowidx_stride, long long cap)
+{
+  __shared__ __align__(16) float lds_vals[4][SPC_CAP + 64];
+  __shared__ __align__(16) uint16_t lds_cols[4][SPC_CAP + 64];
+  __shared__ __align__(16) uint16_t lds_rows[4][264];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float* const bv = lds_vals[wv]; uint16_t* const bc = lds_cols[wv]; uint16_t* const br = lds_rows[wv];
+  const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+  const bool in_range = (lane < ncols);
+  typedef unsigned sp_u32x4c __attribute__((ext_vector_type(4)));
+  typedef float sp_f32x4c __attribute__((ext_vector_type(4)));
+  for (long long s = wave; s < nslices; s += nwaves) {
+    const float* const in = a + s * a_slice_stride;
+    uint16_t* const ri = rowidx + s * rowidx_stride;
+    uint16_t* const ci = colidx + s * cap;
+    float* const va = values + s * cap;
+    unsigned cnt = 0;      // entries of the slice so far
+    unsigned flushed = 0;  // entries already in HBM (multiple of 8)
+    auto flush = [&](unsigned upto) { // entries [flushed, upto) leave the buffer; upto - flushed is a multiple of 8 (or the final tail, padded)
+      const unsigned n = upto - flushed;
+      wave_lds_sync();
+      for (unsigned i = lane; 4 * i < n; i += 64) __builtin_nontemporal_store(*reinterpret_cast<const sp_f32x4c*>(bv + 4 * i), reinterpret_cast<sp_f32x4c*>(va + flushed + 4 * i));
+      for (unsigned i = lane; 8 * i < n; i += 64) __builtin_nontemporal_store(*reinterpret_cast<const sp_u32x4c*>(bc + 8 * i), reinterpret_cast<sp_u32x4c*>(ci + flushed + 8 * i));
+      wave_lds_sync();
+    };
+    for (int r0 = 0; r0 < nrows; r0 += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int r = r0 + u;
+        v[u] = (in_range && r < nrows) ? __builtin_nontemporal_load(transa ? (in + (size_t)lane * ld + r) : (in + (size_t)r * ld + lane)) : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int r = r0 + u;
+        if (r < nrows) {
+          if (0 == lane) br[r] = (uint16_t)cnt;
+          const bool keep = in_range && !(0.f == v[u]); // LIBXSMM_FEQ(0, v) ? 0 : 1  (-0 is zero, NaN is kept)
+          const unsigned long long mask = __ballot(keep);
+          if (keep) {
+            const unsigned pos = (cnt - flushed) + __popcll(mask & ((1ULL << lane) - 1ULL));
+            bc[pos] = (uint16_t)lane; bv[pos] = v[u];
+          }
+          cnt += __popcll(mask);
+        }
+      }
+      if (cnt - flushed >= (unsigned)(SPC_CAP - 8 * 64)) { // the next eight rows might not fit: write whole groups of 8 entries out
+        const unsigned upto = flushed + ((cnt - flushed) & ~7u);
+        const unsigned rest = cnt - upto;
+        flush(upto);
+        if (lane < rest) { const float tv = bv[(upto - flushed) + lane]; const uint16_t tc = bc[(upto - flushed) + lane]; wave_lds_sync(); bv[lane] = tv; bc[lane] = tc; }
+        else wave_lds_sync();
+        flushed = upto;
+      }
+    }
+    if (0 == lane) br[nrows] = (uint16_t)cnt;
+    flush(cnt + ((8 - ((cnt - flushed) & 7)) & 7)); // tail padded to a whole 16-byte piece (stays inside the slot: cap % 8 == 0)
+    for (int i = lane; i <= nrows; i += 64) ri[i] = br[i];
+    wave_lds_sync();
+  }
+}
+
 // ---- spmdm: CSR x dense -----------------------------------------------------------------------------------------
 // Generic form (any geometry, transposes, beta): one thread per C element of one item; B is read through the
 // caches. The tuned batch kernel for small problems is spmdm_compute_lds_kernel.
@@ -461,6 +532,13 @@ int launch_spmdm_create(const SpmdmGeom& g, int transa, const float* a, uint16_t
   hipStream_t st = (hipStream_t)stream;
   *name = "spmdm_create_slices_wave";
   if (0 == g.batch) return 0;
+  static const int staged = []() { const char* e = getenv("XSMM_SPMDM_CREATE_STAGED"); return (nullptr != e && 0 != *e) ? atoi(e) : 1; }();
+  if (0 != staged && g.k <= 64 && g.m <= 255 && 0 == (g.cap & 7)) { // entries collected in LDS, 16-byte stores
+    *name = "spmdm_create_slices_staged";
+    hipLaunchKernelGGL(spmdm_create_staged_kernel, dim3(grid_for(g.batch, 4)), dim3(256), 0, st,
+      g.batch, g.m, g.k, transa, a, (long long)g.m * g.k, transa ? g.m : g.k, rowidx, colidx, values, (long long)g.rstride, (long long)g.cap);
+    return (int)hipGetLastError();
+  }
   hipLaunchKernelGGL(spmdm_create_kernel, dim3(grid_for(g.batch, 4)), dim3(256), 0, st,
     g.batch, g.m, g.k, transa, a, (long long)g.m * g.k, transa ? g.m : g.k, 0, g.m, g.k, g.m, g.k,
     rowidx, colidx, values, (long long)g.rstride, (long long)g.cap);

@@ -248,10 +248,28 @@ def secondary(torch, xs, L):
             xs.gemm_batch(xs.F64, "N", "N", m, n, k, 1.0, a, m, b, k, 1.0, c, m, 0, 4, ia, ib, ic, s_)
     _, t = time_steps(torch, stacks, 5, 2, None)
     mt = sum(t) / len(t) * 1e-3
-    L.libxsmm_amd_set_mfma(old_mfma)
     res["cp2k_stacks_f64_27shapes"] = {"products": 27 * 19418, "kernel": xs.last_kernel(), "streams": 1, "ms": round(mt * 1e3, 4),
                                        "hbm_gbs": round(byt / mt / 1e9, 1), "frac": round(byt / mt / 1e9 / HBM_PEAK_GBS, 4),
                                        "gflops": round(flops / mt / 1e9, 1)}
+    # the same 27 calls with the shape groups (independent C arrays) spread over 8 caller streams: batch calls make no host
+    # round trip, so the groups overlap on the GPU (each group alone is a set of sequential accumulation chains)
+    main = torch.cuda.current_stream()
+    pool = [torch.cuda.Stream() for _ in range(8)]
+
+    def stacks_streams():
+        fork = torch.cuda.Event(); fork.record(main)
+        for st in pool:
+            st.wait_event(fork)
+        for gi, (m, n, k, s_, a, b, c, ia, ib, ic) in enumerate(groups):
+            L.libxsmm_amd_set_stream(C.c_void_p(pool[gi % len(pool)].cuda_stream))
+            xs.gemm_batch(xs.F64, "N", "N", m, n, k, 1.0, a, m, b, k, 1.0, c, m, 0, 4, ia, ib, ic, s_)
+        L.libxsmm_amd_set_stream(C.c_void_p(main.cuda_stream))
+        for st in pool:
+            ev = torch.cuda.Event(); ev.record(st); main.wait_event(ev)
+    _, t8 = time_steps(torch, stacks_streams, 5, 2, None)
+    m8 = sum(t8) / len(t8) * 1e-3
+    res["cp2k_stacks_f64_27shapes"]["streams8"] = {"ms": round(m8 * 1e3, 4), "hbm_gbs": round(byt / m8 / 1e9, 1), "frac": round(byt / m8 / 1e9 / HBM_PEAK_GBS, 4)}
+    L.libxsmm_amd_set_mfma(old_mfma)
     return res
 
 

@@ -93,10 +93,11 @@ JitKernel* jit_compile(const std::string& src, const char* fname, std::string* l
 int jit_check_source(const std::string& src, std::string* log);
 void jit_release(JitKernel* k);
 int jit_launch_panels(JitKernel* k, const void* B, void* C, long long ncols, long long ldb, long long ldc, int vec, void* stream);
+int jit_blocks_per_cu(JitKernel* k, int threads); // occupancy of a generated kernel (0: unknown)
 int jit_launch_args(JitKernel* k, unsigned blocks, unsigned threads, void** args, void* stream);
 int jit_launch_raw(JitKernel* k, unsigned blocks, unsigned threads, void* arg0, size_t arg0_size, void* arg1, void* stream);
 // dense SMM kernels specialised per shape (xsmm_jit_smm.cpp)
-enum { SMM_JIT_SCALAR = 1, SMM_JIT_RUNS = 2, SMM_JIT_WGRUNS = 4, SMM_JIT_HASWG = 8 }; // variant bits of the generated dense kernel
+enum { SMM_JIT_SCALAR = 1, SMM_JIT_RUNS = 2, SMM_JIT_WGRUNS = 4, SMM_JIT_HASWG = 8, SMM_JIT_BIG = 16 }; // variant bits of the generated dense kernel
 std::string gen_smm_source(int typesize, int m, int n, int k, int flags, int variant);
 bool smm_jit_eligible(const SmmBatch& s);
 int launch_smm_jit(const SmmBatch& s, void* stream, const char** name); // -1: not available

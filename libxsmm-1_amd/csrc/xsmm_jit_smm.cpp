@@ -458,6 +458,144 @@ extern "C" __global__ __launch_bounds__(64 * XWAVES) void xsmm_smm_op(DevAddr ad
 #endif
 )XSMM";
 
+// ---- shapes with 32 < M or N <= 64: one work-group (256 threads, 16 x 16) per item, K in chunks of KC through LDS ------
+const char* const SMM_JIT_BIG_BODY = R"XSMM(
+#define XGLOBAL __attribute__((address_space(1)))
+struct DevAddr {
+  const char* a; const char* b; char* c;
+  const char* ia; const char* ib; const char* ic;
+  long long sa, sb, sc;
+  int index_base, index_stride, mode;
+  const int* flags;
+};
+template<typename P> __device__ __forceinline__ P* resolve(const char* base, const char* idx, long long stride, const DevAddr& ad, long long i)
+{
+  if (0 == ad.mode) return (P*)base + i * stride;
+  if (1 == ad.mode) { if (nullptr == idx) return (P*)base; const int v = *(const XGLOBAL int*)(idx + i * (long long)ad.index_stride); return (P*)base + ((long long)v - ad.index_base); }
+  return *(P* const XGLOBAL*)(base + i * stride);
+}
+__device__ __forceinline__ float xfma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double xfma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+// barrier that orders LDS traffic only (a work-group-scope fence would drain the prefetched global loads as well)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+constexpr int M = XM, N = XN, K = XK, KC = XKC;
+constexpr int TM = (M + 15) / 16, TN = (N + 15) / 16;             // register tile of a thread (tx = t & 15 along m, ty = t >> 4 along n)
+constexpr int NCH = (K + KC - 1) / KC;                             // k-chunks per item
+constexpr int AEL = KC * M, BEL = KC * N;                          // elements of one chunk
+constexpr int NLA = (AEL + 255) / 256, NLB = (BEL + 255) / 256;    // per thread
+constexpr int MP = 16 * TM, NP = 16 * TN;
+// LDS images of a chunk: A as [kk][MP], B as [kk][NPP]: a thread's TM resp. TN operands of one k are contiguous (one or two
+// 16-byte reads each). B arrives k-contiguous unless TRANS_B, so its LDS writes stride by a row; the 16-byte row padding
+// keeps that at a 4-way bank conflict on the (16x rarer) writes while the reads stay aligned.
+constexpr int NPP = NP + 16 / (int)sizeof(T);
+constexpr int AS = KC * MP, BS = KC * NPP;
+constexpr int BUF = ((AS + BS + 3) / 4) * 4;
+
+// chunk ch of one item: A rows k0..k0+KC (contiguous KC*M elements), B rows k0..k0+KC of every column (TRANS_B: contiguous)
+__device__ __forceinline__ void load_chunk(const T* pa, const T* pb, int ch, int t, T (&ra)[NLA], T (&rb)[NLB])
+{
+  const int k0 = ch * KC, kc = (K - k0 < KC) ? (K - k0) : KC;
+  const XGLOBAL T* const ga = (const XGLOBAL T*)pa + (long long)k0 * M;
+#pragma unroll
+  for (int j = 0; j < NLA; ++j) { const int e = 256 * j + t; if (e < kc * M) ra[j] = __builtin_nontemporal_load(ga + e); }
+  if (XTRANSB) {
+    const XGLOBAL T* const gb = (const XGLOBAL T*)pb + (long long)k0 * N;
+#pragma unroll
+    for (int j = 0; j < NLB; ++j) { const int e = 256 * j + t; if (e < kc * N) rb[j] = __builtin_nontemporal_load(gb + e); }
+  }
+  else {
+    const XGLOBAL T* const gb = (const XGLOBAL T*)pb + k0;
+#pragma unroll
+    for (int j = 0; j < NLB; ++j) { const int e = 256 * j + t, n = e / KC, kk = e - n * KC; if (e < BEL && kk < kc) rb[j] = __builtin_nontemporal_load(gb + (long long)n * K + kk); }
+  }
+}
+__device__ __forceinline__ void park_chunk(T* As, T* Bs, int ch, int t, const T (&ra)[NLA], const T (&rb)[NLB])
+{
+  const int k0 = ch * KC, kc = (K - k0 < KC) ? (K - k0) : KC;
+#pragma unroll
+  for (int j = 0; j < NLA; ++j) { const int e = 256 * j + t; if (e < kc * M) { const int kk = e / M, m = e - kk * M; As[kk * MP + m] = ra[j]; } }
+  if (XTRANSB) {
+#pragma unroll
+    for (int j = 0; j < NLB; ++j) { const int e = 256 * j + t; if (e < kc * N) { const int kk = e / N, n = e - kk * N; Bs[kk * NPP + n] = rb[j]; } }
+  }
+  else {
+#pragma unroll
+    for (int j = 0; j < NLB; ++j) { const int e = 256 * j + t, n = e / KC, kk = e - n * KC; if (e < BEL && kk < kc) Bs[kk * NPP + n] = rb[j]; }
+  }
+}
+
+extern "C" __global__ __launch_bounds__(256) void xsmm_smm_op(DevAddr ad, long long batch)
+{
+  __shared__ __attribute__((aligned(16))) T lds[2 * BUF];
+  const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
+  long long item = blockIdx.x;
+  if (item >= batch) return;
+  const long long G = gridDim.x;
+  T ra[NLA], rb[NLB], rc[TM][TN], acc[TM][TN];
+  // software pipeline over (item, chunk): the registers hold the chunk after the one that is being multiplied
+  load_chunk(resolve<const T>(ad.a, ad.ia, ad.sa, ad, item), resolve<const T>(ad.b, ad.ib, ad.sb, ad, item), 0, t, ra, rb);
+  if (!XBETA0) {
+    const XGLOBAL T* const gc = (const XGLOBAL T*)resolve<T>(ad.c, ad.ic, ad.sc, ad, item);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) { const int m = tx * TM + i, n = ty * TN + j; if (m < M && n < N) rc[i][j] = gc[n * M + m]; }
+    }
+  }
+  int buf = 0;
+  for (; item < batch; item += G) {
+    T* const pc = resolve<T>(ad.c, ad.ic, ad.sc, ad, item);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = XBETA0 ? (T)0 : rc[i][j];
+    }
+    const long long next = item + G;
+#pragma unroll 1
+    for (int ch = 0; ch < NCH; ++ch) {
+      T* const As = lds + buf * BUF;
+      T* const Bs = As + AS;
+      park_chunk(As, Bs, ch, t, ra, rb);
+      if (ch + 1 < NCH) load_chunk(resolve<const T>(ad.a, ad.ia, ad.sa, ad, item), resolve<const T>(ad.b, ad.ib, ad.sb, ad, item), ch + 1, t, ra, rb);
+      else if (next < batch) { // first chunk and C of the next item
+        load_chunk(resolve<const T>(ad.a, ad.ia, ad.sa, ad, next), resolve<const T>(ad.b, ad.ib, ad.sb, ad, next), 0, t, ra, rb);
+        if (!XBETA0) {
+          const XGLOBAL T* const gc = (const XGLOBAL T*)resolve<T>(ad.c, ad.ic, ad.sc, ad, next);
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) { const int m = tx * TM + i, n = ty * TN + j; if (m < M && n < N) rc[i][j] = gc[n * M + m]; }
+          }
+        }
+      }
+      lds_barrier();
+      const int k0 = ch * KC, kc = (K - k0 < KC) ? (K - k0) : KC;
+#pragma unroll 4
+      for (int kk = 0; kk < kc; ++kk) {
+        T av[TM], bv[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) av[i] = As[kk * MP + tx * TM + i];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bv[j] = Bs[kk * NPP + ty * TN + j];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = xfma(av[i], bv[j], acc[i][j]);
+        }
+      }
+      buf ^= 1;
+    }
+    XGLOBAL T* const gc = (XGLOBAL T*)pc;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) { const int m = tx * TM + i, n = ty * TN + j; if (m < M && n < N) __builtin_nontemporal_store(acc[i][j], gc + n * M + m); }
+    }
+  }
+}
+)XSMM";
+
 struct SmmKey {
   int typesize, m, n, k, flags, variant;
   bool operator==(const SmmKey& o) const { return typesize == o.typesize && m == o.m && n == o.n && k == o.k && flags == o.flags && variant == o.variant; }
@@ -470,6 +608,23 @@ std::unordered_map<SmmKey, JitKernel*, SmmKeyHash> g_smm_cache; // nullptr value
 } // namespace
 
 static int smm_jit_waves(int typesize, int m, int n, int k, int flags);
+
+// k-chunk of the work-group-per-item form: the largest of 32/16/8 whose two LDS buffers fit 64 KiB (0: none does)
+static size_t smm_jit_big_buf(int typesize, int m, int n, int kc, int flags)
+{
+  const size_t mp = 16 * (size_t)((m + 15) / 16), np = 16 * (size_t)((n + 15) / 16);
+  (void)flags;
+  const size_t as = (size_t)kc * mp, bs = (size_t)kc * (np + 16 / (size_t)typesize);
+  return ((as + bs + 3) / 4) * 4 * (size_t)typesize;
+}
+static int smm_jit_big_kc(int typesize, int m, int n, int k, int flags)
+{
+  for (int kc = 32; kc >= 8; kc /= 2) {
+    if (kc / 2 >= k && kc > 8) continue; // a shorter chunk already covers K
+    if (2 * smm_jit_big_buf(typesize, m, n, kc, flags) <= 65536) return kc;
+  }
+  return 0;
+}
 
 // Products whose operands a run kernel keeps in flight (register stages). Measured on CP2K stacks (MI355X): once the
 // per-item index loads are off the critical path (address windows) a run is bound by its on-chip work per product, not by
@@ -490,6 +645,11 @@ std::string gen_smm_source(int typesize, int m, int n, int k, int flags, int var
   s += "#define XM " + std::to_string(m) + "\n#define XN " + std::to_string(n) + "\n#define XK " + std::to_string(k) + "\n";
   s += std::string("#define XBETA0 ") + ((flags & LIBXSMM_GEMM_FLAG_BETA_0) ? "1" : "0") + "\n";
   s += std::string("#define XTRANSB ") + ((flags & LIBXSMM_GEMM_FLAG_TRANS_B) ? "1" : "0") + "\n";
+  if (0 != (variant & SMM_JIT_BIG)) { // work-group per item, K chunked
+    s += "#define XKC " + std::to_string(smm_jit_big_kc(typesize, m, n, k, flags)) + "\n";
+    s += SMM_JIT_BIG_BODY;
+    return s;
+  }
   s += "#define XWAVES " + std::to_string(smm_jit_waves(typesize, m, n, k, flags)) + "\n";
   s += std::string("#define XSCALAR ") + ((variant & SMM_JIT_SCALAR) ? "1" : "0") + "\n"; // element-wide loads/stores only
   // runs of equal C accumulate in registers: 1 = a wave per run, 2 = a work-group per run (long runs)
@@ -532,8 +692,14 @@ bool smm_jit_eligible(const SmmBatch& s)
   if (SYNC_NONE != s.sync && 0 != (s.flags & LIBXSMM_GEMM_FLAG_BETA_0)) return false; // (never chosen: beta == 0 needs no care)
   if (s.lda != s.m || s.ldc != s.m) return false;
   if (0 != (s.flags & LIBXSMM_GEMM_FLAG_TRANS_B) ? (s.ldb != s.n) : (s.ldb != s.k)) return false;
-  if (s.m > 32 || s.n > 32 || s.k > 64) return false;                       // 8x8 lanes x (<=4x4) tile
-  if (0 == smm_jit_waves(s.typesize, s.m, s.n, s.k, s.flags)) return false;                // static LDS limit per work-group
+  if (s.m > 32 || s.n > 32) { // work-group-per-item form: 16x16 threads x (<=4x4) tile, K chunked; independent C only
+    if (s.m > 64 || s.n > 64 || s.k > 1024 || SYNC_NONE != s.sync) return false;
+    if (0 == smm_jit_big_kc(s.typesize, s.m, s.n, s.k, s.flags)) return false;
+  }
+  else {
+    if (s.k > 64) return false;                                                // 8x8 lanes x (<=4x4) tile, whole K in LDS
+    if (0 == smm_jit_waves(s.typesize, s.m, s.n, s.k, s.flags)) return false; // static LDS limit per work-group
+  }
   const char* const env_min = getenv("LIBXSMM_AMD_JIT_MINBATCH");
   const long long min_batch = (nullptr != env_min && 0 != *env_min) ? atoll(env_min) : 16384LL;
   if (s.batch < min_batch) return false;                                      // compile time must be worth it
@@ -589,6 +755,21 @@ static int smm_jit_launch_variant(const SmmBatch& s, int variant, void* stream)
   ad.flags = (SYNC_DEVICE == s.sync ? s.devflags : nullptr);
   long long batch = s.batch;
   static const int bpc_env = []() { const char* e = getenv("XSMM_SMMJIT_BPC"); return (nullptr != e && 0 != *e) ? atoi(e) : 0; }();
+  if (0 != (variant & SMM_JIT_BIG)) { // one work-group per item, walking the batch with a stride of the grid
+    const size_t lds = 2 * smm_jit_big_buf(s.typesize, s.m, s.n, smm_jit_big_kc(s.typesize, s.m, s.n, s.k, s.flags), s.flags);
+    long long per_cu = (long long)((160 * 1024) / (lds ? lds : 1));
+    if (per_cu > 4) per_cu = 4;
+    // a persistent grid must not exceed what is resident: a work-group that starts after the others have finished their
+    // share is pure tail (measured: f64 64^3 with 150 VGPRs fits 3 per CU; a grid of 4 per CU loses 12 %)
+    const int occ = jit_blocks_per_cu(k, 256);
+    if (0 < occ && occ < per_cu) per_cu = occ;
+    if (per_cu < 1) per_cu = 1;
+    if (0 < bpc_env) per_cu = bpc_env;
+    long long blocks = batch;
+    if (blocks > 256 * per_cu) blocks = 256 * per_cu;
+    if (blocks < 1) blocks = 1;
+    return jit_launch_raw(k, (unsigned)blocks, 256u, &ad, sizeof(ad), &batch, stream);
+  }
   if (0 != (variant & SMM_JIT_WGRUNS)) { // work-groups of 256 threads, dealt chunks of 64 items
     const size_t buf = smm_jit_wg_buf(s.typesize, s.m, s.n, s.k, s.flags);
     const size_t lds = (2 * buf <= 65536 ? 2 : 1) * buf;
@@ -619,6 +800,10 @@ int launch_smm_jit(const SmmBatch& s, void* stream, const char** name)
 { // returns -1 when no specialised kernel is available
   const int width = smm_jit_width_variant(s);
   const bool f64 = (8 == s.typesize);
+  if (s.m > 32 || s.n > 32) { // (eligibility made sure of SYNC_NONE)
+    *name = f64 ? "smm_f64_jit_shape_wg" : "smm_f32_jit_shape_wg";
+    return smm_jit_launch_variant(s, SMM_JIT_BIG, stream);
+  }
   if (SYNC_NONE == s.sync) { // every item owns its C
     *name = f64 ? "smm_f64_jit_shape" : "smm_f32_jit_shape";
     return smm_jit_launch_variant(s, width, stream);

@@ -19,6 +19,13 @@ def test_generated_sources_compile_for_gfx950(xs):
     L = xs.lib()
     buf = C.create_string_buffer(1 << 17)
     for prec in (xs.F64, xs.F32):
+        for (m, n, k) in [(64, 64, 64), (48, 33, 200)]:  # work-group-per-item form (variant bit 16)
+            for beta, flags in ((1.0, 0), (0.0, xs.FLAG_TRANS_B)):
+                blob, d = xs.descriptor(prec, m, n, k, beta=beta, flags=flags)
+                rc = L.libxsmm_amd_smm_kernel_source(d, 16, buf, len(buf), 1)
+                if rc == -1:
+                    pytest.skip("libhiprtc is not available here")
+                assert rc == 0 and "#define XKC" in buf.value.decode()
         for (m, n, k) in [(23, 23, 23), (13, 23, 32), (32, 32, 64), (1, 1, 1)]:
             for beta, flags in ((1.0, 0), (0.0, 0), (1.0, xs.FLAG_TRANS_B)):
                 blob, d = xs.descriptor(prec, m, n, k, beta=beta, flags=flags)
@@ -200,3 +207,42 @@ def test_jit_stands_down_for_out_of_order_repeats(xs, orc, torch_gpu, dtype):
     out = dc.cpu().numpy()
     tol = 1e-12 if dtype == np.float64 else 1e-6
     assert np.max(np.abs(out - ref)) <= tol * max(1.0, np.max(np.abs(ref))) * 64
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("shape", [(64, 64, 64), (48, 40, 56), (33, 64, 17), (64, 33, 100), (40, 8, 5)])
+def test_jit_work_group_form_for_shapes_up_to_64(xs, orc, torch_gpu, dtype, shape):
+    """32 < M or N <= 64: one work-group per item, K in chunks through LDS (any K): the k-ascending fma chain continues
+    across the chunks, so the result is still the oracle's, bit for bit. Strided and index batches, beta 0/1, TRANS_B."""
+    torch = torch_gpu
+    m, n, k = shape
+    batch = 301
+    rng = np.random.default_rng(m + 3 * n + 7 * k)
+    prec = xs.F64 if dtype == np.float64 else xs.F32
+    with _JitForced(xs):
+        for beta, flags in ((1.0, 0), (0.0, 0), (1.0, xs.FLAG_TRANS_B)):
+            a = rng.uniform(-1, 1, batch * m * k).astype(dtype); b = rng.uniform(-1, 1, batch * k * n).astype(dtype)
+            c = rng.uniform(-1, 1, batch * m * n).astype(dtype)
+            if beta == 0.0:
+                c[:] = np.nan
+            ref = c.copy()
+            oflags = (orc.FLAG_BETA_0 if beta == 0.0 else 0) | (orc.FLAG_TRANS_B if flags else 0)
+            ldb = n if flags else k
+            orc.gemm_batch_strided(orc.FMA, oflags, m, n, k, m, ldb, m, a, b, ref, m * k, k * n, m * n, batch, 4)
+            da, db, dc = (torch.from_numpy(x).cuda() for x in (a, b, c))
+            blob, desc = xs.descriptor(prec, m, n, k, beta=beta, flags=flags)
+            assert 0 == xs.lib().libxsmm_amd_gemm_batch_strided(desc, xs.dptr(da), xs.dptr(db), xs.dptr(dc), m * k, k * n, m * n, batch)
+            torch.cuda.synchronize()
+            assert xs.last_kernel().endswith("_jit_shape_wg"), xs.last_kernel()
+            assert np.array_equal(dc.cpu().numpy(), ref), (shape, beta, flags)
+        # index batch with shuffled operands; the caller promises distinct C (negative batchsize)
+        a = rng.uniform(-1, 1, batch * m * k).astype(dtype); b = rng.uniform(-1, 1, batch * k * n).astype(dtype); c = rng.uniform(-1, 1, batch * m * n).astype(dtype)
+        sa = (rng.permutation(batch) * m * k).astype(np.int32); sb = (rng.permutation(batch) * k * n).astype(np.int32); sc = (rng.permutation(batch) * m * n).astype(np.int32)
+        ref = c.copy()
+        assert 0 == orc.gemm_batch_idx(orc.FMA, 0, m, n, k, m, k, m, a, b, ref, 0, sa, sb, sc, batch)
+        da, db, dc = (torch.from_numpy(x).cuda() for x in (a, b, c))
+        xs.gemm_batch(prec, "N", "N", m, n, k, 1.0, da, m, db, k, 1.0, dc, m, 0, 4, sa, sb, sc, -batch)
+        torch.cuda.synchronize()
+        assert xs.last_kernel().endswith("_jit_shape_wg"), xs.last_kernel()
+        assert np.array_equal(dc.cpu().numpy(), ref)

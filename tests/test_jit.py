@@ -246,3 +246,45 @@ def test_jit_work_group_form_for_shapes_up_to_64(xs, orc, torch_gpu, dtype, shap
         torch.cuda.synchronize()
         assert xs.last_kernel().endswith("_jit_shape_wg"), xs.last_kernel()
         assert np.array_equal(dc.cpu().numpy(), ref)
+
+
+@pytest.mark.gpu
+def test_batch_calls_are_graph_capturable(xs, orc, torch_gpu):
+    """A batch call makes no host round trip (the C-ordering verdict stays on the device), so a sequence of calls can be
+    captured in a HIP graph and replayed: CP2K-style stacks (runs of equal C) of two shapes, replayed twice."""
+    torch = torch_gpu
+    rng = np.random.default_rng(21)
+    groups = []
+    for (m, n, k, batch, nc) in ((23, 23, 23, 500, 9), (13, 32, 23, 400, 400)):
+        a = rng.uniform(-1, 1, batch * m * k); b = rng.uniform(-1, 1, batch * k * n); c = rng.uniform(-1, 1, nc * m * n)
+        cidx = np.sort(rng.integers(0, nc, batch)) if nc < batch else np.arange(batch)
+        sa = (np.arange(batch) * m * k).astype(np.int32); sb = (np.arange(batch) * k * n).astype(np.int32); sc = (cidx * m * n).astype(np.int32)
+        dev = [torch.from_numpy(x).cuda() for x in (a, b, c, sa, sb, sc)]
+        groups.append((m, n, k, batch, a, b, c, sa, sb, sc, dev))
+
+    def calls():
+        for (m, n, k, batch, a, b, c, sa, sb, sc, dev) in groups:
+            xs.gemm_batch(xs.F64, "N", "N", m, n, k, 1.0, dev[0], m, dev[1], k, 1.0, dev[2], m, 0, 4, dev[3], dev[4], dev[5], batch)
+
+    L = xs.lib()
+    with _JitForced(xs):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        old_stream = L.libxsmm_amd_get_stream()
+        try:
+            with torch.cuda.stream(side):
+                L.libxsmm_amd_set_stream(C.c_void_p(side.cuda_stream))
+                calls()  # warm-up outside the capture: kernels get compiled and loaded, the flag ring is allocated
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=side):
+                    calls()
+                graph.replay(); graph.replay()
+                torch.cuda.synchronize()
+        finally:
+            L.libxsmm_amd_set_stream(C.c_void_p(old_stream))
+    for (m, n, k, batch, a, b, c, sa, sb, sc, dev) in groups:
+        ref = c.copy()
+        for _ in range(3):  # warm-up + two replays (capturing itself does not execute)
+            assert 0 == orc.gemm_batch_idx(orc.FMA, 0, m, n, k, m, k, m, a, b, ref, 0, sa, sb, sc, batch)
+        assert np.array_equal(dev[2].cpu().numpy(), ref)

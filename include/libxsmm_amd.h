@@ -16,7 +16,9 @@
 /* ---- device / stream ------------------------------------------------------------------------ */
 /** Number of usable HIP devices (0: none; every compute entry point then fails loudly). */
 LIBXSMM_API int libxsmm_amd_device_count(void);
-/** HIP stream (hipStream_t) on which device-resident work is enqueued; NULL selects the default stream. */
+/** HIP stream (hipStream_t) on which the calling thread's device-resident work is enqueued; NULL selects the default
+ *  stream. The setting is per thread (every entry point may be called from any thread): independent batches can be put
+ *  on different streams, by one thread switching streams between calls or by several threads. */
 LIBXSMM_API void libxsmm_amd_set_stream(void* hip_stream);
 LIBXSMM_API void* libxsmm_amd_get_stream(void);
 /** Block until all work enqueued by this library on its stream has completed. Returns EXIT_SUCCESS/FAILURE. */

@@ -21,7 +21,9 @@ struct Scratch { void* ptr = nullptr; size_t size = 0; void* stream = nullptr; b
 thread_local Scratch tl_scratch[8];
 }
 
-Device& device() { return g_device; }
+// The engine's current stream is a per-thread setting (every entry point may be called from any thread, as in the
+// reference; a thread that never calls libxsmm_amd_set_stream launches on the default stream).
+Device& device() { thread_local Device tl_device; tl_device.count = g_device.count; return tl_device; }
 
 bool device_ready()
 {
@@ -63,18 +65,18 @@ void dev_free(void* p) { if (nullptr != p) (void)hipFree(p); }
 int h2d(void* dst, const void* src, size_t bytes)
 {
   if (0 == bytes) return 0;
-  return (int)hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)g_device.stream);
+  return (int)hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)device().stream);
 }
 
 int d2h(void* dst, const void* src, size_t bytes)
 {
   if (0 == bytes) return 0;
-  hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)g_device.stream);
-  if (hipSuccess == e) e = hipStreamSynchronize((hipStream_t)g_device.stream);
+  hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)device().stream);
+  if (hipSuccess == e) e = hipStreamSynchronize((hipStream_t)device().stream);
   return (int)e;
 }
 
-int stream_sync() { return (int)hipStreamSynchronize((hipStream_t)g_device.stream); }
+int stream_sync() { return (int)hipStreamSynchronize((hipStream_t)device().stream); }
 
 void note_launch(const char* name)
 {
@@ -104,7 +106,7 @@ void* scratch(int slot, size_t bytes)
   // (Scratch only serves the staging of host-resident operands -- the compatibility path -- so the wait costs nothing
   // on the device-resident path.)
   if (s.used) (void)hipStreamSynchronize((hipStream_t)s.stream);
-  s.stream = g_device.stream; s.used = true;
+  s.stream = device().stream; s.used = true;
   if (s.size < bytes) {
     if (nullptr != s.ptr) (void)hipFree(s.ptr);
     s.ptr = nullptr; s.size = 0;

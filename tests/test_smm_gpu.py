@@ -314,3 +314,50 @@ def test_host_operands_are_staged(xs, orc, torch_gpu):
         assert np.array_equal(out2, ref)
     finally:
         xs.lib().libxsmm_amd_set_mfma(old)
+
+
+def test_concurrent_threads_with_their_own_streams(xs, orc, torch_gpu):
+    """Every entry point may be called from any thread (reference tests/threadsafety.c); the engine's stream is a per-thread
+    setting, so threads can overlap independent batches on the GPU. Four threads, four shapes, stacks with runs of equal C."""
+    import threading
+    torch = torch_gpu
+    shapes = [(23, 23, 23), (13, 32, 5), (32, 32, 32), (7, 9, 11)]
+    results, errors = {}, []
+
+    def work(tid, shape):
+        try:
+            m, n, k = shape
+            batch, nc = 700 + 13 * tid, 31
+            rng = np.random.default_rng(100 + tid)
+            a = rng.uniform(-1, 1, batch * m * k); b = rng.uniform(-1, 1, batch * k * n); c = rng.uniform(-1, 1, nc * m * n)
+            cidx = np.sort(rng.integers(0, nc, batch))
+            sa = (np.arange(batch) * m * k).astype(np.int32); sb = (np.arange(batch) * k * n).astype(np.int32); sc = (cidx * m * n).astype(np.int32)
+            ref = c.copy()
+            for _ in range(3):
+                orc.gemm_batch_idx(orc.FMA, 0, m, n, k, m, k, m, a, b, ref, 0, sa, sb, sc, batch)
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                da, db, dc = (torch.from_numpy(x).cuda() for x in (a, b, c))
+                dia, dib, dic = (torch.from_numpy(x).cuda() for x in (sa, sb, sc))
+                stream.synchronize()
+                xs.lib().libxsmm_amd_set_stream(C.c_void_p(stream.cuda_stream))
+                for _ in range(3):
+                    xs.gemm_batch(xs.F64, "N", "N", m, n, k, 1.0, da, m, db, k, 1.0, dc, m, 0, 4, dia, dib, dic, batch)
+                stream.synchronize()
+                results[tid] = (dc.cpu().numpy(), ref)
+        except Exception as exc:  # surfaced in the main thread
+            errors.append(repr(exc))
+
+    old = xs.lib().libxsmm_amd_set_mfma(0)
+    try:
+        threads = [threading.Thread(target=work, args=(i, s)) for i, s in enumerate(shapes)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+    finally:
+        xs.lib().libxsmm_amd_set_mfma(old)
+    assert not errors, errors
+    for tid in range(len(shapes)):
+        out, ref = results[tid]
+        assert np.array_equal(out, ref), tid

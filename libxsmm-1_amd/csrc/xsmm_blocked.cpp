@@ -119,6 +119,7 @@ int bgemm_copy(const libxsmm_blocked_gemm_handle* h, int which, const void* src,
   if (0 != e) return EXIT_FAILURE;
   if (dst_host) return 0 == d2h(dst, dd, dst_bytes) ? EXIT_SUCCESS : EXIT_FAILURE;
   if (src_host) return 0 == stream_sync() ? EXIT_SUCCESS : EXIT_FAILURE;
+  settle(src, dst);
   return EXIT_SUCCESS;
 }
 }
@@ -144,6 +145,7 @@ int bgemm_permute(const libxsmm_blocked_gemm_handle* h, int which, const void* s
   if (0 != e) return EXIT_FAILURE;
   if (dst_host) return 0 == d2h(dst, dd, bytes) ? EXIT_SUCCESS : EXIT_FAILURE;
   if (src_host) return 0 == stream_sync() ? EXIT_SUCCESS : EXIT_FAILURE;
+  settle(src, dst);
   return EXIT_SUCCESS;
 }
 }
@@ -180,6 +182,7 @@ void bgemm_run(const libxsmm_blocked_gemm_handle* h, const void* a, const void* 
   if (0 != e) { fprintf(stderr, "LIBXSMM-AMD ERROR: kernel launch failed (%s, hip error %d)\n", name, e); return; }
   if (c_host) (void)d2h(c, dc, ec);
   else if (da != a || db != b) (void)stream_sync();
+  else settle(a, b, c);
 }
 }
 

@@ -52,6 +52,22 @@ bool is_device_ptr(const void* p)
       || hipMemoryTypeArray == attr.type;
 }
 
+bool is_host_visible(const void* p)
+{ // pinned host memory (libxsmm_malloc, hipHostMalloc) and managed memory: the GPU works on it in place, the CPU may read it
+  if (nullptr == p || !device_ready()) return false;
+  hipPointerAttribute_t attr;
+  memset(&attr, 0, sizeof(attr));
+  if (hipSuccess != hipPointerGetAttributes(&attr, p)) { (void)hipGetLastError(); return false; }
+  return hipMemoryTypeHost == attr.type || hipMemoryTypeManaged == attr.type;
+}
+
+void settle(const void* p0, const void* p1, const void* p2)
+{ // Work on device memory stays asynchronous (the caller needs a copy or a synchronisation to touch it anyway). Operands
+  // in memory the CPU addresses directly (libxsmm_malloc / pinned / managed) must be done with when the call returns: an
+  // unchanged CPU caller reads the result, or overwrites an input, next.
+  if (is_host_visible(p0) || is_host_visible(p1) || is_host_visible(p2)) (void)stream_sync();
+}
+
 void* dev_alloc(size_t bytes)
 {
   void* p = nullptr;

@@ -37,6 +37,12 @@ int run_smm(const SmmBatch& s)
   if (e < 0) e = launch_smm_generic(s, device().stream, &name);                     // any descriptor
   note_launch(name);
   if (0 != e) fprintf(stderr, "LIBXSMM-AMD ERROR: kernel launch failed (%s, hip error %d)\n", name, e);
+  else if (ADDR_POINTER == s.mode) { // arrays of pointers: look at the first operands if the arrays can be read here
+    if (is_host_visible(s.a) && is_host_visible(s.b) && is_host_visible(s.c)) {
+      settle(*static_cast<const void* const*>(s.a), *static_cast<const void* const*>(s.b), *static_cast<void* const*>(s.c));
+    }
+  }
+  else settle(s.a, s.b, s.c);
   return e;
 }
 
@@ -325,6 +331,7 @@ void call_kernel(Kernel* k, const void* a, const void* b, void* c, const void* x
       p.b = b; p.c = c;
       const int e = launch_csr_panels(p, device().stream, &name); note_launch(name);
       if (0 != e) fprintf(stderr, "LIBXSMM-AMD ERROR: kernel launch failed (%s, hip error %d)\n", name, e);
+      else settle(b, c);
     }
     else {
       const size_t eb = (size_t)(p.k - 1) * p.ldb + p.n, ec = (size_t)(p.m - 1) * p.ldc + p.n;

@@ -571,6 +571,7 @@ LIBXSMM_API int libxsmm_amd_spgemm_execute_batch(const libxsmm_amd_spgemm* handl
   if (0 != e) return EXIT_FAILURE;
   if (c_host) return 0 == d2h(c, dc, bytes_c) ? EXIT_SUCCESS : EXIT_FAILURE;
   if (dv != sparse_values || dd != dense) return 0 == stream_sync() ? EXIT_SUCCESS : EXIT_FAILURE; // staged inputs must have landed
+  settle(sparse_values, dense, c);
   return EXIT_SUCCESS;
 }
 

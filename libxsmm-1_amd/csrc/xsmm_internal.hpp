@@ -128,6 +128,8 @@ Device& device();
 bool device_ready();                      // probes once; false if no HIP device
 void fail_no_device(const char* what);    // prints a loud error (always) -- the product has no CPU compute path
 bool is_device_ptr(const void* p);
+bool is_host_visible(const void* p);      // pinned host or managed memory (processed in place, but the CPU reads it directly)
+void settle(const void* p0, const void* p1 = nullptr, const void* p2 = nullptr); // wait for the stream if an operand is host-visible
 int* flag_slot();                         // device int[4] for one batch call's C-ordering verdict (nullptr: out of memory)
 void* dev_alloc(size_t bytes);
 void dev_free(void* p);

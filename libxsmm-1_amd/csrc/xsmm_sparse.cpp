@@ -122,7 +122,7 @@ int fsspmdm_run(const H* h, const T* B, T* C, long long batch)
     const int e = launch_csr_panels(p, device().stream, &name); note_launch(name);
     return e;
   };
-  if (is_device_ptr(B) && is_device_ptr(C)) return 0 == launch(B, C) ? EXIT_SUCCESS : EXIT_FAILURE;
+  if (is_device_ptr(B) && is_device_ptr(C)) { const int e = launch(B, C); if (0 == e) settle(B, C); return 0 == e ? EXIT_SUCCESS : EXIT_FAILURE; }
   // host panels: stage rows [0,K) x columns [0, N*batch) of B and rows [0,M) of C (strided by ldb/ldc)
   const long long ncols = (long long)h->N * batch;
   const size_t eb = (size_t)(h->K - 1) * h->ldb + ncols, ec = (size_t)(h->M - 1) * h->ldc + ncols;
@@ -306,6 +306,7 @@ void spmdm_compute_block(const libxsmm_spmdm_handle* handle, int tb, int tc, flo
     }
   }
   else if (sync_inputs) (void)stream_sync(); // staged inputs are reused by the next call
+  else settle(db, c);
 }
 }
 
@@ -320,6 +321,7 @@ LIBXSMM_API void libxsmm_spmdm_createSparseSlice_fp32_thread(const libxsmm_spmdm
   if (!ok) return;
   spmdm_create_block(handle, ('T' == transa || 't' == transa), da, block_id);
   if (da != a) (void)stream_sync(); // the staging buffer is reused by the next call
+  else settle(a);
 }
 
 LIBXSMM_API void libxsmm_spmdm_createSparseSlice_bfloat16_thread(const libxsmm_spmdm_handle* handle, char transa,
@@ -405,6 +407,7 @@ LIBXSMM_API int libxsmm_amd_spmdm_batch_create_slices(libxsmm_amd_spmdm_batch* s
   const char* name = "";
   const int e = launch_spmdm_create(sb->g, ('T' == transa || 't' == transa) ? 1 : 0, a, sb->rowidx, sb->colidx, sb->values, device().stream, &name);
   note_launch(name);
+  if (0 == e) settle(a);
   return 0 == e ? EXIT_SUCCESS : EXIT_FAILURE;
 }
 
@@ -416,6 +419,7 @@ LIBXSMM_API int libxsmm_amd_spmdm_batch_compute(libxsmm_amd_spmdm_batch* sb, cha
   const int e = launch_spmdm_compute(sb->g, ('T' == transb || 't' == transb) ? 1 : 0, ('T' == transc || 't' == transc) ? 1 : 0, *beta,
     sb->rowidx, sb->colidx, sb->values, b, c, device().stream, &name);
   note_launch(name);
+  if (0 == e) settle(b, c);
   return 0 == e ? EXIT_SUCCESS : EXIT_FAILURE;
 }
 

@@ -1,0 +1,21 @@
+"""Callers written in C against the reference API only (examples/*.c: the flows of samples/smm/specialized.cpp,
+samples/cp2k/cp2k.cpp and samples/spmdm/spmdm.c) are compiled with gcc, linked against libxsmm.so and run on the GPU
+box: the drop-in claim, end to end. They check themselves against plain loops and return 0."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", ["smm_caller", "spmdm_caller"])
+def test_c_caller_runs_on_the_gpu(xs, torch_gpu, tmp_path, name):
+    libdir = os.path.dirname(xs.LIB_PATH)
+    exe = tmp_path / name
+    subprocess.run(["gcc", "-std=c99", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", name + ".c"),
+                    "-o", str(exe), "-L", libdir, "-lxsmm", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-lm"], check=True)
+    res = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, (res.returncode, res.stdout, res.stderr)
+    assert name in res.stdout

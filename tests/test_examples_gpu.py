@@ -1,5 +1,5 @@
 """Callers written in C against the reference API only (examples/*.c: the flows of samples/smm/specialized.cpp,
-samples/cp2k/cp2k.cpp and samples/spmdm/spmdm.c) are compiled with gcc, linked against libxsmm.so and run on the GPU
+samples/cp2k/cp2k.cpp, samples/spmdm/spmdm.c, samples/pyfr/pyfr_driver_asp_reg.c and samples/blocked_gemm/blocked_gemm.c) are compiled with gcc, linked against libxsmm.so and run on the GPU
 box: the drop-in claim, end to end. They check themselves against plain loops and return 0."""
 import os
 import subprocess
@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name", ["smm_caller", "spmdm_caller"])
+@pytest.mark.parametrize("name", ["smm_caller", "spmdm_caller", "pyfr_caller", "blocked_caller"])
 def test_c_caller_runs_on_the_gpu(xs, torch_gpu, tmp_path, name):
     libdir = os.path.dirname(xs.LIB_PATH)
     exe = tmp_path / name

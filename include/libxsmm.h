@@ -602,6 +602,53 @@ LIBXSMM_API void libxsmm_gemm_print2(void* ostream, libxsmm_gemm_precision iprec
   const void* alpha, const void* a, const libxsmm_blasint* lda, const void* b, const libxsmm_blasint* ldb,
   const void* beta, void* c, const libxsmm_blasint* ldc);
 
+#if defined(__cplusplus)
+/* ---------------------------------------------------------------------------------------------
+ * C++ convenience layer used by the C++ programs under samples/smm (src/template/libxsmm.h:416-511): precision traits and the
+ * libxsmm_mmfunction<> functor (dispatch in the constructor, call through operator()).
+ * --------------------------------------------------------------------------------------------- */
+template<typename T> struct libxsmm_gemm_precision_enum { static const libxsmm_gemm_precision value = static_cast<libxsmm_gemm_precision>(LIBXSMM_DATATYPE_UNSUPPORTED); };
+template<> struct libxsmm_gemm_precision_enum<double> { static const libxsmm_gemm_precision value = LIBXSMM_GEMM_PRECISION_F64; };
+template<> struct libxsmm_gemm_precision_enum<float> { static const libxsmm_gemm_precision value = LIBXSMM_GEMM_PRECISION_F32; };
+template<> struct libxsmm_gemm_precision_enum<int> { static const libxsmm_gemm_precision value = LIBXSMM_GEMM_PRECISION_I32; };
+template<> struct libxsmm_gemm_precision_enum<short> { static const libxsmm_gemm_precision value = LIBXSMM_GEMM_PRECISION_I16; };
+template<> struct libxsmm_gemm_precision_enum<libxsmm_bfloat16> { static const libxsmm_gemm_precision value = LIBXSMM_GEMM_PRECISION_BF16; };
+template<typename INP_TYPE> struct libxsmm_gemm_default_output { typedef INP_TYPE type; };
+template<> struct libxsmm_gemm_default_output<short> { typedef int type; };
+
+template<typename INP_TYPE, typename OUT_TYPE = typename libxsmm_gemm_default_output<INP_TYPE>::type>
+class libxsmm_mmfunction {
+  mutable libxsmm_xmmfunction m_function;
+  void dispatch(int flags, libxsmm_blasint m, libxsmm_blasint n, libxsmm_blasint k, libxsmm_blasint lda, libxsmm_blasint ldb, libxsmm_blasint ldc,
+                const OUT_TYPE* alpha, const OUT_TYPE* beta, int prefetch) {
+    libxsmm_descriptor_blob blob;
+    const int strategy = (0 > prefetch ? (int)libxsmm_get_gemm_auto_prefetch() : prefetch); /* recorded, no effect on gfx950 */
+    const libxsmm_gemm_descriptor* const desc = libxsmm_gemm_descriptor_init2(&blob,
+      libxsmm_gemm_precision_enum<INP_TYPE>::value, libxsmm_gemm_precision_enum<OUT_TYPE>::value,
+      m, n, k, lda, ldb, ldc, alpha, beta, flags, strategy);
+    m_function.xmm = (0 != desc ? libxsmm_xmmdispatch(desc).xmm : 0);
+  }
+public:
+  typedef INP_TYPE itype;
+  typedef OUT_TYPE otype;
+  libxsmm_mmfunction() { m_function.xmm = 0; }
+  libxsmm_mmfunction(libxsmm_blasint m, libxsmm_blasint n, libxsmm_blasint k, int flags = LIBXSMM_FLAGS) { dispatch(flags, m, n, k, m, k, m, 0, 0, LIBXSMM_PREFETCH); }
+  libxsmm_mmfunction(int flags, libxsmm_blasint m, libxsmm_blasint n, libxsmm_blasint k, int prefetch) { dispatch(flags, m, n, k, m, k, m, 0, 0, prefetch); }
+  libxsmm_mmfunction(int flags, libxsmm_blasint m, libxsmm_blasint n, libxsmm_blasint k, otype alpha, otype beta) { dispatch(flags, m, n, k, m, k, m, &alpha, &beta, LIBXSMM_PREFETCH); }
+  libxsmm_mmfunction(int flags, libxsmm_blasint m, libxsmm_blasint n, libxsmm_blasint k, otype alpha, otype beta, int prefetch) { dispatch(flags, m, n, k, m, k, m, &alpha, &beta, prefetch); }
+  libxsmm_mmfunction(int flags, libxsmm_blasint m, libxsmm_blasint n, libxsmm_blasint k,
+    libxsmm_blasint lda, libxsmm_blasint ldb, libxsmm_blasint ldc, int prefetch) { dispatch(flags, m, n, k, lda, ldb, ldc, 0, 0, prefetch); }
+  libxsmm_mmfunction(int flags, libxsmm_blasint m, libxsmm_blasint n, libxsmm_blasint k,
+    libxsmm_blasint lda, libxsmm_blasint ldb, libxsmm_blasint ldc, otype alpha, otype beta) { dispatch(flags, m, n, k, lda, ldb, ldc, &alpha, &beta, LIBXSMM_PREFETCH); }
+  libxsmm_mmfunction(int flags, libxsmm_blasint m, libxsmm_blasint n, libxsmm_blasint k,
+    libxsmm_blasint lda, libxsmm_blasint ldb, libxsmm_blasint ldc, otype alpha, otype beta, int prefetch) { dispatch(flags, m, n, k, lda, ldb, ldc, &alpha, &beta, prefetch); }
+  const libxsmm_xmmfunction& kernel() const { return m_function; }
+  operator const void*() const { return 0 != m_function.xmm ? this : 0; }
+  void operator()(const itype* a, const itype* b, otype* c) const { LIBXSMM_MMCALL_ABC(m_function.xmm, a, b, c); }
+  void operator()(const itype* a, const itype* b, otype* c, const itype* pa, const itype* pb, const otype* pc) const { LIBXSMM_MMCALL_PRF(m_function.xmm, a, b, c, pa, pb, pc); }
+};
+#endif /* __cplusplus */
+
 #include "libxsmm_amd.h"
 
 #endif /* LIBXSMM_H */

@@ -10,12 +10,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name", ["smm_caller", "spmdm_caller", "pyfr_caller", "blocked_caller"])
+@pytest.mark.parametrize("name", ["smm_caller.c", "spmdm_caller.c", "pyfr_caller.c", "blocked_caller.c", "smm_functor.cpp"])
 def test_c_caller_runs_on_the_gpu(xs, torch_gpu, tmp_path, name):
     libdir = os.path.dirname(xs.LIB_PATH)
-    exe = tmp_path / name
-    subprocess.run(["gcc", "-std=c99", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", name + ".c"),
-                    "-o", str(exe), "-L", libdir, "-lxsmm", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-lm"], check=True)
+    exe = tmp_path / name.split(".")[0]
+    cc = ["gcc", "-std=c99"] if name.endswith(".c") else ["g++", "-std=c++11"]
+    subprocess.run(cc + ["-O1", "-Wall", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", name),
+                         "-o", str(exe), "-L", libdir, "-lxsmm", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-lm"], check=True)
     res = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, (res.returncode, res.stdout, res.stderr)
-    assert name in res.stdout
+    assert name.split(".")[0] in res.stdout

@@ -438,6 +438,15 @@ LIBXSMM_API void libxsmm_sgemm(const char* transa, const char* transb,
   const libxsmm_blasint* m, const libxsmm_blasint* n, const libxsmm_blasint* k,
   const float* alpha, const float* a, const libxsmm_blasint* lda, const float* b, const libxsmm_blasint* ldb,
   const float* beta, float* c, const libxsmm_blasint* ldc);
+/* the library's BLAS fallback entry points (src/template/libxsmm.h:402-414); here: the engine's general-form kernel */
+LIBXSMM_API void libxsmm_blas_dgemm(const char* transa, const char* transb,
+  const libxsmm_blasint* m, const libxsmm_blasint* n, const libxsmm_blasint* k,
+  const double* alpha, const double* a, const libxsmm_blasint* lda, const double* b, const libxsmm_blasint* ldb,
+  const double* beta, double* c, const libxsmm_blasint* ldc);
+LIBXSMM_API void libxsmm_blas_sgemm(const char* transa, const char* transb,
+  const libxsmm_blasint* m, const libxsmm_blasint* n, const libxsmm_blasint* k,
+  const float* alpha, const float* a, const libxsmm_blasint* lda, const float* b, const libxsmm_blasint* ldb,
+  const float* beta, float* c, const libxsmm_blasint* ldc);
 
 /* ---------------------------------------------------------------------------------------------
  * fsspmdm -- fixed-sparsity operator times dense panels (include/libxsmm_fsspmdm.h:37-58)
@@ -602,6 +611,84 @@ LIBXSMM_API void libxsmm_gemm_print2(void* ostream, libxsmm_gemm_precision iprec
   const void* alpha, const void* a, const libxsmm_blasint* lda, const void* b, const libxsmm_blasint* ldb,
   const void* beta, void* c, const libxsmm_blasint* ldc);
 
+/* ---------------------------------------------------------------------------------------------
+ * Frontend conveniences the reference's sample programs lean on (include/libxsmm_macros.h, include/libxsmm_frontend.h,
+ * include/libxsmm_cpuid.h:40-52, include/libxsmm_timer.h:36): type-name pasting, pragmas, multi-dimensional views.
+ * Own definitions with the reference's names and meaning.
+ * --------------------------------------------------------------------------------------------- */
+#define LIBXSMM_X86_GENERIC 1002
+#define LIBXSMM_X86_SSE3 1003
+#define LIBXSMM_X86_SSE4 1004
+#define LIBXSMM_X86_AVX 1005
+#define LIBXSMM_X86_AVX2 1006
+#define LIBXSMM_X86_AVX512 1007
+#define LIBXSMM_X86_AVX512_MIC 1010
+#define LIBXSMM_X86_AVX512_KNM 1011
+#define LIBXSMM_X86_AVX512_CORE 1020
+#define LIBXSMM_X86_AVX512_CLX 1021
+#define LIBXSMM_X86_AVX512_CPX 1022
+#define libxsmm_timer_diff(TICK0, TICK1) libxsmm_timer_cycles(TICK0, TICK1)
+#define LIBXSMM_GEMM_CONST const
+#define LIBXSMM_PRAGMA(DIRECTIVE) _Pragma(LIBXSMM_STRINGIFY(DIRECTIVE))
+#define LIBXSMM_PRAGMA_SIMD
+#define LIBXSMM_PRAGMA_UNROLL
+#define LIBXSMM_PRAGMA_UNROLL_N(N)
+#define LIBXSMM_PRAGMA_LOOP_COUNT(MIN, MAX, AVG)
+#define LIBXSMM_PRAGMA_NONTEMPORAL
+#define LIBXSMM_OPENMP_COLLAPSE(N) collapse(N)
+#define LIBXSMM_OMP_VAR(A) LIBXSMM_UNUSED(A)
+#define LIBXSMM_VERSION2(MAJOR, MINOR) ((MAJOR) * 10000 + (MINOR) * 100)
+#define LIBXSMM_VERSION3(MAJOR, MINOR, UPDATE) (LIBXSMM_VERSION2(MAJOR, MINOR) + (UPDATE))
+/* d/s prefixes and type predicates: LIBXSMM_MMFUNCTION_TYPE(double) -> libxsmm_dmmfunction, LIBXSMM_EQUAL(float, float) -> 1 */
+#define LIBXSMM_TPREFIX_double d
+#define LIBXSMM_TPREFIX_float s
+#define LIBXSMM_TPREFIX(TYPE, FUNCTION) LIBXSMM_CONCATENATE(LIBXSMM_CONCATENATE(LIBXSMM_TPREFIX_, TYPE), FUNCTION)
+#define LIBXSMM_MMFUNCTION_TYPE(TYPE) LIBXSMM_CONCATENATE(libxsmm_, LIBXSMM_TPREFIX(TYPE, mmfunction))
+#define LIBXSMM_MMDISPATCH_SYMBOL(TYPE) LIBXSMM_CONCATENATE(libxsmm_, LIBXSMM_TPREFIX(TYPE, mmdispatch))
+#define LIBXSMM_XGEMM_SYMBOL(TYPE) LIBXSMM_CONCATENATE(libxsmm_, LIBXSMM_TPREFIX(TYPE, gemm))
+#define LIBXSMM_XBLAS_SYMBOL(TYPE) LIBXSMM_CONCATENATE(libxsmm_blas_, LIBXSMM_TPREFIX(TYPE, gemm))
+#define LIBXSMM_EQUAL_doubledouble 1
+#define LIBXSMM_EQUAL_floatfloat 1
+#define LIBXSMM_EQUAL_doublefloat 0
+#define LIBXSMM_EQUAL_floatdouble 0
+#define LIBXSMM_EQUAL(T1, T2) LIBXSMM_CONCATENATE(LIBXSMM_CONCATENATE(LIBXSMM_EQUAL_, T1), T2)
+#define LIBXSMM_TYPEINFO_FP_double 1
+#define LIBXSMM_TYPEINFO_FP_float 1
+#define LIBXSMM_TYPEINFO_FP_int 0
+#define LIBXSMM_TYPEINFO_FP_short 0
+#define LIBXSMM_TYPEINFO_FP_char 0
+#define LIBXSMM_TYPEINFO(TYPE, INFO) LIBXSMM_CONCATENATE(LIBXSMM_CONCATENATE(LIBXSMM_CONCATENATE(LIBXSMM_TYPEINFO_, INFO), _), TYPE)
+/* LIBXSMM_INLINE_XGEMM / LIBXSMM_XGEMM / LIBXSMM_BLAS_XGEMM: one GEMM for a type given as a token (the reference inlines
+ * CPU loops for the first; there is no CPU compute path here, all three reach the engine) */
+#define LIBXSMM_XGEMM(ITYPE, OTYPE, TRANSA, TRANSB, M, N, K, ALPHA, A, LDA, B, LDB, BETA, C, LDC) \
+  LIBXSMM_XGEMM_SYMBOL(ITYPE)(TRANSA, TRANSB, M, N, K, ALPHA, A, LDA, B, LDB, BETA, C, LDC)
+#define LIBXSMM_INLINE_XGEMM LIBXSMM_XGEMM
+#define LIBXSMM_BLAS_XGEMM(ITYPE, OTYPE, TRANSA, TRANSB, M, N, K, ALPHA, A, LDA, B, LDB, BETA, C, LDC) \
+  LIBXSMM_XBLAS_SYMBOL(ITYPE)(TRANSA, TRANSB, M, N, K, ALPHA, A, LDA, B, LDB, BETA, C, LDC)
+/* Fortran BLAS symbols some samples use for their gold results (a BLAS library must then be linked by the sample) */
+#define LIBXSMM_GEMM_SYMBOL(TYPE) LIBXSMM_CONCATENATE(LIBXSMM_TPREFIX(TYPE, gemm), _)
+#define LIBXSMM_BLAS_SYMBOL_DECL(TYPE, KIND) LIBXSMM_EXTERN_C void LIBXSMM_CONCATENATE(LIBXSMM_TPREFIX(TYPE, KIND), _)( \
+  const char*, const char*, const libxsmm_blasint*, const libxsmm_blasint*, const libxsmm_blasint*, const TYPE*, const TYPE*, \
+  const libxsmm_blasint*, const TYPE*, const libxsmm_blasint*, const TYPE*, TYPE*, const libxsmm_blasint*);
+/* Views of a flat array as an N-dimensional one (N <= 5): LIBXSMM_VLA_DECL(3, T, v, ptr, d1, d2) then
+ * LIBXSMM_VLA_ACCESS(3, v, i0, i1, i2, d1, d2) is ptr[(i0*d1 + i1)*d2 + i2] (row-major, the leading extent is implied). */
+#define LIBXSMM_VLA_POSTFIX _
+#define LIBXSMM_VLA_DECL(NDIMS, ELEMENT_TYPE, ARRAY_VAR, ...) \
+  ELEMENT_TYPE *LIBXSMM_RESTRICT LIBXSMM_CONCATENATE(ARRAY_VAR, LIBXSMM_VLA_POSTFIX) = LIBXSMM_VLA_INIT(__VA_ARGS__, 0)
+#define LIBXSMM_VLA_INIT(INIT, ...) INIT
+#define LIBXSMM_VLA_INDEX_1(I0) ((size_t)(I0))
+#define LIBXSMM_VLA_INDEX_2(I0, I1, S1) ((size_t)(I0) * (S1) + (I1))
+#define LIBXSMM_VLA_INDEX_3(I0, I1, I2, S1, S2) (LIBXSMM_VLA_INDEX_2(I0, I1, S1) * (S2) + (I2))
+#define LIBXSMM_VLA_INDEX_4(I0, I1, I2, I3, S1, S2, S3) (LIBXSMM_VLA_INDEX_3(I0, I1, I2, S1, S2) * (S3) + (I3))
+#define LIBXSMM_VLA_INDEX_5(I0, I1, I2, I3, I4, S1, S2, S3, S4) (LIBXSMM_VLA_INDEX_4(I0, I1, I2, I3, S1, S2, S3) * (S4) + (I4))
+#define LIBXSMM_VLA_ACCESS(NDIMS, ARRAY, ...) \
+  LIBXSMM_CONCATENATE(ARRAY, LIBXSMM_VLA_POSTFIX)[LIBXSMM_CONCATENATE(LIBXSMM_VLA_INDEX_, NDIMS)(__VA_ARGS__)]
+#if defined(__cplusplus)
+# define LIBXSMM_RESTRICT __restrict__
+#else
+# define LIBXSMM_RESTRICT restrict
+#endif
+
 #if defined(__cplusplus)
 /* ---------------------------------------------------------------------------------------------
  * C++ convenience layer used by the C++ programs under samples/smm (src/template/libxsmm.h:416-511): precision traits and the
@@ -647,6 +734,18 @@ public:
   void operator()(const itype* a, const itype* b, otype* c) const { LIBXSMM_MMCALL_ABC(m_function.xmm, a, b, c); }
   void operator()(const itype* a, const itype* b, otype* c, const itype* pa, const itype* pb, const otype* pc) const { LIBXSMM_MMCALL_PRF(m_function.xmm, a, b, c, pa, pb, pc); }
 };
+/* overloads by element type, m/n/k by pointer or by value (src/template/libxsmm.h:619-720) */
+#define LIBXSMM_CXX_GEMM(NAME, TYPE, TARGET) \
+inline void NAME(const char* transa, const char* transb, const libxsmm_blasint* m, const libxsmm_blasint* n, const libxsmm_blasint* k, \
+  const TYPE* alpha, const TYPE* a, const libxsmm_blasint* lda, const TYPE* b, const libxsmm_blasint* ldb, const TYPE* beta, TYPE* c, const libxsmm_blasint* ldc) \
+{ TARGET(transa, transb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc); } \
+inline void NAME(const char* transa, const char* transb, libxsmm_blasint m, libxsmm_blasint n, libxsmm_blasint k, \
+  const TYPE* alpha, const TYPE* a, const libxsmm_blasint* lda, const TYPE* b, const libxsmm_blasint* ldb, const TYPE* beta, TYPE* c, const libxsmm_blasint* ldc) \
+{ TARGET(transa, transb, &m, &n, &k, alpha, a, lda, b, ldb, beta, c, ldc); }
+LIBXSMM_CXX_GEMM(libxsmm_gemm, double, libxsmm_dgemm)
+LIBXSMM_CXX_GEMM(libxsmm_gemm, float, libxsmm_sgemm)
+LIBXSMM_CXX_GEMM(libxsmm_blas_gemm, double, libxsmm_blas_dgemm)
+LIBXSMM_CXX_GEMM(libxsmm_blas_gemm, float, libxsmm_blas_sgemm)
 #endif /* __cplusplus */
 
 #include "libxsmm_amd.h"

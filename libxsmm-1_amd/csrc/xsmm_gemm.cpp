@@ -555,6 +555,20 @@ LIBXSMM_API void libxsmm_sgemm(const char* transa, const char* transb,
   const float* beta, float* c, const libxsmm_blasint* ldc)
 { xgemm<float>(LIBXSMM_GEMM_PRECISION_F32, transa, transb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc); }
 
+// libxsmm_blas_?gemm (reference src/libxsmm_gemm.c:703-760): "the BLAS the library falls back to". There is no host BLAS
+// behind this engine; the general-form kernel (any alpha/beta/transposes) is that fallback, so these are the same call.
+LIBXSMM_API void libxsmm_blas_dgemm(const char* transa, const char* transb,
+  const libxsmm_blasint* m, const libxsmm_blasint* n, const libxsmm_blasint* k,
+  const double* alpha, const double* a, const libxsmm_blasint* lda, const double* b, const libxsmm_blasint* ldb,
+  const double* beta, double* c, const libxsmm_blasint* ldc)
+{ xgemm<double>(LIBXSMM_GEMM_PRECISION_F64, transa, transb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc); }
+
+LIBXSMM_API void libxsmm_blas_sgemm(const char* transa, const char* transb,
+  const libxsmm_blasint* m, const libxsmm_blasint* n, const libxsmm_blasint* k,
+  const float* alpha, const float* a, const libxsmm_blasint* lda, const float* b, const libxsmm_blasint* ldb,
+  const float* beta, float* c, const libxsmm_blasint* ldc)
+{ xgemm<float>(LIBXSMM_GEMM_PRECISION_F32, transa, transb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc); }
+
 // ---- auto-batch (reference src/libxsmm_ext_gemm.c:1016-1135) ---------------------------------------------------------
 LIBXSMM_APIEXT void libxsmm_mmbatch_begin(libxsmm_gemm_precision precision, const int* flags,
   const libxsmm_blasint* m, const libxsmm_blasint* n, const libxsmm_blasint* k,

@@ -138,6 +138,31 @@ int main(int argc, char* argv[]) {
     assert lines[1].startswith("dgemm('N', 'N', 23/*m*/, 24/*n*/, 25/*k*/,") and "/*ldb*/" in lines[3] and lines[4].endswith("23/*ldc*/)")
 
 
+REFERENCE = "/root/reference"
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REFERENCE, "samples")), reason="the reference tree is only mounted in the build container")
+def test_reference_sample_programs_compile_and_link_unchanged(xs, tmp_path):
+    """The drop-in claim at the source level: the reference's own sample callers (read in place, never copied, never run)
+    compile against include/libxsmm.h and link against libxsmm.so without a change -- samples/smm (specialized, dispatched),
+    samples/cp2k, samples/spmdm, samples/blocked_gemm (compile only: its gold needs a Fortran BLAS) and samples/edge."""
+    libdir = os.path.dirname(xs.LIB_PATH)
+    inc = ["-I", os.path.join(ROOT, "include")]
+    link = ["-L", libdir, "-lxsmm", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-lm"]
+    S = os.path.join(REFERENCE, "samples")
+    jobs = [(["g++", "-std=c++11"], ["smm/specialized.cpp"], True), (["g++", "-std=c++11"], ["smm/dispatched.cpp"], True),
+            (["g++", "-std=c++11"], ["cp2k/cp2k.cpp"], True), (["gcc", "-std=gnu99"], ["spmdm/spmdm.c"], True),
+            (["gcc", "-std=gnu99"], ["blocked_gemm/blocked_gemm.c"], False)]
+    for name in ("asparse_srsoa", "bsparse_srsoa", "bsparse_scsoa", "dense_rmacsoa", "dense_rmbcsoa"):
+        jobs.append((["gcc", "-std=gnu99", "-I", os.path.join(S, "edge")], ["edge/%s.c" % name, "edge/edge_proxy_common.c"], True))
+    for cc, srcs, do_link in jobs:
+        out = tmp_path / os.path.basename(srcs[0]).split(".")[0]
+        cmd = cc + ["-O0", "-fopenmp"] + inc + [os.path.join(S, f) for f in srcs]
+        cmd += (["-o", str(out)] + link) if do_link else ["-fsyntax-only"]
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        assert res.returncode == 0, (srcs, res.stderr[-3000:])
+
+
 def test_descriptor_rules(xs):
     """include/libxsmm_generator.h:36-39: NULL unless alpha == 1, beta in {0,1}, no TRANS_A; beta == 0 sets FLAG_BETA_0."""
     L = xs.lib()

@@ -81,13 +81,13 @@ void dev_free(void* p) { if (nullptr != p) (void)hipFree(p); }
 int h2d(void* dst, const void* src, size_t bytes)
 {
   if (0 == bytes) return 0;
-  return (int)hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)device().stream);
+  return (int)hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, (hipStream_t)device().stream);
 }
 
 int d2h(void* dst, const void* src, size_t bytes)
 {
   if (0 == bytes) return 0;
-  hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)device().stream);
+  hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, (hipStream_t)device().stream);
   if (hipSuccess == e) e = hipStreamSynchronize((hipStream_t)device().stream);
   return (int)e;
 }

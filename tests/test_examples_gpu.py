@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name", ["smm_caller.c", "spmdm_caller.c", "pyfr_caller.c", "blocked_caller.c", "smm_functor.cpp"])
+@pytest.mark.parametrize("name", ["smm_caller.c", "spmdm_caller.c", "pyfr_caller.c", "blocked_caller.c", "smm_functor.cpp", "cp2k_caller.cpp"])
 def test_c_caller_runs_on_the_gpu(xs, torch_gpu, tmp_path, name):
     libdir = os.path.dirname(xs.LIB_PATH)
     exe = tmp_path / name.split(".")[0]

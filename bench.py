@@ -269,6 +269,14 @@ def secondary(torch, xs, L):
     _, t8 = time_steps(torch, stacks_streams, 5, 2, None)
     m8 = sum(t8) / len(t8) * 1e-3
     res["cp2k_stacks_f64_27shapes"]["streams8"] = {"ms": round(m8 * 1e3, 4), "hbm_gbs": round(byt / m8 / 1e9, 1), "frac": round(byt / m8 / 1e9 / HBM_PEAK_GBS, 4)}
+    # the multi-threaded entry point (libxsmm_gemm_batch_omp: the reference adds into a shared C under a lock, in no defined
+    # order), one stream: few long runs are cut into segments whose sums join C with floating-point atomics
+    def stacks_omp():
+        for (m, n, k, s_, a, b, c, ia, ib, ic) in groups:
+            xs.gemm_batch(xs.F64, "N", "N", m, n, k, 1.0, a, m, b, k, 1.0, c, m, 0, 4, ia, ib, ic, s_, omp=True)
+    _, to = time_steps(torch, stacks_omp, 5, 2, None)
+    mo = sum(to) / len(to) * 1e-3
+    res["cp2k_stacks_f64_27shapes"]["omp_entry"] = {"ms": round(mo * 1e3, 4), "hbm_gbs": round(byt / mo / 1e9, 1), "frac": round(byt / mo / 1e9 / HBM_PEAK_GBS, 4)}
     L.libxsmm_amd_set_mfma(old_mfma)
     return res
 

@@ -345,6 +345,22 @@ void call_kernel(Kernel* k, const void* a, const void* b, void* c, const void* x
   }
 }
 
+// Whether the products that share a C may be summed in any order. The reference's sequential entry points
+// (libxsmm_gemm_batch, mmbatch with one task) add them in batch order; its multi-threaded ones (libxsmm_gemm_batch_omp,
+// ?gemm_batch_omp, mmbatch with several tasks: a lock per C, src/libxsmm_gemm.c:1366-1423) in whatever order the threads
+// arrive. Only the latter may be served by the segment/atomic form of the run kernels. LIBXSMM_AMD_BATCH_ORDER=relaxed
+// (strict) overrides for all entry points. Floating-point atomics do not reach host memory: C the CPU addresses stays strict.
+thread_local int tl_relaxed_order = 0;
+bool relaxed_order(int ntasks, libxsmm_blasint index_stride, const void* c)
+{
+  static const int env = []() { const char* e = getenv("LIBXSMM_AMD_BATCH_ORDER"); return (nullptr == e || 0 == *e) ? 0 : (('r' == *e || 'R' == *e) ? 1 : -1); }();
+  if (0 > env || (0 == env && ntasks <= 1 && 0 == tl_relaxed_order)) return false;
+  if (0 != index_stride) return !is_host_visible(c);
+  if (is_device_ptr(c) && !is_host_visible(c)) return true; // device array of pointers: the matrices live on the device as well
+  const void* const c0 = *static_cast<const void* const*>(c);
+  return !is_host_visible(c0);
+}
+
 } // namespace xsmm
 
 // ---- public batch interface ------------------------------------------------------------------------------------
@@ -360,6 +376,7 @@ LIBXSMM_API int libxsmm_mmbatch_kernel(libxsmm_xmmfunction kernel, libxsmm_blasi
   const long long tasksize = (size + ntasks - 1) / ntasks;
   const long long begin = (long long)tid * tasksize, span = begin + tasksize, end = (span < size ? span : size);
   SmmBatch s = from_descriptor(k->desc);
+  s.relaxed = relaxed_order(ntasks, index_stride, c) ? 1 : 0;
   // ntasks > 1: the tasks run concurrently on the caller's threads and may share C across slices; as in the
   // reference (lock per C, :1366-1423) correctness then needs atomic updates unless the caller opts out.
   const bool nosync = (batchsize < 0);
@@ -469,11 +486,13 @@ LIBXSMM_APIEXT void libxsmm_gemm_batch_omp(libxsmm_gemm_precision iprec, libxsmm
   libxsmm_blasint batchsize)
 { // the reference spreads the batch over OpenMP threads (src/libxsmm_ext_gemm.c:758-972); the device grid is the
   // parallel loop here, so the whole batch is one launch
+  ++tl_relaxed_order;
   libxsmm_mmbatch(iprec, oprec, transa, transb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, index_base, index_stride,
     stride_a, stride_b, stride_c, batchsize, 0, 1);
+  --tl_relaxed_order;
 }
 
-#define XSMM_GROUP_BATCH(NAME, T, PREC)                                                                        \
+#define XSMM_GROUP_BATCH(NAME, T, PREC, CALL)                                                                      \
 LIBXSMM_API void NAME(const char transa_array[], const char transb_array[],                                   \
   const libxsmm_blasint m_array[], const libxsmm_blasint n_array[], const libxsmm_blasint k_array[],         \
   const T alpha_array[], const T* a_array[], const libxsmm_blasint lda_array[],                              \
@@ -485,16 +504,16 @@ LIBXSMM_API void NAME(const char transa_array[], const char transb_array[],     
   libxsmm_blasint i, j = 0;                                                                                    \
   for (i = 0; i < ngroups; ++i) {                                                                              \
     const libxsmm_blasint size = group_size[i];                                                                \
-    libxsmm_gemm_batch(PREC, PREC, transa_array + i, transb_array + i, m_array[i], n_array[i], k_array[i],  \
+    CALL(PREC, PREC, transa_array + i, transb_array + i, m_array[i], n_array[i], k_array[i],  \
       alpha_array + i, a_array + j, lda_array + i, b_array + j, ldb_array + i, beta_array + i, c_array + j,  \
       ldc_array + i, 0/*index_base*/, 0/*index_stride*/, &ptrsize, &ptrsize, &ptrsize, size);                \
     j += LIBXSMM_ABS(size);                                                                                    \
   }                                                                                                            \
 }
-XSMM_GROUP_BATCH(libxsmm_dgemm_batch, double, LIBXSMM_GEMM_PRECISION_F64)
-XSMM_GROUP_BATCH(libxsmm_sgemm_batch, float, LIBXSMM_GEMM_PRECISION_F32)
-XSMM_GROUP_BATCH(libxsmm_dgemm_batch_omp, double, LIBXSMM_GEMM_PRECISION_F64)
-XSMM_GROUP_BATCH(libxsmm_sgemm_batch_omp, float, LIBXSMM_GEMM_PRECISION_F32)
+XSMM_GROUP_BATCH(libxsmm_dgemm_batch, double, LIBXSMM_GEMM_PRECISION_F64, libxsmm_gemm_batch)
+XSMM_GROUP_BATCH(libxsmm_sgemm_batch, float, LIBXSMM_GEMM_PRECISION_F32, libxsmm_gemm_batch)
+XSMM_GROUP_BATCH(libxsmm_dgemm_batch_omp, double, LIBXSMM_GEMM_PRECISION_F64, libxsmm_gemm_batch_omp)
+XSMM_GROUP_BATCH(libxsmm_sgemm_batch_omp, float, LIBXSMM_GEMM_PRECISION_F32, libxsmm_gemm_batch_omp)
 
 LIBXSMM_API int libxsmm_amd_gemm_batch_strided(const libxsmm_gemm_descriptor* descriptor,
   const void* a, const void* b, void* c, long long stride_a, long long stride_b, long long stride_c, long long batchsize)
@@ -618,7 +637,7 @@ LIBXSMM_API int libxsmm_amd_smm_kernel_source(const libxsmm_gemm_descriptor* des
   const libxsmm_gemm_descriptor& d = *descriptor;
   const int ip = LIBXSMM_GETENUM_INP(d.datatype);
   if (LIBXSMM_GEMM_PRECISION_F64 != ip && LIBXSMM_GEMM_PRECISION_F32 != ip) return -1;
-  const std::string src = gen_smm_source(LIBXSMM_GEMM_PRECISION_F64 == ip ? 8 : 4, (int)d.m, (int)d.n, (int)d.k, d.flags, variant & 31);
+  const std::string src = gen_smm_source(LIBXSMM_GEMM_PRECISION_F64 == ip ? 8 : 4, (int)d.m, (int)d.n, (int)d.k, d.flags, variant & 63);
   if (nullptr != buffer && 0 < buffer_size) {
     const size_t n = (src.size() < buffer_size - 1 ? src.size() : buffer_size - 1);
     memcpy(buffer, src.data(), n); buffer[n] = 0;

@@ -57,6 +57,7 @@ struct SmmBatch {
   long long batch;
   int sync;                 // SyncMode
   const int* devflags;      // SYNC_DEVICE*: device int[2] written by the check kernel earlier on the same stream
+  int relaxed;              // != 0: sums into a shared C may be formed in any order (the caller's reference path is multi-threaded)
   int use_mfma;             // policy bit (0: scalar FMA only)
   // general form used by the BLAS-like fallback (libxsmm_?gemm with alpha/beta/trans outside the SMM domain)
   double alpha, beta; int general;              // general != 0: C = alpha*op(A)*op(B) + beta*C, flags may hold TRANS_A
@@ -97,7 +98,7 @@ int jit_blocks_per_cu(JitKernel* k, int threads); // occupancy of a generated ke
 int jit_launch_args(JitKernel* k, unsigned blocks, unsigned threads, void** args, void* stream);
 int jit_launch_raw(JitKernel* k, unsigned blocks, unsigned threads, void* arg0, size_t arg0_size, void* arg1, void* stream);
 // dense SMM kernels specialised per shape (xsmm_jit_smm.cpp)
-enum { SMM_JIT_SCALAR = 1, SMM_JIT_RUNS = 2, SMM_JIT_WGRUNS = 4, SMM_JIT_HASWG = 8, SMM_JIT_BIG = 16 }; // variant bits of the generated dense kernel
+enum { SMM_JIT_SCALAR = 1, SMM_JIT_RUNS = 2, SMM_JIT_WGRUNS = 4, SMM_JIT_HASWG = 8, SMM_JIT_BIG = 16, SMM_JIT_SPLIT = 32 }; // variant bits of the generated dense kernel
 std::string gen_smm_source(int typesize, int m, int n, int k, int flags, int variant);
 bool smm_jit_eligible(const SmmBatch& s);
 int launch_smm_jit(const SmmBatch& s, void* stream, const char** name); // -1: not available

@@ -223,6 +223,24 @@ __device__ __forceinline__ void store_c(T* Cs, T* pc, int lane, int tx, int ty, 
   wave_lds_sync();
 }
 
+#if XSPLIT
+__device__ __forceinline__ void xatomic_add(double* p, double v) { (void)__builtin_amdgcn_global_atomic_fadd_f64((__attribute__((address_space(1))) double*)p, v); }
+__device__ __forceinline__ void xatomic_add(float* p, float v) { (void)__builtin_amdgcn_global_atomic_fadd_f32((__attribute__((address_space(1))) float*)p, v); }
+// a segment's sum joins C: through LDS so that the atomics of a wave cover consecutive addresses
+__device__ __forceinline__ void atomic_c(T* Cs, T* pc, int lane, int tx, int ty, const T (&acc)[TM][TN])
+{
+  wave_lds_sync();
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) { const int m = tx * TM + i, n = ty * TN + j; if (m < M && n < N) Cs[n * M + m] = acc[i][j]; }
+  }
+  wave_lds_sync();
+  for (int e = lane; e < M * N; e += 64) xatomic_add(pc + e, Cs[e]);
+  wave_lds_sync();
+}
+#endif
+
 // bit l: item first + l starts a run, i.e. its C differs from its predecessor's (item 0 always does)
 __device__ __forceinline__ unsigned long long head_mask(const DevAddr& ad, long long first, int lane, long long batch)
 {
@@ -254,6 +272,22 @@ __device__ __forceinline__ bool is_head(unsigned long long heads, long long chun
 { // beyond the chunk the walk only continues through non-heads
   return (i < chunk + 64) && (0 != ((heads >> (int)(i - chunk)) & 1ULL));
 }
+
+#if XSPLIT
+// Relaxed order (the caller's reference path is itself multi-threaded with a lock per C: libxsmm_gemm_batch_omp, mmbatch
+// with several tasks). A batch of few, long runs is a handful of sequential chains and leaves the chip idle; here such a
+// batch is cut into segments of `len` items, a wave sums the products of its segment from zero and adds the sum to C with
+// floating-point atomics (one C-sized atomic update per segment instead of a C read and write per run). Returns 0 when
+// the batch has chains enough (or repeats out of order) and is walked run by run in batch order.
+__device__ __forceinline__ int split_len(const int* flags, long long batch)
+{
+  if (nullptr == flags || 0 != flags[1]) return 0;
+  const long long runs = batch - flags[0];
+  if (runs >= 2048 || 16 * runs > batch) return 0;
+  const long long len = (batch + 4095) / 4096;
+  return (int)(len < 8 ? 8 : (len > 64 ? 64 : len));
+}
+#endif
 
 constexpr int D = XDEPTH; // products whose operands are in flight (register stages)
 
@@ -306,6 +340,9 @@ extern "C" __global__ __launch_bounds__(256) void xsmm_smm_op(DevAddr ad, long l
   if (nullptr != ad.flags) {
     if (0 != ad.flags[1]) return;                                    // C repeats out of order: the atomic kernel owns this batch
     if (8LL * ad.flags[0] < 7LL * batch) return;                     // runs shorter than 8 on average: the wave form owns it
+#if XSPLIT
+    if (0 != split_len(ad.flags, batch)) return;                     // few long runs, order relaxed: the wave form cuts them up
+#endif
   }
   T ra[D][NLA][VA], rb[D][NLB][VB];
   int buf = 0;
@@ -386,12 +423,26 @@ extern "C" __global__ __launch_bounds__(64 * XWAVES) void xsmm_smm_op(DevAddr ad
   // the next item, if it starts a run). A batch of distinct C blocks is the special case "all heads".
   if (nullptr != ad.flags) {
     if (0 != ad.flags[1]) return;                  // C blocks repeat out of order: the atomic kernel owns this batch
+#if XSPLIT
+    if (XHASWG && 0 == split_len(ad.flags, batch) && 8LL * ad.flags[0] >= 7LL * batch) return;
+#else
     if (XHASWG && 8LL * ad.flags[0] >= 7LL * batch) return; // runs of 8 and more on average: the work-group form owns this batch
+#endif
   }
+#if XSPLIT
+  const int seg = split_len(ad.flags, batch);
+#else
+  constexpr int seg = 0;
+#endif
+  const long long step = (0 != seg ? seg : 64);
   T ra[D][NLA][VA], rb[D][NLB][VB], rc[NLC][VC];
-  for (long long chunk = w * 64; chunk < batch; chunk += W * 64) {
+  for (long long chunk = w * step; chunk < batch; chunk += W * step) {
     unsigned long long heads; long long first, end;
-    if (!chain_of_chunk(ad, chunk, lane, batch, heads, first, end)) continue;
+    if (0 != seg) { // a segment is walked from its first item, whoever opened the run it starts in
+      heads = head_mask(ad, chunk, lane, batch) | 1ULL;
+      first = chunk; end = (chunk + seg < batch ? chunk + seg : batch);
+    }
+    else if (!chain_of_chunk(ad, chunk, lane, batch, heads, first, end)) continue;
     AddrWindow win; window_fill(win, ad, first, lane, end);
 #pragma unroll
     for (int s = 0; s < D; ++s) {
@@ -401,7 +452,7 @@ extern "C" __global__ __launch_bounds__(64 * XWAVES) void xsmm_smm_op(DevAddr ad
         load_flat<VB, NLB, BE>(pb, lane, rb[s]);
       }
     }
-    if (!XBETA0) load_flat<VC, NLC, CE>(resolve<const T>(ad.c, ad.ic, ad.sc, ad, first), lane, rc);
+    if (!XBETA0 && 0 == seg) load_flat<VC, NLC, CE>(resolve<const T>(ad.c, ad.ic, ad.sc, ad, first), lane, rc);
     T acc[TM][TN];
     T* pc = nullptr;
     for (long long i0 = first; i0 < end; i0 += D) {
@@ -410,10 +461,20 @@ extern "C" __global__ __launch_bounds__(64 * XWAVES) void xsmm_smm_op(DevAddr ad
         const long long i = i0 + s;
         if (i < end) {
           if (is_head(heads, chunk, i)) { // item i opens a run: close the previous one, take over its C
-            if (nullptr != pc) store_c(Cs, pc, lane, tx, ty, acc);
-            pc = resolve<T>(ad.c, ad.ic, ad.sc, ad, i);
-            if (!XBETA0) { park_c(Cs, lane, rc); wave_lds_sync(); }
-            acc_from_c(Cs, tx, ty, acc, XBETA0);
+#if XSPLIT
+            if (0 != seg) {
+              if (nullptr != pc) atomic_c(Cs, pc, lane, tx, ty, acc);
+              pc = resolve<T>(ad.c, ad.ic, ad.sc, ad, i);
+              acc_from_c(Cs, tx, ty, acc, true);
+            }
+            else
+#endif
+            {
+              if (nullptr != pc) store_c(Cs, pc, lane, tx, ty, acc);
+              pc = resolve<T>(ad.c, ad.ic, ad.sc, ad, i);
+              if (!XBETA0) { park_c(Cs, lane, rc); wave_lds_sync(); }
+              acc_from_c(Cs, tx, ty, acc, XBETA0);
+            }
           }
           park_ab(As, Bs, lane, ra[s], rb[s]);
           if (i + D < end) {
@@ -421,13 +482,17 @@ extern "C" __global__ __launch_bounds__(64 * XWAVES) void xsmm_smm_op(DevAddr ad
             load_flat<VA, NLA, AE>(pa, lane, ra[s]);
             load_flat<VB, NLB, BE>(pb, lane, rb[s]);
           }
-          if (!XBETA0 && i + 1 < end && is_head(heads, chunk, i + 1)) load_flat<VC, NLC, CE>(resolve<const T>(ad.c, ad.ic, ad.sc, ad, i + 1), lane, rc);
+          if (!XBETA0 && 0 == seg && i + 1 < end && is_head(heads, chunk, i + 1)) load_flat<VC, NLC, CE>(resolve<const T>(ad.c, ad.ic, ad.sc, ad, i + 1), lane, rc);
           wave_lds_sync();
           multiply_pipelined(As, Bs, tx, ty * TN, acc);
           wave_lds_sync();
         }
       }
     }
+#if XSPLIT
+    if (0 != seg) atomic_c(Cs, pc, lane, tx, ty, acc);
+    else
+#endif
     store_c(Cs, pc, lane, tx, ty, acc);
   }
 #else
@@ -600,7 +665,7 @@ struct SmmKey {
   int typesize, m, n, k, flags, variant;
   bool operator==(const SmmKey& o) const { return typesize == o.typesize && m == o.m && n == o.n && k == o.k && flags == o.flags && variant == o.variant; }
 };
-struct SmmKeyHash { size_t operator()(const SmmKey& k) const { return (size_t)((((k.m * 131 + k.n) * 131 + k.k) * 8 + k.flags * 2 + (k.typesize == 8)) * 16 + k.variant); } };
+struct SmmKeyHash { size_t operator()(const SmmKey& k) const { return (size_t)((((k.m * 131 + k.n) * 131 + k.k) * 8 + k.flags * 2 + (k.typesize == 8)) * 64 + k.variant); } };
 
 std::mutex g_smm_lock;
 std::unordered_map<SmmKey, JitKernel*, SmmKeyHash> g_smm_cache; // nullptr value: compilation failed, do not retry
@@ -661,6 +726,7 @@ std::string gen_smm_source(int typesize, int m, int n, int k, int flags, int var
     s += std::string("#define XFLAT ") + (flat ? "1" : "0") + "\n";
   }
   s += "#define XDEPTH " + std::to_string(smm_jit_depth(typesize, m, n, k, variant)) + "\n";  // register stages of the run forms
+  s += std::string("#define XSPLIT ") + ((variant & SMM_JIT_SPLIT) ? "1" : "0") + "\n";  // relaxed order: few long runs are cut into segments (atomics)
   s += std::string("#define XHASWG ") + ((variant & SMM_JIT_HASWG) ? "1" : "0") + "\n";   // wave form: leave long runs to the work-group form
   s += SMM_JIT_BODY;
   return s;
@@ -789,7 +855,8 @@ static int smm_jit_launch_variant(const SmmBatch& s, int variant, void* stream)
   if (per_cu < 1) per_cu = 1;
   if (0 < bpc_env) per_cu = bpc_env;
   // run form: a wave scans chunks of 64 items for run heads, so the grid is sized by chunks
-  const long long units = (0 != (variant & SMM_JIT_RUNS)) ? ((batch + 63) / 64) : batch;
+  // (segments of 8 items and more when few long runs may be cut up: waves without a chunk leave at once)
+  const long long units = (0 != (variant & SMM_JIT_RUNS)) ? ((batch + ((variant & SMM_JIT_SPLIT) ? 7 : 63)) / ((variant & SMM_JIT_SPLIT) ? 8 : 64)) : batch;
   long long blocks = (units + waves - 1) / waves;
   if (blocks > 256 * per_cu) blocks = 256 * per_cu;
   if (blocks < 1) blocks = 1;
@@ -822,11 +889,12 @@ int launch_smm_jit(const SmmBatch& s, void* stream, const char** name)
   }
   // SYNC_DEVICE: both run forms are launched; each reads the device-side verdict (average run length) and one of them works
   *name = f64 ? "smm_f64_jit_shape_runs" : "smm_f32_jit_shape_runs";
-  int e = smm_jit_launch_variant(s, width | SMM_JIT_RUNS | (wg_fits ? SMM_JIT_HASWG : 0), stream);
+  const int split = (0 != s.relaxed ? SMM_JIT_SPLIT : 0); // the caller's reference path is unordered as well
+  int e = smm_jit_launch_variant(s, width | split | SMM_JIT_RUNS | (wg_fits ? SMM_JIT_HASWG : 0), stream);
   if (0 == e && wg_fits) {
-    e = smm_jit_launch_variant(s, width | SMM_JIT_WGRUNS, stream);
+    e = smm_jit_launch_variant(s, width | split | SMM_JIT_WGRUNS, stream);
     if (e < 0) { // the companion did not compile: fall back to the wave form alone (it must then take long runs as well)
-      e = smm_jit_launch_variant(s, width | SMM_JIT_RUNS, stream);
+      e = smm_jit_launch_variant(s, width | split | SMM_JIT_RUNS, stream);
     }
   }
   return e;

@@ -29,8 +29,9 @@ def test_generated_sources_compile_for_gfx950(xs):
         for (m, n, k) in [(23, 23, 23), (13, 23, 32), (32, 32, 64), (1, 1, 1)]:
             for beta, flags in ((1.0, 0), (0.0, 0), (1.0, xs.FLAG_TRANS_B)):
                 blob, d = xs.descriptor(prec, m, n, k, beta=beta, flags=flags)
-                # wide / element-wide / + wave-per-run / + work-group-per-run / wave-per-run that leaves long runs to the latter
-                for variant in ((0, 1, 3, 5, 11) if beta == 1.0 else (0, 1)):
+                # wide / element-wide / + wave-per-run / + work-group-per-run / wave-per-run that leaves long runs to the latter /
+                # the relaxed-order twins (bit 32: few long runs are cut into segments that join C with atomics)
+                for variant in ((0, 1, 3, 5, 11, 35, 37, 43) if beta == 1.0 else (0, 1)):
                     rc = L.libxsmm_amd_smm_kernel_source(d, variant, buf, len(buf), 1)
                     if rc == -1:
                         pytest.skip("libhiprtc is not available here")
@@ -181,6 +182,46 @@ def test_jit_pointer_batches_with_runs(xs, orc, torch_gpu):
         torch.cuda.synchronize()
         assert xs.last_kernel().endswith("_jit_shape_runs"), xs.last_kernel()
     assert np.array_equal(dc.cpu().numpy(), ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("shape", [(23, 23, 23), (13, 5, 7), (32, 32, 32)])
+def test_relaxed_order_cuts_long_runs_into_segments(xs, orc, torch_gpu, dtype, shape):
+    """libxsmm_gemm_batch_omp (src/libxsmm_ext_gemm.c:758-972: threads + a lock per C, i.e. no defined order of the sums)
+    may cut a batch of few, long runs into segments that join C with atomics; libxsmm_gemm_batch on the same batch keeps
+    the sequential chain bit for bit. Run lengths include 1 and lengths that straddle segment borders; the last segment
+    is ragged; one C block in the middle is never referenced."""
+    torch = torch_gpu
+    m, n, k = shape
+    rng = np.random.default_rng(m + 3 * n + 5 * k)
+    lens = np.array([700, 1, 333, 8, 1201, 64, 15, 999, 1500, 2, 813], dtype=np.int64)
+    batch, nc = int(lens.sum()), len(lens) + 1
+    owners = np.array([0, 1, 2, 3, 4, 6, 7, 8, 9, 10, 11])
+    cidx = np.repeat(owners, lens)
+    prec = xs.F64 if dtype == np.float64 else xs.F32
+    a = rng.uniform(-1, 1, batch * m * k).astype(dtype); b = rng.uniform(-1, 1, batch * k * n).astype(dtype)
+    c = rng.uniform(-1, 1, nc * m * n).astype(dtype)
+    sa = (rng.permutation(batch) * m * k).astype(np.int32); sb = (np.arange(batch) * k * n).astype(np.int32); sc = (cidx * m * n).astype(np.int32)
+    ref = c.copy()
+    assert 0 == orc.gemm_batch_idx(orc.FMA, 0, m, n, k, m, k, m, a, b, ref, 0, sa, sb, sc, batch)
+    da, db = (torch.from_numpy(x).cuda() for x in (a, b))
+    with _JitForced(xs):
+        dc = torch.from_numpy(c).cuda()
+        xs.gemm_batch(prec, "N", "N", m, n, k, 1.0, da, m, db, k, 1.0, dc, m, 0, 4, sa, sb, sc, batch)
+        torch.cuda.synchronize()
+        assert np.array_equal(dc.cpu().numpy(), ref)  # strict entry point: batch order
+        dc = torch.from_numpy(c).cuda()
+        xs.gemm_batch(prec, "N", "N", m, n, k, 1.0, da, m, db, k, 1.0, dc, m, 0, 4, sa, sb, sc, batch, omp=True)
+        torch.cuda.synchronize()
+        assert "_jit_shape_runs" in xs.last_kernel(), xs.last_kernel()
+    out = dc.cpu().numpy()
+    # two orders of the same sum of up to 1500 * k terms: rounding errors random-walk, eps * sqrt(terms) with a margin of 4
+    # (for one product per C this is far inside the north_star tolerance of 1e-6 / 1e-12 relative)
+    tol = np.finfo(dtype).eps * np.sqrt(float(lens.max()) * k) * 4
+    assert np.max(np.abs(out - ref)) <= tol * np.max(np.abs(ref))
+    assert not np.array_equal(out, ref) or m * n * k < 1000  # the order really differs (else the segment form did not run)
+    assert np.array_equal(out[5 * m * n:6 * m * n], c[5 * m * n:6 * m * n])  # the unreferenced block is untouched
 
 
 @pytest.mark.gpu

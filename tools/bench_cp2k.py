@@ -3,7 +3,7 @@
 shape, every u consecutive products of a group accumulating into one C block (samples/cp2k/cp2k.cpp:155,328-360).
 One libxsmm_gemm_batch call (index arrays) per shape group, all on the engine's stream.
 
-usage: python3 tools/bench_cp2k.py [products=524288] [reps=7]
+usage: python3 tools/bench_cp2k.py [products=524288] [reps=7] [omp=0]   (omp=1: libxsmm_gemm_batch_omp, order of the sums relaxed)
 Algorithmic bytes (the reference's bwsize, cp2k.cpp:156): sum over products 8*(M*K+K*N) + sum over C blocks 2*8*M*N."""
 import importlib
 import math
@@ -18,6 +18,7 @@ xs = importlib.import_module("libxsmm-1_amd")
 L = xs.lib()
 products = int(sys.argv[1]) if len(sys.argv) > 1 else 524288
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 7
+OMP = bool(int(sys.argv[3])) if len(sys.argv) > 3 else False
 torch.cuda.set_device(0)
 g = torch.Generator(device="cuda"); g.manual_seed(1)
 L.libxsmm_amd_set_mfma(0)
@@ -50,7 +51,7 @@ def one_pass(streams):
     A batch call makes no host round trip, so the 27 calls are queued back to back and the groups overlap on the GPU."""
     if not streams:
         for (m, n, k, s, a, b, c, ia, ib, ic) in groups:
-            xs.gemm_batch(xs.F64, "N", "N", m, n, k, 1.0, a, m, b, k, 1.0, c, m, 0, 4, ia, ib, ic, s)
+            xs.gemm_batch(xs.F64, "N", "N", m, n, k, 1.0, a, m, b, k, 1.0, c, m, 0, 4, ia, ib, ic, s, omp=OMP)
         return
     main = torch.cuda.current_stream()
     fork = torch.cuda.Event(); fork.record(main)
@@ -59,7 +60,7 @@ def one_pass(streams):
     for gi, (m, n, k, s, a, b, c, ia, ib, ic) in enumerate(groups):
         st = streams[gi % len(streams)]
         L.libxsmm_amd_set_stream(C.c_void_p(st.cuda_stream))
-        xs.gemm_batch(xs.F64, "N", "N", m, n, k, 1.0, a, m, b, k, 1.0, c, m, 0, 4, ia, ib, ic, s)
+        xs.gemm_batch(xs.F64, "N", "N", m, n, k, 1.0, a, m, b, k, 1.0, c, m, 0, 4, ia, ib, ic, s, omp=OMP)
     L.libxsmm_amd_set_stream(C.c_void_p(main.cuda_stream))
     for st in streams:
         ev = torch.cuda.Event(); ev.record(st); main.wait_event(ev)
@@ -78,15 +79,15 @@ for nstreams in (0, 4, 8, 27):
         if it >= 2:
             times.append(e0.elapsed_time(e1))
     t = sorted(times)[len(times) // 2]
-    print("cp2k stacks, %2d streams: kernels %s  median %.3f ms (min %.3f)  %.0f GB/s (%.1f%% of 8 TB/s)  %.0f GFLOP/s"
-          % (nstreams if nstreams else 1, sorted(names), t, min(times), tot_bytes / t / 1e6, tot_bytes / t / 1e6 / 80.0, tot_flops / t / 1e6))
+    print("cp2k stacks%s, %2d streams: kernels %s  median %.3f ms (min %.3f)  %.0f GB/s (%.1f%% of 8 TB/s)  %.0f GFLOP/s"
+          % (" (omp entry)" if OMP else "", nstreams if nstreams else 1, sorted(names), t, min(times), tot_bytes / t / 1e6, tot_bytes / t / 1e6 / 80.0, tot_flops / t / 1e6))
 # per-group breakdown (each group alone, synchronised)
 for (m, n, k, s, a, b, c, ia, ib, ic) in groups[::13]:
     ts = []
     for it in range(5):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        xs.gemm_batch(xs.F64, "N", "N", m, n, k, 1.0, a, m, b, k, 1.0, c, m, 0, 4, ia, ib, ic, s)
+        xs.gemm_batch(xs.F64, "N", "N", m, n, k, 1.0, a, m, b, k, 1.0, c, m, 0, 4, ia, ib, ic, s, omp=OMP)
         e1.record(); torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1))
     u = max(1, math.isqrt(s * 160 // 240)); nc = (s + u - 1) // u

@@ -24,7 +24,7 @@ inline DevAddr make_addr(const SmmBatch& s)
   d.ia = (const char*)s.ia; d.ib = (const char*)s.ib; d.ic = (const char*)s.ic;
   d.sa = s.sa; d.sb = s.sb; d.sc = s.sc;
   d.index_base = s.index_base; d.index_stride = s.index_stride; d.mode = s.mode;
-  d.flags = ((SYNC_DEVICE == s.sync || SYNC_DEVICE_FALLBACK == s.sync) ? s.devflags : nullptr);
+  d.flags = (SYNC_DEVICE == s.sync ? s.devflags : nullptr);
   return d;
 }
 

@@ -30,10 +30,6 @@ void smm_generic_kernel(DevAddr ad, int M, int N, int K, int lda, int ldb, int l
   if (SYNC_DEVICE == sync_arg) { // how C blocks repeat was established on the device (c_order_kernel, same stream)
     sync = (0 != ad.flags[1]) ? SYNC_ATOMIC : ((0 != ad.flags[0]) ? SYNC_RUNS : SYNC_NONE);
   }
-  else if (SYNC_DEVICE_FALLBACK == sync_arg) { // the run kernel in front of this launch took the batch unless C repeats out of order
-    if (0 == ad.flags[1]) return;
-    sync = SYNC_ATOMIC;
-  }
   constexpr int G = TGM * TGN;
   constexpr int PPB = 256 / G;
   constexpr int MP = TGM * TM;
@@ -143,10 +139,14 @@ void smm_generic_kernel(DevAddr ad, int M, int N, int K, int lda, int ldb, int l
   }
 }
 
-// counts adjacent C operands that are equal (out[0]) or decreasing (out[1])
+// Counts adjacent C operands that are equal (out[0]) or decreasing (out[1]). No launch in front of it has to clear
+// anything: every block leaves its counts in its own pair out[4 + 2*block ..], the block that arrives last (a ticket
+// counter, out[2], which atomicInc wraps back to zero) adds the pairs up and writes the totals.
 template<typename T>
 __global__ __launch_bounds__(256) void c_order_kernel(DevAddr ad, long long batch, int* out)
 {
+  __shared__ int red[2][4];
+  __shared__ bool last;
   int eq = 0, dec = 0;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x + 1; i < batch; i += (long long)gridDim.x * blockDim.x) {
     const T* const c0 = addr_c<T>(ad, i - 1);
@@ -154,8 +154,31 @@ __global__ __launch_bounds__(256) void c_order_kernel(DevAddr ad, long long batc
     eq += (c1 == c0) ? 1 : 0;
     dec += (c1 < c0) ? 1 : 0;
   }
-  if (eq) atomicAdd(out + 0, eq);
-  if (dec) atomicAdd(out + 1, dec);
+  for (int o = 32; o > 0; o >>= 1) { eq += __shfl_xor(eq, o); dec += __shfl_xor(dec, o); }
+  if (0 == (threadIdx.x & 63)) { red[0][threadIdx.x >> 6] = eq; red[1][threadIdx.x >> 6] = dec; }
+  __syncthreads();
+  if (0 == threadIdx.x) {
+    __hip_atomic_store(out + 4 + 2 * blockIdx.x, red[0][0] + red[0][1] + red[0][2] + red[0][3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(out + 5 + 2 * blockIdx.x, red[1][0] + red[1][1] + red[1][2] + red[1][3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();
+    last = (gridDim.x - 1 == atomicInc(reinterpret_cast<unsigned*>(out + 2), gridDim.x - 1));
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  eq = dec = 0;
+  for (unsigned b = threadIdx.x; b < gridDim.x; b += blockDim.x) {
+    eq += __hip_atomic_load(out + 4 + 2 * b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    dec += __hip_atomic_load(out + 5 + 2 * b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  for (int o = 32; o > 0; o >>= 1) { eq += __shfl_xor(eq, o); dec += __shfl_xor(dec, o); }
+  __syncthreads();
+  if (0 == (threadIdx.x & 63)) { red[0][threadIdx.x >> 6] = eq; red[1][threadIdx.x >> 6] = dec; }
+  __syncthreads();
+  if (0 == threadIdx.x) {
+    out[0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    out[1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  }
 }
 
 template<typename T, int TM, int TGM, bool GENERAL>
@@ -214,10 +237,8 @@ int launch_smm_generic(const SmmBatch& s, void* stream, const char** name)
 int launch_c_order_check(const SmmBatch& s, int* d_out, void* stream)
 {
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(d_out, 0, 2 * sizeof(int), st);
-  if (hipSuccess != e) return (int)e;
   long long blocks = (s.batch + 255) / 256;
-  if (blocks > 2048) blocks = 2048;
+  if (blocks > FLAG_SLOT_BLOCKS) blocks = FLAG_SLOT_BLOCKS;
   if (blocks < 1) blocks = 1;
   if (8 == s.typesize) hipLaunchKernelGGL((c_order_kernel<double>), dim3((unsigned)blocks), dim3(256), 0, st, make_addr(s), s.batch, d_out);
   else hipLaunchKernelGGL((c_order_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, st, make_addr(s), s.batch, d_out);

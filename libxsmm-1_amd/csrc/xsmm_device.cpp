@@ -101,18 +101,21 @@ void note_launch(const char* name)
 }
 
 int* flag_slot()
-{ // ring of int[4] slots in device memory: one per batch call whose C ordering is inspected on the device; a slot is
-  // written (memset + check kernel) and read (compute kernels) by launches of one stream, in order
+{ // Ring of slots in device memory, one per batch call whose C ordering is inspected on the device: int[4] {equal pairs,
+  // decreasing pairs, ticket counter, -} followed by a pair of counts per block of the check kernel. A slot is written
+  // (check kernel) and read (compute kernels) by launches of one stream, in order; nothing has to be cleared between uses
+  // (the ticket counter wraps back to zero, see c_order_kernel), only once here.
   static int* ring = nullptr;
   static std::once_flag once;
   static std::atomic<unsigned> next{0};
-  constexpr unsigned SLOTS = 4096;
+  constexpr unsigned SLOTS = 2048, INTS = 4 + 2 * FLAG_SLOT_BLOCKS;
   std::call_once(once, []() {
     void* p = nullptr;
-    if (hipSuccess == hipMalloc(&p, SLOTS * 4 * sizeof(int))) ring = static_cast<int*>(p); else (void)hipGetLastError();
+    if (hipSuccess == hipMalloc(&p, (size_t)SLOTS * INTS * sizeof(int)) && hipSuccess == hipMemset(p, 0, (size_t)SLOTS * INTS * sizeof(int))) ring = static_cast<int*>(p);
+    else (void)hipGetLastError();
   });
   if (nullptr == ring) return nullptr;
-  return ring + 4 * (next.fetch_add(1, std::memory_order_relaxed) % SLOTS);
+  return ring + (size_t)INTS * (next.fetch_add(1, std::memory_order_relaxed) % SLOTS);
 }
 
 void* scratch(int slot, size_t bytes)

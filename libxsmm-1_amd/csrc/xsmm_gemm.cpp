@@ -27,12 +27,7 @@ int run_smm(const SmmBatch& s)
   int e = -1;
   if (0 == s.general) e = launch_smm_special(s, device().stream, &name);            // hand-tuned shapes
   if (e < 0 && smm_jit_eligible(s)) {                                               // shape-specialised via hiprtc
-    e = launch_smm_jit(s, device().stream, &name);
-    if (0 == e && SYNC_DEVICE == s.sync) { // the run kernel stands down if C blocks repeat out of order; then this one works
-      SmmBatch f = s; f.sync = SYNC_DEVICE_FALLBACK;
-      const char* fallback = "";
-      e = launch_smm_generic(f, device().stream, &fallback);
-    }
+    e = launch_smm_jit(s, device().stream, &name); // (SYNC_DEVICE: whatever the verdict on the device, one of its kernels works)
   }
   if (e < 0) e = launch_smm_generic(s, device().stream, &name);                     // any descriptor
   note_launch(name);
@@ -71,6 +66,9 @@ int choose_sync(SmmBatch& s, bool nosync)
   const int e = launch_c_order_check(s, d_flags, device().stream);
   if (0 != e) return e;
   s.sync = SYNC_DEVICE; s.devflags = d_flags;
+  // C blocks that repeat out of order are summed with floating-point atomics, which do not reach host memory
+  if (ADDR_POINTER != s.mode) s.c_atomics = is_host_visible(s.c) ? 0 : 1;
+  else s.c_atomics = (is_host_visible(s.c) && is_host_visible(*static_cast<void* const*>(s.c))) ? 0 : 1;
   return 0;
 }
 

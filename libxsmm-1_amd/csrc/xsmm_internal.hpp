@@ -41,8 +41,8 @@ enum SyncMode : int {
   SYNC_ATOMIC = 2,    // arbitrary duplicates: product from zero, then atomic add into C
   // Decided on the device, without a host round trip: a check kernel leaves {#equal neighbours, #out-of-order repeats}
   // in SmmBatch::devflags and the compute kernels read them -- the call stays asynchronous (and graph-capturable).
-  SYNC_DEVICE = 3,          // pick NONE / RUNS / ATOMIC from the flags (generic kernel); run kernel: proceed unless [1] != 0
-  SYNC_DEVICE_FALLBACK = 4  // generic kernel launched behind a run kernel: ATOMIC if [1] != 0, otherwise nothing to do
+  SYNC_DEVICE = 3           // pick NONE / RUNS / ATOMIC from the flags (generic kernel); run kernels: runs in batch order, or
+                            // segments whose sums join C with atomics ([1] != 0, or few long runs under a relaxed order)
 };
 
 struct SmmBatch {
@@ -57,6 +57,7 @@ struct SmmBatch {
   long long batch;
   int sync;                 // SyncMode
   const int* devflags;      // SYNC_DEVICE*: device int[2] written by the check kernel earlier on the same stream
+  int c_atomics;            // SYNC_DEVICE: != 0 if floating-point atomics reach C (device memory, not host memory the GPU maps)
   int relaxed;              // != 0: sums into a shared C may be formed in any order (the caller's reference path is multi-threaded)
   int use_mfma;             // policy bit (0: scalar FMA only)
   // general form used by the BLAS-like fallback (libxsmm_?gemm with alpha/beta/trans outside the SMM domain)
@@ -66,8 +67,9 @@ struct SmmBatch {
 // returns hipError_t as int (0 == success); *name receives a static string naming the kernel variant
 int launch_smm_batch(const SmmBatch& args, void* stream, const char** name);
 
+constexpr int FLAG_SLOT_BLOCKS = 512; // work-groups of the C ordering check (each leaves a pair of counts in the flag slot)
 // detects how C operands alias across the batch: out[0] = number of i with c_i == c_{i-1},
-// out[1] = number of i with c_i < c_{i-1}. d_out is a device int[2] (zeroed by the launcher).
+// out[1] = number of i with c_i < c_{i-1}. d_out is a slot of flag_slot().
 int launch_c_order_check(const SmmBatch& args, int* d_out, void* stream);
 
 // CSR "register" kernel family (fsspmdm sparse path, libxsmm_create_?csr_reg): row-major

@@ -223,7 +223,7 @@ __device__ __forceinline__ void store_c(T* Cs, T* pc, int lane, int tx, int ty, 
   wave_lds_sync();
 }
 
-#if XSPLIT
+#if XRUNS
 __device__ __forceinline__ void xatomic_add(double* p, double v) { (void)__builtin_amdgcn_global_atomic_fadd_f64((__attribute__((address_space(1))) double*)p, v); }
 __device__ __forceinline__ void xatomic_add(float* p, float v) { (void)__builtin_amdgcn_global_atomic_fadd_f32((__attribute__((address_space(1))) float*)p, v); }
 // a segment's sum joins C: through LDS so that the atomics of a wave cover consecutive addresses
@@ -273,17 +273,20 @@ __device__ __forceinline__ bool is_head(unsigned long long heads, long long chun
   return (i < chunk + 64) && (0 != ((heads >> (int)(i - chunk)) & 1ULL));
 }
 
-#if XSPLIT
-// Relaxed order (the caller's reference path is itself multi-threaded with a lock per C: libxsmm_gemm_batch_omp, mmbatch
-// with several tasks). A batch of few, long runs is a handful of sequential chains and leaves the chip idle; here such a
-// batch is cut into segments of `len` items, a wave sums the products of its segment from zero and adds the sum to C with
-// floating-point atomics (one C-sized atomic update per segment instead of a C read and write per run). Returns 0 when
-// the batch has chains enough (or repeats out of order) and is walked run by run in batch order.
-__device__ __forceinline__ int split_len(const int* flags, long long batch)
+#if XRUNS
+// When a batch is not walked run by run. (1) C blocks repeat out of order: no walk in batch order can keep them apart.
+// (2) XSPLIT -- relaxed order, the caller's reference path is itself multi-threaded with a lock per C
+// (libxsmm_gemm_batch_omp, mmbatch with several tasks) -- and the batch is a handful of long runs, i.e. of sequential
+// chains that leave the chip idle. Such a batch is cut into segments of `len` items; a wave sums the products of a run
+// inside its segment from zero and adds the sum to C with floating-point atomics (one C-sized atomic update per segment
+// instead of a C read and write per run). Returns 0 when the batch is walked run by run, in batch order.
+__device__ __forceinline__ int segment_len(const int* flags, long long batch)
 {
-  if (nullptr == flags || 0 != flags[1]) return 0;
-  const long long runs = batch - flags[0];
-  if (runs >= 2048 || 16 * runs > batch) return 0;
+  if (nullptr == flags) return 0;
+  if (0 == flags[1]) {
+    const long long runs = batch - flags[0];
+    if (!XSPLIT || runs >= 2048 || 16 * runs > batch) return 0;
+  }
   const long long len = (batch + 4095) / 4096;
   return (int)(len < 8 ? 8 : (len > 64 ? 64 : len));
 }
@@ -338,11 +341,8 @@ extern "C" __global__ __launch_bounds__(256) void xsmm_smm_op(DevAddr ad, long l
   const int tx = lane & (TGM - 1), ty = lane >> 4;
   const int ncol0 = wave * NQ + ty * TN;
   if (nullptr != ad.flags) {
-    if (0 != ad.flags[1]) return;                                    // C repeats out of order: the atomic kernel owns this batch
     if (8LL * ad.flags[0] < 7LL * batch) return;                     // runs shorter than 8 on average: the wave form owns it
-#if XSPLIT
-    if (0 != split_len(ad.flags, batch)) return;                     // few long runs, order relaxed: the wave form cuts them up
-#endif
+    if (0 != segment_len(ad.flags, batch)) return;                   // not walked run by run: the wave form cuts it into segments
   }
   T ra[D][NLA][VA], rb[D][NLB][VB];
   int buf = 0;
@@ -420,20 +420,10 @@ extern "C" __global__ __launch_bounds__(64 * XWAVES) void xsmm_smm_op(DevAddr ad
   // keeps C in registers and adds the products in batch order -- what the reference's sequential loop does. Chunks of 64
   // items are dealt round-robin to the waves; run heads are found 64 items at a time (one item per lane, __ballot). A
   // wave walks its chain (see chain_of_chunk) item by item with the operands of the next D items in flight (and the C of
-  // the next item, if it starts a run). A batch of distinct C blocks is the special case "all heads".
-  if (nullptr != ad.flags) {
-    if (0 != ad.flags[1]) return;                  // C blocks repeat out of order: the atomic kernel owns this batch
-#if XSPLIT
-    if (XHASWG && 0 == split_len(ad.flags, batch) && 8LL * ad.flags[0] >= 7LL * batch) return;
-#else
-    if (XHASWG && 8LL * ad.flags[0] >= 7LL * batch) return; // runs of 8 and more on average: the work-group form owns this batch
-#endif
-  }
-#if XSPLIT
-  const int seg = split_len(ad.flags, batch);
-#else
-  constexpr int seg = 0;
-#endif
+  // the next item, if it starts a run). A batch of distinct C blocks is the special case "all heads". Batches that
+  // cannot (or need not) be walked in batch order go segment by segment, see segment_len.
+  const int seg = segment_len(ad.flags, batch);
+  if (XHASWG && nullptr != ad.flags && 0 == seg && 8LL * ad.flags[0] >= 7LL * batch) return; // runs of 8 and more on average: the work-group form owns this batch
   const long long step = (0 != seg ? seg : 64);
   T ra[D][NLA][VA], rb[D][NLB][VB], rc[NLC][VC];
   for (long long chunk = w * step; chunk < batch; chunk += W * step) {
@@ -461,15 +451,12 @@ extern "C" __global__ __launch_bounds__(64 * XWAVES) void xsmm_smm_op(DevAddr ad
         const long long i = i0 + s;
         if (i < end) {
           if (is_head(heads, chunk, i)) { // item i opens a run: close the previous one, take over its C
-#if XSPLIT
             if (0 != seg) {
               if (nullptr != pc) atomic_c(Cs, pc, lane, tx, ty, acc);
               pc = resolve<T>(ad.c, ad.ic, ad.sc, ad, i);
               acc_from_c(Cs, tx, ty, acc, true);
             }
-            else
-#endif
-            {
+            else {
               if (nullptr != pc) store_c(Cs, pc, lane, tx, ty, acc);
               pc = resolve<T>(ad.c, ad.ic, ad.sc, ad, i);
               if (!XBETA0) { park_c(Cs, lane, rc); wave_lds_sync(); }
@@ -489,11 +476,8 @@ extern "C" __global__ __launch_bounds__(64 * XWAVES) void xsmm_smm_op(DevAddr ad
         }
       }
     }
-#if XSPLIT
     if (0 != seg) atomic_c(Cs, pc, lane, tx, ty, acc);
-    else
-#endif
-    store_c(Cs, pc, lane, tx, ty, acc);
+    else store_c(Cs, pc, lane, tx, ty, acc);
   }
 #else
   if (w >= batch) return;
@@ -756,6 +740,7 @@ bool smm_jit_eligible(const SmmBatch& s)
   const bool enabled = (nullptr == env_jit || 0 != atoi(env_jit));
   if (!enabled || 0 != s.general || SYNC_ATOMIC == s.sync) return false;
   if (SYNC_NONE != s.sync && 0 != (s.flags & LIBXSMM_GEMM_FLAG_BETA_0)) return false; // (never chosen: beta == 0 needs no care)
+  if (SYNC_DEVICE == s.sync && 0 == s.c_atomics) return false;  // the generic kernel's compare-and-swap path serves mapped host memory
   if (s.lda != s.m || s.ldc != s.m) return false;
   if (0 != (s.flags & LIBXSMM_GEMM_FLAG_TRANS_B) ? (s.ldb != s.n) : (s.ldb != s.k)) return false;
   if (s.m > 32 || s.n > 32) { // work-group-per-item form: 16x16 threads x (<=4x4) tile, K chunked; independent C only
@@ -855,8 +840,8 @@ static int smm_jit_launch_variant(const SmmBatch& s, int variant, void* stream)
   if (per_cu < 1) per_cu = 1;
   if (0 < bpc_env) per_cu = bpc_env;
   // run form: a wave scans chunks of 64 items for run heads, so the grid is sized by chunks
-  // (segments of 8 items and more when few long runs may be cut up: waves without a chunk leave at once)
-  const long long units = (0 != (variant & SMM_JIT_RUNS)) ? ((batch + ((variant & SMM_JIT_SPLIT) ? 7 : 63)) / ((variant & SMM_JIT_SPLIT) ? 8 : 64)) : batch;
+  // (the verdict is on the device: segments of 8 items and more if the batch is cut up -- waves without a chunk leave at once)
+  const long long units = (0 != (variant & SMM_JIT_RUNS)) ? ((nullptr != ad.flags ? (batch + 7) / 8 : (batch + 63) / 64)) : batch;
   long long blocks = (units + waves - 1) / waves;
   if (blocks > 256 * per_cu) blocks = 256 * per_cu;
   if (blocks < 1) blocks = 1;

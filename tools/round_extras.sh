@@ -4,6 +4,8 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 timeout -k 10 300 python tools/bench_dense.py all 7 2>&1 | grep -v amdgpu.ids > gpurun_out/dense_shapes.txt &&
 (timeout -k 10 200 python tools/bench_sparse.py spmdm 10; timeout -k 10 200 python tools/bench_sparse.py fsspmdm 10) 2>&1 | grep -v amdgpu.ids > gpurun_out/sparse_phases.txt &&
-GPU_MAX_HW_QUEUES=16 timeout -k 10 200 python tools/bench_cp2k.py 524288 5 2>&1 | grep -v amdgpu.ids > gpurun_out/cp2k_stacks.txt &&
+(echo "== libxsmm_gemm_batch (sums in batch order), GPU_MAX_HW_QUEUES=16"; GPU_MAX_HW_QUEUES=16 timeout -k 10 200 python tools/bench_cp2k.py 524288 5 0;
+ echo "== libxsmm_gemm_batch_omp (order relaxed, as in the reference's multi-threaded path), GPU_MAX_HW_QUEUES=16"; GPU_MAX_HW_QUEUES=16 timeout -k 10 200 python tools/bench_cp2k.py 524288 5 1;
+ echo "== full config 5 on one GPU (4 194 304 products), default queues"; timeout -k 10 200 python tools/bench_cp2k.py 4194304 5 0; timeout -k 10 200 python tools/bench_cp2k.py 4194304 5 1) 2>&1 | grep -v amdgpu.ids > gpurun_out/cp2k_stacks.txt &&
 timeout -k 10 300 bash tools/pmc_spmdm.sh
 tail -n 4 gpurun_out/dense_shapes.txt gpurun_out/sparse_phases.txt gpurun_out/cp2k_stacks.txt

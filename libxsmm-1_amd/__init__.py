@@ -123,6 +123,9 @@ def _declare(L):
     sig("libxsmm_xmmdispatch", vp, vp)
     sig("libxsmm_dmmdispatch", vp, i, i, i, c_int_p, c_int_p, c_int_p, C.POINTER(C.c_double), C.POINTER(C.c_double), c_int_p, c_int_p)
     sig("libxsmm_smmdispatch", vp, i, i, i, c_int_p, c_int_p, c_int_p, C.POINTER(C.c_float), C.POINTER(C.c_float), c_int_p, c_int_p)
+    sig("libxsmm_wimmdispatch", vp, i, i, i, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p)
+    for name in ("libxsmm_wsmmdispatch", "libxsmm_bsmmdispatch", "libxsmm_bmmdispatch"):
+        sig(name, vp, i, i, i, c_int_p, c_int_p, c_int_p, C.POINTER(C.c_float), C.POINTER(C.c_float), c_int_p, c_int_p)
     sig("libxsmm_dmmdispatch_reducebatch", vp, i, i, i, c_int_p, c_int_p, c_int_p, C.POINTER(C.c_double), C.POINTER(C.c_double), c_int_p, c_int_p)
     sig("libxsmm_smmdispatch_reducebatch", vp, i, i, i, c_int_p, c_int_p, c_int_p, C.POINTER(C.c_float), C.POINTER(C.c_float), c_int_p, c_int_p)
     sig("libxsmm_wimmdispatch", vp, i, i, i, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p)

@@ -297,9 +297,56 @@ bool try_record(const libxsmm_gemm_descriptor& d, const void* a, const void* b, 
 namespace xsmm {
 
 // What a kernel thunk does when user code calls the bare function pointer.
-void call_kernel(Kernel* k, const void* a, const void* b, void* c, const void* x3)
+// One product of a low-precision kernel, or a batch of them with independent C operands (device-reachable operands).
+SmmBatch lowp_from_descriptor(const libxsmm_gemm_descriptor& d, float scf)
+{
+  SmmBatch s; memset(&s, 0, sizeof(s));
+  const int ip = LIBXSMM_GETENUM_INP(d.datatype), op = LIBXSMM_GETENUM_OUT(d.datatype);
+  s.lowp = (LIBXSMM_GEMM_PRECISION_I16 == ip) ? (LIBXSMM_GEMM_PRECISION_I32 == op ? 1 : 2) : (LIBXSMM_GEMM_PRECISION_F32 == op ? 3 : 4);
+  s.scf = scf; s.typesize = 2;
+  s.m = (int)d.m; s.n = (int)d.n; s.k = (int)d.k; s.lda = (int)d.lda; s.ldb = (int)d.ldb; s.ldc = (int)d.ldc;
+  s.flags = d.flags & LIBXSMM_GEMM_FLAG_BETA_0;
+  return s;
+}
+
+int lowp_launch(const SmmBatch& s)
+{
+  const char* name = "";
+  const int e = launch_smm_lowp(s, device().stream, &name);
+  note_launch(name);
+  if (0 != e) fprintf(stderr, "LIBXSMM-AMD ERROR: kernel launch failed (%s, hip error %d)\n", name, e);
+  return e;
+}
+
+int lowp_single_execute(SmmBatch s, const void* a, const void* b, void* c)
+{
+  if (!device_ready()) { fail_no_device("a dispatched low-precision kernel"); return EXIT_FAILURE; }
+  s.mode = ADDR_STRIDED; s.batch = 1; s.sync = SYNC_NONE;
+  if (is_device_ptr(a) && is_device_ptr(b) && is_device_ptr(c)) {
+    s.a = a; s.b = b; s.c = c;
+    if (0 != lowp_launch(s)) return EXIT_FAILURE;
+    settle(a, b, c);
+    return EXIT_SUCCESS;
+  }
+  const size_t csize = (4 == s.lowp ? 2 : 4);
+  const size_t ba = ((size_t)(s.k / 2 - 1) * s.lda + s.m) * 2 * 2, bb = ((size_t)(s.n - 1) * s.ldb + s.k) * 2, bc = ((size_t)(s.n - 1) * s.ldc + s.m) * csize;
+  char* const da = static_cast<char*>(scratch(3, ba)); char* const db = static_cast<char*>(scratch(4, bb)); char* const dc = static_cast<char*>(scratch(5, bc));
+  if (nullptr == da || nullptr == db || nullptr == dc) return EXIT_FAILURE;
+  if (0 != h2d(da, a, ba) || 0 != h2d(db, b, bb) || 0 != h2d(dc, c, bc)) return EXIT_FAILURE;
+  s.a = da; s.b = db; s.c = dc;
+  if (0 != lowp_launch(s)) return EXIT_FAILURE;
+  return 0 == d2h(c, dc, bc) ? EXIT_SUCCESS : EXIT_FAILURE;
+}
+
+void call_kernel(Kernel* k, const void* a, const void* b, void* c, const void* x3, const void* x6)
 {
   if (nullptr == k) return;
+  if (KC_LOWP == k->kclass) { // i16 -> f32 kernels are called as kernel(a, b, c, pa, pb, pc, &scf) (samples/xgemm/kernel.c:262)
+    const bool scaled = (LIBXSMM_GEMM_PRECISION_I16 == LIBXSMM_GETENUM_INP(k->desc.datatype) && LIBXSMM_GEMM_PRECISION_F32 == LIBXSMM_GETENUM_OUT(k->desc.datatype));
+    if (scaled && nullptr == x6) return;
+    (void)lowp_single_execute(lowp_from_descriptor(k->desc, scaled ? *static_cast<const float*>(x6) : 1.f), a, b, c);
+    return;
+  }
   if (KC_DENSE == k->kclass) {
     if (try_record(k->desc, a, b, c)) return;
     (void)single_execute(from_descriptor(k->desc), a, b, c);
@@ -373,6 +420,35 @@ LIBXSMM_API int libxsmm_mmbatch_kernel(libxsmm_xmmfunction kernel, libxsmm_blasi
   const long long size = (batchsize < 0 ? -(long long)batchsize : batchsize);
   const long long tasksize = (size + ntasks - 1) / ntasks;
   const long long begin = (long long)tid * tasksize, span = begin + tasksize, end = (span < size ? span : size);
+  if (KC_LOWP == k->kclass) { // batches of low-precision products: independent C operands, everything device-reachable
+    if (!device_ready()) { fail_no_device("libxsmm_mmbatch_kernel"); return EXIT_FAILURE; }
+    if (end <= begin) return EXIT_SUCCESS;
+    if (LIBXSMM_GEMM_PRECISION_I16 == LIBXSMM_GETENUM_INP(k->desc.datatype) && LIBXSMM_GEMM_PRECISION_F32 == LIBXSMM_GETENUM_OUT(k->desc.datatype)) return EXIT_FAILURE; // no way to pass the scaling factor
+    SmmBatch s = lowp_from_descriptor(k->desc, 1.f);
+    s.batch = end - begin; s.sync = SYNC_NONE;
+    bool ok = is_device_ptr(a) && is_device_ptr(b) && is_device_ptr(c);
+    if (ok && 0 != index_stride) {
+      s.mode = ADDR_INDEX; s.index_base = index_base; s.index_stride = index_stride; s.a = a; s.b = b; s.c = c;
+      s.ia = device_indexes(nullptr != stride_a ? reinterpret_cast<const int*>(reinterpret_cast<const char*>(stride_a) + begin * index_stride) : nullptr, index_stride, s.batch, 0, &ok);
+      s.ib = device_indexes(nullptr != stride_b ? reinterpret_cast<const int*>(reinterpret_cast<const char*>(stride_b) + begin * index_stride) : nullptr, index_stride, s.batch, 1, &ok);
+      s.ic = device_indexes(nullptr != stride_c ? reinterpret_cast<const int*>(reinterpret_cast<const char*>(stride_c) + begin * index_stride) : nullptr, index_stride, s.batch, 2, &ok);
+    }
+    else if (ok) { // arrays of pointers in device-reachable memory
+      s.mode = ADDR_POINTER;
+      s.sa = (nullptr != stride_a ? ((long long)*stride_a - (long long)index_base * (long long)sizeof(void*)) : 0);
+      s.sb = (nullptr != stride_b ? ((long long)*stride_b - (long long)index_base * (long long)sizeof(void*)) : 0);
+      s.sc = (nullptr != stride_c ? ((long long)*stride_c - (long long)index_base * (long long)sizeof(void*)) : 0);
+      s.a = static_cast<const char*>(a) + s.sa * begin; s.b = static_cast<const char*>(b) + s.sb * begin; s.c = static_cast<char*>(c) + s.sc * begin;
+    }
+    if (!ok) {
+      fprintf(stderr, "LIBXSMM-AMD ERROR: batches of low-precision products need operands the GPU can reach (libxsmm_malloc or device memory)\n");
+      return EXIT_FAILURE;
+    }
+    if (0 != lowp_launch(s)) return EXIT_FAILURE;
+    if (ADDR_INDEX == s.mode) settle(a, b, c);
+    else (void)stream_sync();
+    return EXIT_SUCCESS;
+  }
   SmmBatch s = from_descriptor(k->desc);
   s.relaxed = relaxed_order(ntasks, index_stride, c) ? 1 : 0;
   // ntasks > 1: the tasks run concurrently on the caller's threads and may share C across slices; as in the

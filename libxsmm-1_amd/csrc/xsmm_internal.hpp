@@ -58,6 +58,7 @@ struct SmmBatch {
   int sync;                 // SyncMode
   const int* devflags;      // SYNC_DEVICE*: device int[2] written by the check kernel earlier on the same stream
   int c_atomics;            // SYNC_DEVICE: != 0 if floating-point atomics reach C (device memory, not host memory the GPU maps)
+  int lowp; float scf;      // low-precision kernels (kernels/smm_lowp.hip): 1 i16->i32, 2 i16->f32 (times scf), 3 bf16->f32, 4 bf16->bf16; 0: f32/f64
   int relaxed;              // != 0: sums into a shared C may be formed in any order (the caller's reference path is multi-threaded)
   int use_mfma;             // policy bit (0: scalar FMA only)
   // general form used by the BLAS-like fallback (libxsmm_?gemm with alpha/beta/trans outside the SMM domain)
@@ -66,6 +67,7 @@ struct SmmBatch {
 
 // returns hipError_t as int (0 == success); *name receives a static string naming the kernel variant
 int launch_smm_batch(const SmmBatch& args, void* stream, const char** name);
+int launch_smm_lowp(const SmmBatch& args, void* stream, const char** name);  // args.lowp != 0; independent C operands
 
 constexpr int FLAG_SLOT_BLOCKS = 512; // work-groups of the C ordering check (each leaves a pair of counts in the flag slot)
 // detects how C operands alias across the batch: out[0] = number of i with c_i == c_{i-1},
@@ -144,7 +146,8 @@ void note_launch(const char* name);
 // grow-only device scratch, one per thread-local slot id
 void* scratch(int slot, size_t bytes);
 
-enum KernelClass : int { KC_DENSE = 0, KC_REDUCE = 1, KC_CSR_REG = 2, KC_TEXT = 3 /* pattern kernel compiled from generated text (SOA family) */ };
+enum KernelClass : int { KC_DENSE = 0, KC_REDUCE = 1, KC_CSR_REG = 2, KC_TEXT = 3 /* pattern kernel compiled from generated text (SOA family) */,
+  KC_LOWP = 4 /* i16 / bf16 inputs (kernels/smm_lowp.hip) */ };
 
 struct Kernel {                 // what a dispatched function pointer stands for
   libxsmm_gemm_descriptor desc;
@@ -164,7 +167,7 @@ int text_kernel_execute(void* text, const void* a, const void* b, void* c, long 
 void text_kernel_destroy(void* text);
 void* make_thunk(Kernel* k);                           // executable stub carrying k
 void free_thunk(void* thunk);
-void call_kernel(Kernel* k, const void* a, const void* b, void* c, const void* x3); // what a thunk does
+void call_kernel(Kernel* k, const void* a, const void* b, void* c, const void* x3, const void* x6); // what a thunk does (x3, x6: the 4th and 7th argument of the call)
 
 int verbosity();
 bool once(int* flag);   // true the first time

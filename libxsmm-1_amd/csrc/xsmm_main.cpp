@@ -103,10 +103,12 @@ void init_once()
 // trampolines is used instead.
 extern "C" void xsmm_thunk_entry(void);
 extern "C" void xsmm_thunk_dispatch(const void* a, const void* b, void* c, const void* x3, const void* x4,
-                                    const void* x5, void* ctx)
-{
-  (void)x4; (void)x5;
-  call_kernel(static_cast<Kernel*>(ctx), a, b, c, x3);
+                                    const void* x5, void* ctx, const void* return_address, const void* x6)
+{ // stack at this point: [ctx pushed by xsmm_thunk_entry][the user's return address][the user's 7th argument, if any]:
+  // x6 is what i16 -> f32 kernels receive as the scaling factor (kernel(a, b, c, pa, pb, pc, &scf)); for every other
+  // kernel it is an unused word of the caller's frame
+  (void)x4; (void)x5; (void)return_address;
+  call_kernel(static_cast<Kernel*>(ctx), a, b, c, x3, x6);
 }
 
 __asm__(
@@ -138,8 +140,10 @@ template<int I> void pool_tramp(const void* a, const void* b, void* c, ...)
   // area; when the caller passed only three arguments this yields an unused garbage value, never a fault.
   va_list ap; va_start(ap, c);
   const void* const x3 = va_arg(ap, const void*);
+  (void)va_arg(ap, const void*); (void)va_arg(ap, const void*);
+  const void* const x6 = va_arg(ap, const void*); // 7th argument (first one on the stack): the scaling factor of i16 -> f32 kernels
   va_end(ap);
-  call_kernel(g_pool_ctx[I], a, b, c, x3);
+  call_kernel(g_pool_ctx[I], a, b, c, x3, x6);
 }
 template<int... I> void fill_pool(void* (&tab)[POOL], std::integer_sequence<int, I...>)
 {
@@ -357,11 +361,24 @@ LIBXSMM_API libxsmm_gemm_descriptor* libxsmm_gemm_descriptor_init(libxsmm_descri
 namespace {
 
 // What the reference's generator rejects (src/generator_gemm.c:211-234) plus what this back end lacks.
+// 1 i16->i32, 2 i16->f32, 3 bf16->f32, 4 bf16->bf16 (0: not a low-precision descriptor)
+int lowp_kind(const libxsmm_gemm_descriptor& d)
+{
+  const int ip = LIBXSMM_GETENUM_INP(d.datatype), op = LIBXSMM_GETENUM_OUT(d.datatype);
+  if (LIBXSMM_GEMM_PRECISION_I16 == ip) return LIBXSMM_GEMM_PRECISION_I32 == op ? 1 : (LIBXSMM_GEMM_PRECISION_F32 == op ? 2 : 0);
+  if (LIBXSMM_GEMM_PRECISION_BF16 == ip) return LIBXSMM_GEMM_PRECISION_F32 == op ? 3 : (LIBXSMM_GEMM_PRECISION_BF16 == op ? 4 : 0);
+  return 0;
+}
+
 bool desc_buildable(const libxsmm_gemm_descriptor& d)
 {
   const int ip = LIBXSMM_GETENUM_INP(d.datatype), op = LIBXSMM_GETENUM_OUT(d.datatype);
-  if (!((LIBXSMM_GEMM_PRECISION_F64 == ip && LIBXSMM_GEMM_PRECISION_F64 == op) ||
-        (LIBXSMM_GEMM_PRECISION_F32 == ip && LIBXSMM_GEMM_PRECISION_F32 == op))) return false; // no low-precision kernels yet
+  if (0 != lowp_kind(d)) { // constraints of the reference's generator (src/generator_gemm.c:121-147,236-243)
+    if (0 != (d.k % 2) || 0 != (d.flags & (LIBXSMM_GEMM_FLAG_TRANS_B | LIBXSMM_GEMM_FLAG_BATCH_REDUCE))) return false;
+    if (LIBXSMM_GEMM_PRECISION_BF16 == op && 0 != (d.m % 16)) return false;
+  }
+  else if (!((LIBXSMM_GEMM_PRECISION_F64 == ip && LIBXSMM_GEMM_PRECISION_F64 == op) ||
+             (LIBXSMM_GEMM_PRECISION_F32 == ip && LIBXSMM_GEMM_PRECISION_F32 == op))) return false;
   if (0 != (d.flags & LIBXSMM_GEMM_FLAG_TRANS_A)) return false;
   if (0 == d.m || 0 == d.n || 0 == d.k) return false;
   if (d.lda < d.m) return false;                                                   // LIBXSMM_ERR_LDA
@@ -389,7 +406,7 @@ LIBXSMM_API libxsmm_xmmfunction libxsmm_xmmdispatch(const libxsmm_gemm_descripto
   if (LIBXSMM_TARGET_ARCH_GENERIC == g_target_archid.load()) return result; // LIBXSMM_TARGET=generic: JIT disabled
   libxsmm_gemm_descriptor d = *descriptor;
   if (0 != (0x80 & d.prefetch)) d.prefetch = (unsigned char)g_auto_prefetch.load(); // "sign bit" => auto (:2146)
-  const int kclass = (0 != (d.flags & LIBXSMM_GEMM_FLAG_BATCH_REDUCE)) ? KC_REDUCE : KC_DENSE;
+  const int kclass = (0 != lowp_kind(d)) ? KC_LOWP : ((0 != (d.flags & LIBXSMM_GEMM_FLAG_BATCH_REDUCE)) ? KC_REDUCE : KC_DENSE);
   const Key key = make_key(d, kclass);
   Registry& r = registry();
   const int p = (LIBXSMM_GEMM_PRECISION_F64 == LIBXSMM_GETENUM_INP(d.datatype)) ? 0 : 1, b = bucket(d.m, d.n, d.k);
@@ -448,17 +465,33 @@ LIBXSMM_API libxsmm_smmfunction_reducebatch libxsmm_smmdispatch_reducebatch(libx
   const float* alpha, const float* beta, const int* flags, const int* prefetch)
 { XSMM_DISPATCH_BODY(libxsmm_sgemm_descriptor_init, float, LIBXSMM_GEMM_FLAG_BATCH_REDUCE, smr); }
 
-// low-precision dispatchers exist for ABI completeness; no kernel => NULL, which callers must handle anyway
-// (the reference returns NULL whenever JIT is unavailable for the type/arch, src/libxsmm_main.c:2200-2259)
-#define XSMM_NULL_DISPATCH(NAME, RET, AT)                                                                    \
-LIBXSMM_API RET NAME(libxsmm_blasint m, libxsmm_blasint n, libxsmm_blasint k,                                \
-  const libxsmm_blasint* lda, const libxsmm_blasint* ldb, const libxsmm_blasint* ldc,                        \
-  const AT* alpha, const AT* beta, const int* flags, const int* prefetch)                                    \
-{ (void)m; (void)n; (void)k; (void)lda; (void)ldb; (void)ldc; (void)alpha; (void)beta; (void)flags; (void)prefetch; return nullptr; }
-XSMM_NULL_DISPATCH(libxsmm_wimmdispatch, libxsmm_wimmfunction, int)
-XSMM_NULL_DISPATCH(libxsmm_wsmmdispatch, libxsmm_wsmmfunction, float)
-XSMM_NULL_DISPATCH(libxsmm_bsmmdispatch, libxsmm_bsmmfunction, float)
-XSMM_NULL_DISPATCH(libxsmm_bmmdispatch, libxsmm_bmmfunction, float)
+// low-precision dispatchers (src/libxsmm_main.c:2198-2259) and their descriptor initialisers (src/libxsmm_generator.c:93-185)
+#define XSMM_LOWP_INIT(NAME, AT, IPREC, OPREC)                                                               \
+LIBXSMM_API libxsmm_gemm_descriptor* NAME(libxsmm_descriptor_blob* blob,                                     \
+  libxsmm_blasint m, libxsmm_blasint n, libxsmm_blasint k, libxsmm_blasint lda, libxsmm_blasint ldb, libxsmm_blasint ldc, \
+  AT alpha, AT beta, int flags, int prefetch)                                                                \
+{ return desc_init(blob, IPREC, OPREC, m, n, k, lda, ldb, ldc, (double)alpha, (double)beta, flags, prefetch); }
+XSMM_LOWP_INIT(libxsmm_wigemm_descriptor_init, int, LIBXSMM_GEMM_PRECISION_I16, LIBXSMM_GEMM_PRECISION_I32)
+XSMM_LOWP_INIT(libxsmm_wsgemm_descriptor_init, float, LIBXSMM_GEMM_PRECISION_I16, LIBXSMM_GEMM_PRECISION_F32)
+XSMM_LOWP_INIT(libxsmm_bsgemm_descriptor_init, float, LIBXSMM_GEMM_PRECISION_BF16, LIBXSMM_GEMM_PRECISION_F32)
+XSMM_LOWP_INIT(libxsmm_bgemm_descriptor_init, float, LIBXSMM_GEMM_PRECISION_BF16, LIBXSMM_GEMM_PRECISION_BF16)
+
+LIBXSMM_API libxsmm_wimmfunction libxsmm_wimmdispatch(libxsmm_blasint m, libxsmm_blasint n, libxsmm_blasint k,
+  const libxsmm_blasint* lda, const libxsmm_blasint* ldb, const libxsmm_blasint* ldc,
+  const int* alpha, const int* beta, const int* flags, const int* prefetch)
+{ XSMM_DISPATCH_BODY(libxsmm_wigemm_descriptor_init, int, 0, wimm); }
+LIBXSMM_API libxsmm_wsmmfunction libxsmm_wsmmdispatch(libxsmm_blasint m, libxsmm_blasint n, libxsmm_blasint k,
+  const libxsmm_blasint* lda, const libxsmm_blasint* ldb, const libxsmm_blasint* ldc,
+  const float* alpha, const float* beta, const int* flags, const int* prefetch)
+{ XSMM_DISPATCH_BODY(libxsmm_wsgemm_descriptor_init, float, 0, wsmm); }
+LIBXSMM_API libxsmm_bsmmfunction libxsmm_bsmmdispatch(libxsmm_blasint m, libxsmm_blasint n, libxsmm_blasint k,
+  const libxsmm_blasint* lda, const libxsmm_blasint* ldb, const libxsmm_blasint* ldc,
+  const float* alpha, const float* beta, const int* flags, const int* prefetch)
+{ XSMM_DISPATCH_BODY(libxsmm_bsgemm_descriptor_init, float, 0, bsmm); }
+LIBXSMM_API libxsmm_bmmfunction libxsmm_bmmdispatch(libxsmm_blasint m, libxsmm_blasint n, libxsmm_blasint k,
+  const libxsmm_blasint* lda, const libxsmm_blasint* ldb, const libxsmm_blasint* ldc,
+  const float* alpha, const float* beta, const int* flags, const int* prefetch)
+{ XSMM_DISPATCH_BODY(libxsmm_bgemm_descriptor_init, float, 0, bmm); }
 
 // ---- caller-owned sparse kernels (src/libxsmm_main.c:2523-2582) ----------------------------------------------
 namespace {

@@ -827,3 +827,45 @@ void xo_soa_rm_bc_##SUFFIX(int flags, int m, int n, int k, int lda, int ldb, int
 }
 XO_DEFINE_SOA(f64, double, fma)
 XO_DEFINE_SOA(f32, float, fmaf)
+
+/* ---- low-precision dense kernels: the gold loops of samples/xgemm/kernel.c (see xsmm_oracle.h) ---- */
+static float xo_bf16_to_f32(unsigned short v) { union { unsigned int u; float f; } t; t.u = (unsigned int)v << 16; return t.f; }
+static unsigned short xo_f32_to_bf16_trunc(float f) { union { unsigned int u; float f; } t; t.f = f; return (unsigned short)(t.u >> 16); }
+
+int xo_gemm_lowp(int kind, int beta0, int m, int n, int k, int lda, int ldb, int ldc,
+                 const unsigned short* a, const unsigned short* b, void* c, float scf)
+{
+  int i, j, s, k2;
+  if (kind < 0 || kind > 3 || 0 != (k % 2) || lda < m || ldb < k || ldc < m) return 1;
+  for (j = 0; j < n; ++j) {
+    for (i = 0; i < m; ++i) {
+      const size_t ci = (size_t)j * ldc + i;
+      if (0 == kind) { /* kernel.c:915-927; the int sum wraps like the hardware's (unsigned arithmetic here: defined) */
+        unsigned int acc = beta0 ? 0u : (unsigned int)((int*)c)[ci];
+        for (s = 0; s < k / 2; ++s) for (k2 = 0; k2 < 2; ++k2) {
+          acc += (unsigned int)((int)(short)a[(size_t)s * lda * 2 + (size_t)i * 2 + k2] * (int)(short)b[(size_t)j * ldb + (size_t)s * 2 + k2]);
+        }
+        ((int*)c)[ci] = (int)acc;
+      }
+      else if (1 == kind) { /* kernel.c:1007-1021: (float)iprod * scf, then the add -- three roundings, no contraction */
+        volatile float acc = beta0 ? 0.f : ((float*)c)[ci];
+        for (s = 0; s < k / 2; ++s) for (k2 = 0; k2 < 2; ++k2) {
+          const int iprod = (int)(short)a[(size_t)s * lda * 2 + (size_t)i * 2 + k2] * (int)(short)b[(size_t)j * ldb + (size_t)s * 2 + k2];
+          volatile float fprod = (float)iprod;
+          volatile float scaled = fprod * scf;
+          acc = acc + scaled;
+        }
+        ((float*)c)[ci] = acc;
+      }
+      else { /* kernel.c:1104-1123 and :1207-1229: the product of two bf16 values is exact in a float, one rounding per add */
+        volatile float acc = beta0 ? 0.f : (2 == kind ? ((float*)c)[ci] : xo_bf16_to_f32(((unsigned short*)c)[ci]));
+        for (s = 0; s < k / 2; ++s) for (k2 = 0; k2 < 2; ++k2) {
+          volatile float prod = xo_bf16_to_f32(a[(size_t)s * lda * 2 + (size_t)i * 2 + k2]) * xo_bf16_to_f32(b[(size_t)j * ldb + (size_t)s * 2 + k2]);
+          acc = acc + prod;
+        }
+        if (2 == kind) ((float*)c)[ci] = acc; else ((unsigned short*)c)[ci] = xo_f32_to_bf16_trunc(acc);
+      }
+    }
+  }
+  return 0;
+}

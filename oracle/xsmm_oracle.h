@@ -155,6 +155,15 @@ void xo_bgemm_transpose_b(const xo_bgemm* h, const void* src, void* dst);
 void xo_bgemm_order(int order, int w_i, int nw_i, int nw_j, int nw_k, int* i2, int* j2, int* k2);
 void xo_bgemm_st(int arith, const xo_bgemm* h, const void* a, const void* b, void* c); /* nthreads = 1 */
 
+/* ---- low-precision dense kernels (libxsmm_wimmdispatch/wsmmdispatch/bsmmdispatch/bmmdispatch, src/libxsmm_main.c:2198-2259) ----
+ * The arithmetic is the gold loop the reference's own harness checks these kernels with (samples/xgemm/kernel.c: i16->i32
+ * :915-927, i16->f32 with a scaling factor :1007-1021, bf16->f32 :1104-1123, bf16->bf16 :1207-1229): A is stored in pairs
+ * of k ("VNNI", a[(k/2)*lda*2 + m*2 + k%2]), B column-major (b[n*ldb + k]), C column-major; k is even; per C element the
+ * terms are added in ascending k. bf16 values are the upper halves of floats; a bf16 result is the upper half of the
+ * float sum (truncation, as the harness does). kind: 0 = i16->i32, 1 = i16->f32 (times scf), 2 = bf16->f32, 3 = bf16->bf16. */
+int xo_gemm_lowp(int kind, int beta0, int m, int n, int k, int lda, int ldb, int ldc,
+                 const unsigned short* a, const unsigned short* b, void* c, float scf);
+
 /* ---- input generators used by the reference's samples ---- */
 /* LIBXSMM_MATINIT, seed != 0 branch (include/libxsmm_frontend.h:414-431) */
 void xo_matinit_f64(int seed, double* dst, int nrows, int ncols, int ld, double scale);

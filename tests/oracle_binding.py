@@ -262,3 +262,11 @@ def rng_seed(seed):
 
 def rng_f64():
     return lib().xo_rng_f64()
+
+
+def gemm_lowp(kind, beta0, m, n, k, lda, ldb, ldc, a, b, c, scf=1.0):
+    """low-precision gold loops (samples/xgemm/kernel.c); kind 0 i16->i32, 1 i16->f32, 2 bf16->f32, 3 bf16->bf16; a, b uint16/int16 arrays"""
+    f = lib().xo_gemm_lowp
+    f.argtypes = [C.c_int] * 8 + [C.c_void_p] * 3 + [C.c_float]
+    f.restype = C.c_int
+    return f(kind, beta0, m, n, k, lda, ldb, ldc, a.ctypes.data, b.ctypes.data, c.ctypes.data, scf)

@@ -191,7 +191,7 @@ def test_dispatch_rules_and_kernel_info(xs):
     assert not L.libxsmm_smmdispatch(32, 32, 32, xs.iptr(16), None, None, None, None, None, None)  # lda < m (generator_gemm.c:211)
     assert not L.libxsmm_smmdispatch(32, 32, 32, None, xs.iptr(8), None, None, None, None, None)   # ldb < k
     assert not L.libxsmm_smmdispatch(32, 32, 32, None, None, xs.iptr(31), None, None, None, None)  # ldc < m
-    assert not L.libxsmm_wimmdispatch(8, 8, 8, None, None, None, None, None, None, None)           # low precision: NULL (ABI-legal)
+    assert not L.libxsmm_wimmdispatch(8, 8, 7, None, None, None, None, None, None, None)           # low precision: k must be even (tests/test_lowp.py)
     assert not L.libxsmm_xmmdispatch(None)
     # TRANS_B: ldb is checked against n
     assert L.libxsmm_dmmdispatch(8, 16, 4, None, xs.iptr(16), None, None, None, xs.iptr(xs.FLAG_TRANS_B), None)

@@ -1,0 +1,187 @@
+"""Low-precision dense kernels: libxsmm_wimmdispatch (i16 -> i32), wsmmdispatch (i16 -> f32, scaled), bsmmdispatch
+(bf16 -> f32), bmmdispatch (bf16 -> bf16) -- reference src/libxsmm_main.c:2198-2259.
+
+The reference's own check for these kernels is the gold loop of its harness samples/xgemm/kernel.c (:915-927, :1007-1021,
+:1104-1123, :1207-1229: A in pairs of k, terms in ascending k, int sums wrap, float forms round product and add
+separately, a bf16 result is the upper half of the float sum). The oracle restates those loops in C; here they are
+restated once more in numpy (independently) to pin the oracle, and the GPU kernels are compared with the oracle bit for bit.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+
+def _bf16(x):
+    """float32 array -> its bf16 truncation as uint16 (what the harness stores: the upper half of the float)"""
+    return (np.ascontiguousarray(x, dtype=np.float32).view(np.uint32) >> 16).astype(np.uint16)
+
+
+def _f32(h):
+    return (h.astype(np.uint32) << 16).view(np.float32)
+
+
+def _inputs(kind, m, n, k, lda, ldb, ldc, seed):
+    rng = np.random.default_rng(seed)
+    if kind in (0, 1):
+        a = rng.integers(-300, 300, lda * k).astype(np.int16).view(np.uint16)
+        b = rng.integers(-300, 300, ldb * n).astype(np.int16).view(np.uint16)
+    else:
+        a = _bf16(rng.uniform(-1, 1, lda * k)); b = _bf16(rng.uniform(-1, 1, ldb * n))
+    if kind == 0:
+        c = rng.integers(-1000, 1000, ldc * n).astype(np.int32)
+    elif kind == 3:
+        c = _bf16(rng.uniform(-1, 1, ldc * n))
+    else:
+        c = rng.uniform(-1, 1, ldc * n).astype(np.float32)
+    return a, b, c
+
+
+def _numpy_gold(kind, beta0, m, n, k, lda, ldb, ldc, a, b, c, scf):
+    """kernel.c's gold loops, vectorised over the C tile: one term after the other in ascending k, every step rounded to
+    float32 (numpy float32 arithmetic rounds each operation)."""
+    out = c.copy()
+    A = a.reshape(k // 2, lda, 2)   # a[(s*lda + i)*2 + k2]
+    B = b.reshape(n, ldb)           # b[j*ldb + kk]
+    C2 = out.reshape(n, ldc)
+    if kind == 0:
+        acc = np.zeros((n, m), dtype=np.int64) if beta0 else C2[:, :m].astype(np.int64)
+        for kk in range(k):
+            acc += np.outer(B[:, kk].view(np.int16).astype(np.int64), A[kk // 2, :m, kk % 2].view(np.int16).astype(np.int64))
+        C2[:, :m] = (acc & 0xFFFFFFFF).astype(np.uint32).view(np.int32)
+        return out
+    if kind == 3:
+        acc = np.zeros((n, m), dtype=np.float32) if beta0 else _f32(C2[:, :m])
+    else:
+        acc = np.zeros((n, m), dtype=np.float32) if beta0 else C2[:, :m].astype(np.float32)
+    for kk in range(k):
+        if kind == 1:
+            iprod = np.outer(B[:, kk].view(np.int16).astype(np.int32), A[kk // 2, :m, kk % 2].view(np.int16).astype(np.int32))
+            term = (iprod.astype(np.float32) * np.float32(scf)).astype(np.float32)
+        else:
+            term = np.outer(_f32(B[:, kk]), _f32(A[kk // 2, :m, kk % 2])).astype(np.float32)
+        acc = (acc + term).astype(np.float32)
+    C2[:, :m] = _bf16(acc) if kind == 3 else acc
+    return out
+
+
+CASES = [(16, 9, 8, 16, 8, 16), (32, 32, 32, 32, 32, 32), (16, 5, 6, 20, 10, 24), (48, 7, 64, 48, 64, 48)]
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2, 3])
+@pytest.mark.parametrize("case", CASES)
+def test_oracle_low_precision_gold_loops(orc, kind, case):
+    m, n, k, lda, ldb, ldc = case
+    for beta0 in (0, 1):
+        a, b, c = _inputs(kind, m, n, k, lda, ldb, ldc, 17 * kind + m + n)
+        scf = 0.0123 if kind == 1 else 1.0
+        ref = c.copy()
+        assert 0 == orc.gemm_lowp(kind, beta0, m, n, k, lda, ldb, ldc, a, b, ref, scf)
+        gold = _numpy_gold(kind, beta0, m, n, k, lda, ldb, ldc, a, b, c, scf)
+        assert np.array_equal(ref.view(np.uint8), gold.view(np.uint8))
+    assert 0 != orc.gemm_lowp(kind, 0, m, n, k + 1, lda, ldb + 2, ldc, a, b, c, 1.0)  # odd k
+
+
+def test_low_precision_dispatch_rules(xs):
+    """k even, no TRANS_B, bf16 output needs m % 16 == 0 (src/generator_gemm.c:121-147,236-243); otherwise NULL."""
+    L = xs.lib()
+    for name in ("libxsmm_wimmdispatch", "libxsmm_wsmmdispatch", "libxsmm_bsmmdispatch", "libxsmm_bmmdispatch"):
+        f = getattr(L, name)
+        assert f(16, 8, 8, None, None, None, None, None, None, None)
+        assert f(16, 8, 8, None, None, None, None, None, None, None) == f(16, 8, 8, None, None, None, None, None, None, None)
+        assert not f(16, 8, 7, None, None, None, None, None, None, None)
+        assert not f(16, 8, 8, None, None, None, None, None, C.byref(C.c_int(xs.FLAG_TRANS_B)), None)
+    assert L.libxsmm_bsmmdispatch(13, 8, 8, None, None, None, None, None, None, None)
+    assert not L.libxsmm_bmmdispatch(13, 8, 8, None, None, None, None, None, None, None)
+    two = C.c_float(2.0)
+    assert not L.libxsmm_bsmmdispatch(16, 8, 8, None, None, None, C.byref(two), None, None, None)  # alpha != 1
+
+
+DISPATCH = {0: "libxsmm_wimmdispatch", 1: "libxsmm_wsmmdispatch", 2: "libxsmm_bsmmdispatch", 3: "libxsmm_bmmdispatch"}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", [0, 1, 2, 3])
+@pytest.mark.parametrize("case", CASES + [(64, 64, 256, 64, 256, 64)])
+def test_low_precision_kernels_match_the_gold_loops(xs, orc, torch_gpu, kind, case):
+    """A dispatched kernel called like the harness does (samples/xgemm/kernel.c:262: kernel(a, b, c, NULL, NULL, NULL[, &scf]))
+    on plain host memory (staged) and on device memory; beta = 1 and beta = 0 (C not read: NaN-safe)."""
+    torch = torch_gpu
+    L = xs.lib()
+    m, n, k, lda, ldb, ldc = case
+    scf = C.c_float(0.0123 if kind == 1 else 1.0)
+    for beta0 in (0, 1):
+        a, b, c = _inputs(kind, m, n, k, lda, ldb, ldc, 5 * kind + m + k)
+        ref = c.copy()
+        assert 0 == orc.gemm_lowp(kind, beta0, m, n, k, lda, ldb, ldc, a, b, ref, scf.value)
+        if beta0 and kind in (1, 2):
+            c[:] = np.nan
+        ilda, ildb, ildc = (C.c_int(v) for v in (lda, ldb, ldc))
+        one, zero, ione, izero = C.c_float(1.0), C.c_float(0.0), C.c_int(1), C.c_int(0)
+        alpha = C.byref(ione if kind == 0 else one)
+        beta = C.byref((izero if beta0 else ione) if kind == 0 else (zero if beta0 else one))
+        fn = getattr(L, DISPATCH[kind])(m, n, k, C.byref(ilda), C.byref(ildb), C.byref(ildc), alpha, beta, None, None)
+        assert fn
+        proto = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
+        # (1) plain host memory
+        out = c.copy()
+        proto(fn)(a.ctypes.data, b.ctypes.data, out.ctypes.data, None, None, None, C.addressof(scf))
+        assert xs.last_kernel().endswith("_lowp"), xs.last_kernel()
+        cols = np.arange(n * ldc).reshape(n, ldc)[:, :m].ravel()  # the m x n tile inside ldc
+        assert np.array_equal(out[cols].view(np.uint8), ref[cols].view(np.uint8))
+        # (2) device memory
+        da, db = (torch.from_numpy(x.view(np.int16)).cuda() for x in (a, b))
+        dc = torch.from_numpy(c.view(np.int16) if kind == 3 else c).cuda()
+        proto(fn)(da.data_ptr(), db.data_ptr(), dc.data_ptr(), None, None, None, C.addressof(scf))
+        torch.cuda.synchronize()
+        got = dc.cpu().numpy()
+        got = got.view(np.uint16) if kind == 3 else got
+        assert np.array_equal(got[cols].view(np.uint8), ref[cols].view(np.uint8))
+        pad = np.setdiff1d(np.arange(n * ldc), cols)
+        assert np.array_equal(got[pad].view(np.uint8), c[pad].view(np.uint8))  # padding rows of C are not touched
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", [0, 2, 3])
+def test_low_precision_batches(xs, orc, torch_gpu, kind):
+    """libxsmm_mmbatch_kernel with index arrays and with arrays of pointers (src/libxsmm_gemm.c:1333-1364, :1426-1461):
+    shuffled operands, every item its own C."""
+    torch = torch_gpu
+    L = xs.lib()
+    m, n, k, batch = 16, 12, 24, 301
+    rng = np.random.default_rng(kind)
+    if kind == 0:
+        a = rng.integers(-300, 300, batch * m * k).astype(np.int16).view(np.uint16); b = rng.integers(-300, 300, batch * k * n).astype(np.int16).view(np.uint16)
+        c = rng.integers(-1000, 1000, batch * m * n).astype(np.int32)
+    else:
+        a = _bf16(rng.uniform(-1, 1, batch * m * k)); b = _bf16(rng.uniform(-1, 1, batch * k * n))
+        c = rng.uniform(-1, 1, batch * m * n).astype(np.float32) if kind == 2 else _bf16(rng.uniform(-1, 1, batch * m * n))
+    pa, pb = rng.permutation(batch), rng.permutation(batch)
+    ref = c.copy()
+    for i in range(batch):
+        ci = ref[i * m * n:(i + 1) * m * n]
+        assert 0 == orc.gemm_lowp(kind, 0, m, n, k, m, k, m, a[pa[i] * m * k:(pa[i] + 1) * m * k], b[pb[i] * k * n:(pb[i] + 1) * k * n], ci, 1.0)
+    fn = getattr(L, DISPATCH[kind])(m, n, k, None, None, None, None, None, None, None)
+    assert fn
+    da, db = (torch.from_numpy(x.view(np.int16)).cuda() for x in (a, b))
+    csize = 2 if kind == 3 else 4
+    # index arrays, index_base 1
+    dc = torch.from_numpy(c.view(np.int16) if kind == 3 else c).cuda()
+    sa = (pa * m * k + 1).astype(np.int32); sb = (pb * k * n + 1).astype(np.int32); sc = (np.arange(batch) * m * n + 1).astype(np.int32)
+    kern = C.c_void_p(fn)
+    rc = L.libxsmm_mmbatch_kernel(kern, 1, 4, xs.dptr(sa), xs.dptr(sb), xs.dptr(sc), da.data_ptr(), db.data_ptr(), dc.data_ptr(), batch, 0, 1, 2, csize, 0)
+    assert rc == 0
+    torch.cuda.synchronize()
+    got = dc.cpu().numpy(); got = got.view(np.uint16) if kind == 3 else got
+    assert np.array_equal(got.view(np.uint8), ref.view(np.uint8))
+    # arrays of pointers (device arrays)
+    dc = torch.from_numpy(c.view(np.int16) if kind == 3 else c).cuda()
+    qa = torch.from_numpy((da.data_ptr() + pa.astype(np.int64) * m * k * 2).astype(np.int64)).cuda()
+    qb = torch.from_numpy((db.data_ptr() + pb.astype(np.int64) * k * n * 2).astype(np.int64)).cuda()
+    qc = torch.from_numpy((dc.data_ptr() + np.arange(batch, dtype=np.int64) * m * n * csize).astype(np.int64)).cuda()
+    ptrsize = np.array([8], dtype=np.int32)
+    rc = L.libxsmm_mmbatch_kernel(kern, 0, 0, xs.dptr(ptrsize), xs.dptr(ptrsize), xs.dptr(ptrsize), qa.data_ptr(), qb.data_ptr(), qc.data_ptr(), batch, 0, 1, 2, csize, 0)
+    assert rc == 0
+    torch.cuda.synchronize()
+    got = dc.cpu().numpy(); got = got.view(np.uint16) if kind == 3 else got
+    assert np.array_equal(got.view(np.uint8), ref.view(np.uint8))

@@ -94,6 +94,7 @@
  * --------------------------------------------------------------------------------------------- */
 typedef int libxsmm_blasint;                 /* :42-48,131 LP64 */
 typedef unsigned short libxsmm_bfloat16;     /* :119 */
+typedef union libxsmm_bfloat16_hp { libxsmm_bfloat16 i[2]; float f; } libxsmm_bfloat16_hp; /* :121-124: i[1] is the bf16 of f (little endian) */
 typedef unsigned long long libxsmm_timer_tickint; /* include/libxsmm_timer.h:42 */
 
 #define LIBXSMM_DESCRIPTOR_MAXSIZE 64        /* :109-111 */
@@ -269,6 +270,9 @@ LIBXSMM_API int libxsmm_get_verbosity(void);                       /* :94 */
 LIBXSMM_API void libxsmm_set_verbosity(int level);                 /* :99 */
 LIBXSMM_API libxsmm_gemm_prefetch_type libxsmm_get_gemm_auto_prefetch(void);            /* :102 */
 LIBXSMM_API void libxsmm_set_gemm_auto_prefetch(libxsmm_gemm_prefetch_type strategy);   /* :104 */
+/* prefetch strategy a dispatcher uses for a caller's request (src/libxsmm_gemm.c:471-494): negative = the configured default */
+LIBXSMM_API libxsmm_gemm_prefetch_type libxsmm_get_gemm_prefetch(int prefetch);
+LIBXSMM_API libxsmm_gemm_prefetch_type libxsmm_get_gemm_xprefetch(const int* prefetch);
 /* arch ids (include/libxsmm_cpuid.h:40-52); LIBXSMM_TARGET_ARCH_GENERIC disables dispatch as in the reference */
 #define LIBXSMM_TARGET_ARCH_UNKNOWN 0
 #define LIBXSMM_TARGET_ARCH_GENERIC 1
@@ -456,6 +460,26 @@ LIBXSMM_API void libxsmm_sgemm(const char* transa, const char* transb,
   const libxsmm_blasint* m, const libxsmm_blasint* n, const libxsmm_blasint* k,
   const float* alpha, const float* a, const libxsmm_blasint* lda, const float* b, const libxsmm_blasint* ldb,
   const float* beta, float* c, const libxsmm_blasint* ldc);
+/* BLAS call wrapper (reference src/libxsmm_ext_gemm.c:256-660, documentation/libxsmm_mm.md "Call Wrapper"): relink an
+ * application that calls the Fortran BLAS symbols with -Wl,--wrap=dgemm_,--wrap=sgemm_ (optionally also
+ * --wrap=dgemm_batch_,--wrap=sgemm_batch_,--wrap=dgemm_batch,--wrap=sgemm_batch) and its calls arrive here. Every call is
+ * served by the device path (general alpha/beta/transposes included): no __real_ symbol, i.e. no BLAS library, is needed. */
+LIBXSMM_APIEXT void __wrap_dgemm_(const char* transa, const char* transb,
+  const libxsmm_blasint* m, const libxsmm_blasint* n, const libxsmm_blasint* k,
+  const double* alpha, const double* a, const libxsmm_blasint* lda, const double* b, const libxsmm_blasint* ldb,
+  const double* beta, double* c, const libxsmm_blasint* ldc);
+LIBXSMM_APIEXT void __wrap_sgemm_(const char* transa, const char* transb,
+  const libxsmm_blasint* m, const libxsmm_blasint* n, const libxsmm_blasint* k,
+  const float* alpha, const float* a, const libxsmm_blasint* lda, const float* b, const libxsmm_blasint* ldb,
+  const float* beta, float* c, const libxsmm_blasint* ldc);
+#define LIBXSMM_AMD_WRAP_BATCH_DECL(NAME, T) LIBXSMM_APIEXT void NAME(const char transa_array[], const char transb_array[], \
+  const libxsmm_blasint m_array[], const libxsmm_blasint n_array[], const libxsmm_blasint k_array[], \
+  const T alpha_array[], const T* a_array[], const libxsmm_blasint lda_array[], const T* b_array[], const libxsmm_blasint ldb_array[], \
+  const T beta_array[], T* c_array[], const libxsmm_blasint ldc_array[], const libxsmm_blasint* group_count, const libxsmm_blasint group_size[])
+LIBXSMM_AMD_WRAP_BATCH_DECL(__wrap_dgemm_batch_, double);
+LIBXSMM_AMD_WRAP_BATCH_DECL(__wrap_sgemm_batch_, float);
+LIBXSMM_AMD_WRAP_BATCH_DECL(__wrap_dgemm_batch, double);
+LIBXSMM_AMD_WRAP_BATCH_DECL(__wrap_sgemm_batch, float);
 /* the library's BLAS fallback entry points (src/template/libxsmm.h:402-414); here: the engine's general-form kernel */
 LIBXSMM_API void libxsmm_blas_dgemm(const char* transa, const char* transb,
   const libxsmm_blasint* m, const libxsmm_blasint* n, const libxsmm_blasint* k,
@@ -567,6 +591,10 @@ LIBXSMM_API unsigned int libxsmm_rng_u32(unsigned int n);                     /*
 LIBXSMM_API void libxsmm_rng_f32_seq(float* rngs, libxsmm_blasint count);     /* :47 */
 LIBXSMM_API size_t libxsmm_shuffle(unsigned int n);                           /* include/libxsmm_math.h:99 */
 LIBXSMM_API unsigned int libxsmm_isqrt_u64(unsigned long long x);             /* :102 */
+LIBXSMM_API unsigned int libxsmm_isqrt_u32(unsigned int x);                   /* :104 */
+LIBXSMM_API unsigned int libxsmm_icbrt_u64(unsigned long long x);             /* :112 floor(cbrt(x)) */
+LIBXSMM_API unsigned int libxsmm_icbrt_u32(unsigned int x);                   /* :114 */
+LIBXSMM_API float libxsmm_sexp2(float x);                                      /* :121 2^x */
 
 /* ---------------------------------------------------------------------------------------------
  * text generators (include/libxsmm_generator.h:120-215, src/generator_spgemm.c, src/generator_gemm.c). On this target
@@ -665,6 +693,9 @@ LIBXSMM_API void libxsmm_gemm_print2(void* ostream, libxsmm_gemm_precision iprec
 #define LIBXSMM_MMDISPATCH_SYMBOL(TYPE) LIBXSMM_CONCATENATE(libxsmm_, LIBXSMM_TPREFIX(TYPE, mmdispatch))
 #define LIBXSMM_XGEMM_SYMBOL(TYPE) LIBXSMM_CONCATENATE(libxsmm_, LIBXSMM_TPREFIX(TYPE, gemm))
 #define LIBXSMM_XBLAS_SYMBOL(TYPE) LIBXSMM_CONCATENATE(libxsmm_blas_, LIBXSMM_TPREFIX(TYPE, gemm))
+#define LIBXSMM_YGEMM_SYMBOL(TYPE) LIBXSMM_XGEMM_SYMBOL(TYPE) /* (the reference appends _omp when OpenMP is on: one device path here) */
+#define LIBXSMM_FSYMBOL(SYMBOL) LIBXSMM_CONCATENATE(SYMBOL, _)
+#define LIBXSMM_BLAS_SYMBOL(TYPE, KIND) LIBXSMM_FSYMBOL(LIBXSMM_TPREFIX(TYPE, KIND))
 #define LIBXSMM_EQUAL_doubledouble 1
 #define LIBXSMM_EQUAL_floatfloat 1
 #define LIBXSMM_EQUAL_doublefloat 0

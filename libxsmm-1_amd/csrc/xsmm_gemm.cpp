@@ -737,3 +737,35 @@ LIBXSMM_API int libxsmm_amd_stream_probe(const void* a, const void* b, void* c, 
   note_launch("stream_abc");
   return 0 == e ? EXIT_SUCCESS : EXIT_FAILURE;
 }
+
+// ---- BLAS call wrapper (reference src/libxsmm_ext_gemm.c:256-660, documentation/libxsmm_mm.md "Call Wrapper") ------------
+// An application that calls the Fortran BLAS symbols is relinked with -Wl,--wrap=dgemm_,--wrap=sgemm_ (and optionally
+// --wrap=dgemm_batch_,--wrap=sgemm_batch_,--wrap=dgemm_batch,--wrap=sgemm_batch): its calls then arrive here. The
+// reference decides per call between its SMM kernels and the original BLAS (__real_?gemm_); here every call is served
+// by the device path (general alpha/beta/transposes included), so no __real_ symbol -- no BLAS library -- is needed.
+// Inside libxsmm_mmbatch_begin/end the calls are recorded and executed as one batch, as in the reference.
+extern "C" {
+LIBXSMM_APIEXT void __wrap_dgemm_(const char* transa, const char* transb, const libxsmm_blasint* m, const libxsmm_blasint* n, const libxsmm_blasint* k,
+  const double* alpha, const double* a, const libxsmm_blasint* lda, const double* b, const libxsmm_blasint* ldb,
+  const double* beta, double* c, const libxsmm_blasint* ldc)
+{ libxsmm_dgemm(transa, transb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc); }
+
+LIBXSMM_APIEXT void __wrap_sgemm_(const char* transa, const char* transb, const libxsmm_blasint* m, const libxsmm_blasint* n, const libxsmm_blasint* k,
+  const float* alpha, const float* a, const libxsmm_blasint* lda, const float* b, const libxsmm_blasint* ldb,
+  const float* beta, float* c, const libxsmm_blasint* ldc)
+{ libxsmm_sgemm(transa, transb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc); }
+
+#define XSMM_WRAP_BATCH(NAME, T, TARGET)                                                                      \
+LIBXSMM_APIEXT void NAME(const char transa_array[], const char transb_array[],                                \
+  const libxsmm_blasint m_array[], const libxsmm_blasint n_array[], const libxsmm_blasint k_array[],         \
+  const T alpha_array[], const T* a_array[], const libxsmm_blasint lda_array[],                              \
+  const T* b_array[], const libxsmm_blasint ldb_array[],                                                     \
+  const T beta_array[], T* c_array[], const libxsmm_blasint ldc_array[],                                     \
+  const libxsmm_blasint* group_count, const libxsmm_blasint group_size[])                                    \
+{ TARGET(transa_array, transb_array, m_array, n_array, k_array, alpha_array, a_array, lda_array, b_array, ldb_array, \
+    beta_array, c_array, ldc_array, group_count, group_size); }
+XSMM_WRAP_BATCH(__wrap_dgemm_batch_, double, libxsmm_dgemm_batch_omp)
+XSMM_WRAP_BATCH(__wrap_sgemm_batch_, float, libxsmm_sgemm_batch_omp)
+XSMM_WRAP_BATCH(__wrap_dgemm_batch, double, libxsmm_dgemm_batch_omp)
+XSMM_WRAP_BATCH(__wrap_sgemm_batch, float, libxsmm_sgemm_batch_omp)
+}

@@ -247,6 +247,14 @@ LIBXSMM_API int libxsmm_get_verbosity(void) { return libxsmm_verbosity; }
 LIBXSMM_API void libxsmm_set_verbosity(int level) { libxsmm_verbosity = level; }
 LIBXSMM_API libxsmm_gemm_prefetch_type libxsmm_get_gemm_auto_prefetch(void) { return (libxsmm_gemm_prefetch_type)g_auto_prefetch.load(); }
 LIBXSMM_API void libxsmm_set_gemm_auto_prefetch(libxsmm_gemm_prefetch_type strategy) { g_auto_prefetch.store((int)strategy); }
+LIBXSMM_API libxsmm_gemm_prefetch_type libxsmm_get_gemm_prefetch(int prefetch)
+{ // src/libxsmm_gemm.c:478-494: a negative value (LIBXSMM_PREFETCH_AUTO) selects the configured strategy
+  return 0 > prefetch ? (libxsmm_gemm_prefetch_type)g_auto_prefetch.load() : (libxsmm_gemm_prefetch_type)prefetch;
+}
+LIBXSMM_API libxsmm_gemm_prefetch_type libxsmm_get_gemm_xprefetch(const int* prefetch)
+{ // src/libxsmm_gemm.c:471-475
+  return libxsmm_get_gemm_prefetch(nullptr == prefetch ? g_auto_prefetch.load() : *prefetch);
+}
 LIBXSMM_API int libxsmm_amd_set_mfma(int mode) { return g_mfma.exchange(0 != mode ? 1 : 0); }
 LIBXSMM_API int libxsmm_amd_get_mfma(void) { return g_mfma.load(); }
 

@@ -194,6 +194,19 @@ LIBXSMM_API unsigned int libxsmm_isqrt_u64(unsigned long long x)
   return (unsigned int)r;
 }
 
+LIBXSMM_API unsigned int libxsmm_isqrt_u32(unsigned int x) { return libxsmm_isqrt_u64(x); } // include/libxsmm_math.h:104
+
+LIBXSMM_API unsigned int libxsmm_icbrt_u64(unsigned long long x)
+{ // floor(cbrt(x)) (include/libxsmm_math.h:112)
+  unsigned long long r = (unsigned long long)std::cbrt((long double)x);
+  while (r * r * r > x) --r;
+  while ((r + 1) * (r + 1) * (r + 1) <= x) ++r;
+  return (unsigned int)r;
+}
+LIBXSMM_API unsigned int libxsmm_icbrt_u32(unsigned int x) { return libxsmm_icbrt_u64(x); }
+
+LIBXSMM_API float libxsmm_sexp2(float x) { return std::exp2(x); } // include/libxsmm_math.h:121 (libm path)
+
 LIBXSMM_API size_t libxsmm_shuffle(unsigned int n)
 { // a stride co-prime to n, close to n/2 (used to permute 0..n-1); include/libxsmm_math.h:99
   if (n < 2) return 0;

@@ -145,14 +145,20 @@ REFERENCE = "/root/reference"
 def test_reference_sample_programs_compile_and_link_unchanged(xs, tmp_path):
     """The drop-in claim at the source level: the reference's own sample callers (read in place, never copied, never run)
     compile against include/libxsmm.h and link against libxsmm.so without a change -- samples/smm (specialized, dispatched),
-    samples/cp2k, samples/spmdm, samples/blocked_gemm (compile only: its gold needs a Fortran BLAS) and samples/edge."""
+    samples/cp2k, samples/spmdm, samples/blocked_gemm (compile only: its gold needs a Fortran BLAS), samples/edge,
+    samples/utilities/wrap (dgemm.c relinked with --wrap=dgemm_, autobatch.c) and samples/xgemm (kernel.c, xgemm.c)."""
     libdir = os.path.dirname(xs.LIB_PATH)
     inc = ["-I", os.path.join(ROOT, "include")]
     link = ["-L", libdir, "-lxsmm", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-lm"]
     S = os.path.join(REFERENCE, "samples")
     jobs = [(["g++", "-std=c++11"], ["smm/specialized.cpp"], True), (["g++", "-std=c++11"], ["smm/dispatched.cpp"], True),
             (["g++", "-std=c++11"], ["cp2k/cp2k.cpp"], True), (["gcc", "-std=gnu99"], ["spmdm/spmdm.c"], True),
-            (["gcc", "-std=gnu99"], ["blocked_gemm/blocked_gemm.c"], False)]
+            (["gcc", "-std=gnu99"], ["blocked_gemm/blocked_gemm.c"], False),
+            # BLAS call wrapper (relinked with --wrap), auto-batching of intercepted calls, the kernel harness incl. low precision
+            (["gcc", "-std=gnu99", "-Wl,--wrap=dgemm_,--wrap=sgemm_"], ["utilities/wrap/dgemm.c"], True),
+            (["gcc", "-std=gnu99"], ["utilities/wrap/autobatch.c"], True),
+            (["gcc", "-std=gnu99", "-Werror=implicit-function-declaration"], ["xgemm/kernel.c"], True),
+            (["gcc", "-std=gnu99", "-Werror=implicit-function-declaration", "-Wl,--wrap=dgemm_,--wrap=sgemm_"], ["xgemm/xgemm.c"], True)]  # (its gold calls dgemm_)
     for name in ("asparse_srsoa", "bsparse_srsoa", "bsparse_scsoa", "dense_rmacsoa", "dense_rmbcsoa"):
         jobs.append((["gcc", "-std=gnu99", "-I", os.path.join(S, "edge")], ["edge/%s.c" % name, "edge/edge_proxy_common.c"], True))
     for cc, srcs, do_link in jobs:

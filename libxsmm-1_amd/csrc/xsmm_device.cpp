@@ -118,6 +118,13 @@ int* flag_slot()
   return ring + (size_t)INTS * (next.fetch_add(1, std::memory_order_relaxed) % SLOTS);
 }
 
+int flag_slot_set(int* slot, int equal_pairs, int decreasing_pairs)
+{ // a verdict fixed by the host, written in stream order like the check kernel's
+  hipError_t e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(slot), equal_pairs, 1, (hipStream_t)device().stream);
+  if (hipSuccess == e) e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(slot + 1), decreasing_pairs, 1, (hipStream_t)device().stream);
+  return (int)e;
+}
+
 void* scratch(int slot, size_t bytes)
 {
   Scratch& s = tl_scratch[slot & 7];

@@ -56,15 +56,26 @@ int choose_sync(SmmBatch& s, bool nosync)
 {
   s.sync = SYNC_NONE;
   if (nosync || 0 != (s.flags & LIBXSMM_GEMM_FLAG_BETA_0) || s.batch < 2 || 0 != s.general) return 0;
-  if (ADDR_STRIDED == s.mode) { s.sync = (0 == s.sc ? SYNC_RUNS : SYNC_NONE); return 0; }
-  if (ADDR_INDEX == s.mode && nullptr == s.ic) { s.sync = SYNC_RUNS; return 0; }
-  if (ADDR_POINTER == s.mode && 0 == s.sc) { s.sync = SYNC_RUNS; return 0; }
+  if (0 == s.shared_across_calls) {
+    if (ADDR_STRIDED == s.mode) { s.sync = (0 == s.sc ? SYNC_RUNS : SYNC_NONE); return 0; }
+    if (ADDR_INDEX == s.mode && nullptr == s.ic) { s.sync = SYNC_RUNS; return 0; }
+    if (ADDR_POINTER == s.mode && 0 == s.sc) { s.sync = SYNC_RUNS; return 0; }
+  }
   // The verdict stays on the device: the check kernel leaves its counts in a flag slot and the compute kernels launched
   // behind it on the same stream read them. No host round trip, the call returns while the GPU is still working.
   int* const d_flags = flag_slot();
   if (nullptr == d_flags) return -1;
-  const int e = launch_c_order_check(s, d_flags, device().stream);
-  if (0 != e) return e;
+  if (0 != s.shared_across_calls) {
+    // Task `tid` of `ntasks`: the other slices of the batch are in flight on other threads' streams and may update the same
+    // C blocks (the reference takes a lock per C, src/libxsmm_gemm.c:1366-1423). No look at this slice alone can rule
+    // that out, so the verdict is fixed to "C repeats out of order": every update of C is an atomic add.
+    const int e = flag_slot_set(d_flags, 0, 1);
+    if (0 != e) return e;
+  }
+  else {
+    const int e = launch_c_order_check(s, d_flags, device().stream);
+    if (0 != e) return e;
+  }
   s.sync = SYNC_DEVICE; s.devflags = d_flags;
   // C blocks that repeat out of order are summed with floating-point atomics, which do not reach host memory
   if (ADDR_POINTER != s.mode) s.c_atomics = is_host_visible(s.c) ? 0 : 1;
@@ -451,6 +462,7 @@ LIBXSMM_API int libxsmm_mmbatch_kernel(libxsmm_xmmfunction kernel, libxsmm_blasi
   }
   SmmBatch s = from_descriptor(k->desc);
   s.relaxed = relaxed_order(ntasks, index_stride, c) ? 1 : 0;
+  s.shared_across_calls = (1 < ntasks && 0 <= batchsize) ? 1 : 0; // (a negative batchsize is the caller's promise that nothing is shared)
   // ntasks > 1: the tasks run concurrently on the caller's threads and may share C across slices; as in the
   // reference (lock per C, :1366-1423) correctness then needs atomic updates unless the caller opts out.
   const bool nosync = (batchsize < 0);

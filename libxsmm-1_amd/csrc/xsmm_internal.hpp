@@ -59,6 +59,7 @@ struct SmmBatch {
   const int* devflags;      // SYNC_DEVICE*: device int[2] written by the check kernel earlier on the same stream
   int c_atomics;            // SYNC_DEVICE: != 0 if floating-point atomics reach C (device memory, not host memory the GPU maps)
   int lowp; float scf;      // low-precision kernels (kernels/smm_lowp.hip): 1 i16->i32, 2 i16->f32 (times scf), 3 bf16->f32, 4 bf16->bf16; 0: f32/f64
+  int shared_across_calls;  // != 0: other tasks of the same libxsmm_mmbatch update the same C blocks concurrently (ntasks > 1): atomics
   int relaxed;              // != 0: sums into a shared C may be formed in any order (the caller's reference path is multi-threaded)
   int use_mfma;             // policy bit (0: scalar FMA only)
   // general form used by the BLAS-like fallback (libxsmm_?gemm with alpha/beta/trans outside the SMM domain)
@@ -135,6 +136,7 @@ void fail_no_device(const char* what);    // prints a loud error (always) -- the
 bool is_device_ptr(const void* p);
 bool is_host_visible(const void* p);      // pinned host or managed memory (processed in place, but the CPU reads it directly)
 void settle(const void* p0, const void* p1 = nullptr, const void* p2 = nullptr); // wait for the stream if an operand is host-visible
+int flag_slot_set(int* slot, int equal_pairs, int decreasing_pairs); // the verdict without a check kernel (0: ok)
 int* flag_slot();                         // device int[4] for one batch call's C-ordering verdict (nullptr: out of memory)
 void* dev_alloc(size_t bytes);
 void dev_free(void* p);

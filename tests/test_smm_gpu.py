@@ -6,6 +6,7 @@ Bar: the scalar-FMA kernels must equal the oracle's k-ordered fma chain bit for 
 1e-6 (fp32) / 1e-12 (fp64) relative (north_star tolerance).
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -361,3 +362,61 @@ def test_concurrent_threads_with_their_own_streams(xs, orc, torch_gpu):
     for tid in range(len(shapes)):
         out, ref = results[tid]
         assert np.array_equal(out, ref), tid
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("big", [False, True])
+def test_mmbatch_tasks_on_threads_share_c_blocks(xs, orc, torch_gpu, big):
+    """libxsmm_mmbatch(..., tid, ntasks) called concurrently from ntasks threads (reference src/libxsmm_gemm.c:1315-1324 slices,
+    :1366-1423 a lock per C): every slice is strictly increasing in C on its own, yet all slices update the same C blocks.
+    The engine cannot see the other slices, so with a positive batchsize every update is an atomic add (tolerance parity:
+    the reference's order depends on thread timing as well)."""
+    import threading
+    torch = torch_gpu
+    L = xs.lib()
+    m, n, k = 23, 11, 17
+    ntasks = 4
+    per = 6000 if big else 300  # big: the hiprtc-specialised kernels (>= 16384 items would need no override; forced below)
+    batch = ntasks * per
+    rng = np.random.default_rng(3)
+    a = rng.uniform(-1, 1, batch * m * k); b = rng.uniform(-1, 1, batch * k * n); c = rng.uniform(-1, 1, per * m * n)
+    sa = (np.arange(batch) * m * k).astype(np.int32); sb = (np.arange(batch) * k * n).astype(np.int32)
+    sc = ((np.arange(batch) % per) * m * n).astype(np.int32)  # slice t: blocks 0 .. per-1, like every other slice
+    ref = c.copy()
+    assert 0 == orc.gemm_batch_idx(orc.FMA, 0, m, n, k, m, k, m, a, b, ref, 0, sa, sb, sc, batch)
+    da, db, dc = (torch.from_numpy(x).cuda() for x in (a, b, c))
+    dsa, dsb, dsc = (torch.from_numpy(x).cuda() for x in (sa, sb, sc))
+    torch.cuda.synchronize()
+    errors = []
+    one = C.c_double(1.0)
+    old_env = os.environ.get("LIBXSMM_AMD_JIT_MINBATCH")
+    if big:
+        os.environ["LIBXSMM_AMD_JIT_MINBATCH"] = "1"
+    old = L.libxsmm_amd_set_mfma(0)
+
+    def work(tid):
+        try:
+            stream = torch.cuda.Stream()
+            L.libxsmm_amd_set_stream(C.c_void_p(stream.cuda_stream))
+            L.libxsmm_mmbatch(xs.F64, xs.F64, b"N", b"N", m, n, k, C.byref(one), da.data_ptr(), None, db.data_ptr(), None, C.byref(one), dc.data_ptr(), None,
+                              0, 4, dsa.data_ptr(), dsb.data_ptr(), dsc.data_ptr(), batch, tid, ntasks)
+            stream.synchronize()
+        except Exception as exc:
+            errors.append(repr(exc))
+    try:
+        threads = [threading.Thread(target=work, args=(t,)) for t in range(ntasks)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+    finally:
+        L.libxsmm_amd_set_mfma(old)
+        if big:
+            if old_env is None:
+                del os.environ["LIBXSMM_AMD_JIT_MINBATCH"]
+            else:
+                os.environ["LIBXSMM_AMD_JIT_MINBATCH"] = old_env
+    assert not errors, errors
+    torch.cuda.synchronize()
+    out = dc.cpu().numpy()
+    assert np.max(np.abs(out - ref)) <= 1e-12 * np.max(np.abs(ref))

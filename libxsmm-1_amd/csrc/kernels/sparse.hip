@@ -498,6 +498,180 @@ void spmdm_compute_wg_kernel(long long batch, int M, int N, int K, float beta,
   }
 }
 
+// ---- spmdm compute on the matrix cores --------------------------------------------------------------------------------
+// The LDS kernel above spends its time gathering B rows per non-zero (LDS pipe ~70 % busy at 50 % density). At such
+// densities it is cheaper to rebuild the slice as a dense 64 x 64 tile in LDS (zero fill + one scattered write per
+// non-zero) and to multiply on the matrix cores: v_mfma_f32_16x16x4_f32 is a k-ordered fmaf chain (one rounding per
+// product, no wider accumulation), and fma(0, b, acc) == acc, so each C element still receives exactly the reference's
+// chain acc = fma(val_p, B[col_p][n], acc) over its row's entries in ascending column order -- the same bits as the
+// sparse kernels (provided B is finite where A has no entry: 0 * inf would be NaN; hence the policy bit).
+// Roles are swapped (D = B^T-tile x A^T-tile): lane l then holds C[m = l & 15][n = 4 * (l >> 4) .. + 3] of a 16 x 16 tile,
+// one 16-byte access per lane. LDS tiles are stored in blocks whose 64 words are exactly one operand fetch of a wave:
+//   As[(m >> 4)][k >> 2][m & 15][k & 3]   (B operand: lane (j = m & 15, kq) reads word 4 * j + kq)
+//   Bs[(k >> 2)][n >> 4][k & 3][n & 15]   (A operand: lane (i = n & 15, kq) reads word 16 * kq + i)
+// so every operand read is a conflict-free ds_read_b32 and there is no padding.
+constexpr int SPM_META = 2304; // CSR entries staged through LDS (entries beyond -- slices denser than 56 % -- come from global)
+
+typedef float spm_f32x4 __attribute__((ext_vector_type(4)));
+
+#if defined(SPM_SYNC)
+# define SPM_BARRIER() __syncthreads()
+#else
+# define SPM_BARRIER() spw_lds_barrier()
+#endif
+template<int NB, int NT>
+__global__ __launch_bounds__(256, 3)
+void spmdm_compute_mfma_kernel(long long batch, int M, int N, int K, float beta,
+                               const uint16_t* __restrict__ rowidx, const uint16_t* __restrict__ colidx, const float* __restrict__ values,
+                               int rstride, long long cap, const float* __restrict__ b, float* __restrict__ c)
+{
+  extern __shared__ __align__(16) unsigned char spm_raw[];
+  float* const As = reinterpret_cast<float*>(spm_raw);                 // 64 x 64, blocked (see above)
+  float* const Bs = As + 64 * 64;                                      // K x (16 * NT), blocked
+  float2* const meta = reinterpret_cast<float2*>(Bs + 64 * 16 * NT);   // [SPM_META] {bitcast(column), value}
+  unsigned short* const ris = reinterpret_cast<unsigned short*>(meta + SPM_META); // [M + 1]
+  float* const spare = reinterpret_cast<float*>(ris + 72);                          // a word nobody reads (inactive scatter lanes)
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  const int tile = K * N, nv4 = tile >> 2, n4 = N >> 2, ksteps = K >> 2;
+  long long item = blockIdx.x;
+  if (item >= batch) return;
+  const long long G = gridDim.x;
+  constexpr int NJ = SPM_META / 512 + 1;
+  sp_f32x4 rb[NB]; unsigned short rix = 0; unsigned cols[NJ]; sp_f32x2 vals[NJ];
+  auto fetch = [&](long long it, int nz) {
+    const sp_f32x4* const src = reinterpret_cast<const sp_f32x4*>(b + it * tile);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) { const int i = 256 * j + t; if (i < nv4) rb[j] = __builtin_nontemporal_load(src + i); }
+    if (t <= M) rix = rowidx[it * rstride + t];
+    const uint16_t* const ci = colidx + it * cap;
+    const float* const va = values + it * cap;
+    const int staged = nz < SPM_META ? nz : SPM_META;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int e = 2 * (t + 256 * j);
+      if (e < staged) {
+        cols[j] = __builtin_nontemporal_load(reinterpret_cast<const unsigned*>(ci + e));
+        vals[j] = __builtin_nontemporal_load(reinterpret_cast<const sp_f32x2*>(va + e));
+      }
+    }
+  };
+  int nnz = rowidx[item * rstride + M];
+  int nnz_next = (item + G < batch) ? (int)rowidx[(item + G) * rstride + M] : 0;
+  fetch(item, nnz);
+  for (; item < batch; item += G) {
+    float* const pc = c + item * (long long)M * N;
+    // ---- (1) clear the dense slice, park B / row starts / CSR entries
+#pragma unroll
+    for (int j = 0; j < 4; ++j) reinterpret_cast<sp_f32x4*>(As)[256 * j + t] = sp_f32x4{ 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int i = 256 * j + t;
+      if (i < nv4) {
+        const int kr = i / n4, jc = i - kr * n4;
+        *reinterpret_cast<sp_f32x4*>(Bs + (((kr >> 2) * NT + (jc >> 2)) << 6) + ((kr & 3) << 4) + ((jc & 3) << 2)) = rb[j];
+      }
+    }
+    if (t <= M) ris[t] = rix;
+    {
+      const int staged = nnz < SPM_META ? nnz : SPM_META;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int e = 2 * (t + 256 * j);
+        if (e < staged) { // (an odd count stages one entry too many: within the slot's capacity, never read)
+          *reinterpret_cast<sp_f32x4*>(meta + e) = sp_f32x4{ __int_as_float((int)(cols[j] & 0xFFFFu)), vals[j][0], __int_as_float((int)(cols[j] >> 16)), vals[j][1] };
+        }
+      }
+    }
+    // ---- next item's loads go out now
+    const long long next = item + G;
+    const int nnz_next2 = (next + G < batch) ? (int)rowidx[(next + G) * rstride + M] : 0;
+    if (next < batch) fetch(next, nnz_next);
+    // C (beta != 0) is requested now and needed after the scatter
+    const int mi = lane & 15, kq = lane >> 4, mrow = 16 * wave + mi;
+    spm_f32x4 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      acc[nt] = spm_f32x4{ 0.f, 0.f, 0.f, 0.f };
+      if (0.f != beta && mrow < M) acc[nt] = __builtin_nontemporal_load(reinterpret_cast<const spm_f32x4*>(pc + (size_t)mrow * N + 16 * nt + 4 * kq));
+    }
+    SPM_BARRIER();
+    // ---- (2) scatter the entries into the dense slice: 16 lanes per row, 16 rows per pass, up to 64 entries per row.
+    // Branch-free: every lane reads (clamped index) and writes (inactive lanes into a spare word), all reads first -- the
+    // compiler cannot tell that meta[] and As[] never overlap, a read-write-read chain would cost an LDS round trip per entry.
+    {
+      const int q = t & 15;
+      float2 ent[4][4]; int pb0[4], cnt[4];
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps) {
+        const int r = 16 * ps + (t >> 4), rc = r < M ? r : M - 1;
+        pb0[ps] = (int)ris[rc] + q;
+        cnt[ps] = (r < M) ? (int)ris[rc + 1] : 0;
+        if (cnt[ps] > SPM_META) cnt[ps] = SPM_META; // (entries beyond the staged ones: below)
+      }
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int p = pb0[ps] + 16 * it;
+          ent[ps][it] = meta[p < SPM_META ? p : SPM_META - 1];
+        }
+      }
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps) {
+        const int r = 16 * ps + (t >> 4);
+        float* const row = As + (((r >> 4) * 16) << 6) + ((r & 15) << 2); // + (k >> 2) * 64 + (k & 3)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int col = __float_as_int(ent[ps][it].x);
+          float* const dst = (pb0[ps] + 16 * it < cnt[ps]) ? (row + ((col >> 2) << 6) + (col & 3)) : spare;
+          *dst = ent[ps][it].y;
+        }
+      }
+      if (nnz > SPM_META) { // slices denser than 56 %: the tail comes straight from global memory
+        const uint16_t* const ci = colidx + item * cap;
+        const float* const va = values + item * cap;
+        for (int r = t >> 4; r < M; r += 16) {
+          const int p1 = ris[r + 1];
+          float* const row = As + (((r >> 4) * 16) << 6) + ((r & 15) << 2);
+          int p = (int)ris[r] + q;
+          if (p < SPM_META) p += ((SPM_META - p + 15) >> 4) << 4;
+          for (; p < p1; p += 16) { const int col = ci[p]; row[((col >> 2) << 6) + (col & 3)] = va[p]; }
+        }
+      }
+    }
+    SPM_BARRIER();
+    // ---- (3) wave w multiplies rows [16 w, 16 w + 16) against all NT column tiles
+    if (16 * wave < M) {
+      const int i = mi, m = mrow;
+      if (0.f != beta && 1.f != beta) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = beta * acc[nt];
+      }
+      const float* const pa = As + ((wave * 16) << 6) + 4 * i + kq;  // + s * 64
+      const float* const pb = Bs + 16 * kq + i;                      // + (s * NT + nt) * 64
+      float bop = pa[0], aop[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) aop[nt] = pb[nt << 6];
+      for (int s = 0; s < ksteps; ++s) {
+        const float bcur = bop; float acur[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acur[nt] = aop[nt];
+        if (s + 1 < ksteps) { // operands of the next step travel during this step's matrix instructions
+          bop = pa[(s + 1) << 6];
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) aop[nt] = pb[((s + 1) * NT + nt) << 6];
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[nt], bcur, acc[nt], 0, 0, 0);
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) __builtin_nontemporal_store(acc[nt], reinterpret_cast<spm_f32x4*>(pc + (size_t)m * N + 16 * nt + 4 * kq));
+    }
+    SPM_BARRIER(); // the tiles are overwritten next
+    nnz = nnz_next; nnz_next = nnz_next2;
+  }
+}
+
 unsigned grid_for(long long work, int per_block)
 {
   long long blocks = (work + per_block - 1) / per_block;
@@ -584,6 +758,25 @@ int launch_spmdm_compute(const SpmdmGeom& g, int transb, int transc, float beta,
                          const float* values, const float* b, float* c, void* stream, const char** name)
 {
   const long long tile = (long long)g.k * g.n;
+  static const int mfma_env = []() { const char* e = getenv("XSMM_SPMDM_MFMA"); return (nullptr != e && 0 != *e) ? atoi(e) : -1; }();
+  const bool use_mfma = (0 <= mfma_env ? 0 != mfma_env : 0 != libxsmm_amd_get_mfma());
+  if (use_mfma && 0 == transb && 0 == transc && 0 < g.batch && g.m <= 64 && 0 == (g.m & 15) && g.k <= 64 && 0 == (g.k & 3)
+      && g.n <= 64 && 0 == (g.n & 15) && 0 == (g.cap & 7)) {
+    hipStream_t st = (hipStream_t)stream; // dense slice in LDS, matrix cores
+    const int nt = g.n / 16;
+    const size_t lds = (size_t)64 * 64 * 4 + (size_t)64 * 16 * nt * 4 + (size_t)SPM_META * 8 + 160; // + row starts (<= 65 x 2 bytes) + spare word
+    long long per_cu = (long long)(160 * 1024 / lds); if (per_cu > 3) per_cu = 3; if (per_cu < 1) per_cu = 1;
+    static const int bpc_env = []() { const char* e = getenv("XSMM_SPMDM_BPC"); return (nullptr != e && 0 != *e) ? atoi(e) : 0; }();
+    if (0 < bpc_env) per_cu = bpc_env;
+    const long long want = 256 * per_cu;
+    const unsigned grid = (unsigned)(g.batch < want ? g.batch : want);
+    *name = "spmdm_compute_mfma";
+#define XSMM_SPM(NB, NT) hipLaunchKernelGGL((spmdm_compute_mfma_kernel<NB, NT>), dim3(grid), dim3(256), lds, st, \
+      g.batch, g.m, g.n, g.k, beta, rowidx, colidx, values, g.rstride, (long long)g.cap, b, c)
+    if (1 == nt) XSMM_SPM(1, 1); else if (2 == nt) XSMM_SPM(2, 2); else if (3 == nt) XSMM_SPM(3, 3); else XSMM_SPM(4, 4);
+#undef XSMM_SPM
+    return (int)hipGetLastError();
+  }
   if (0 == transb && 0 == transc && g.n <= 64 && 0 == (g.n & 3) && 16 * g.k <= SPW_META && (long long)g.k * SPW_LDB * 4 <= 49152 && 0 < g.batch
       && g.m <= 255 && 0 == (g.cap & 7)) {
     hipStream_t st = (hipStream_t)stream; // work-group-per-item LDS kernel

@@ -11,6 +11,7 @@
 //  - compute (src/template/libxsmm_spmdm_compute_fp32_thread.tpl.c:81-558): acc = beta*C (beta == 0: C is not
 //    read), then fma(val, B[col][n], acc) over the k-blocks in order and the row's nnz in order.
 #include "smm_common.cuh"
+#include <type_traits>
 
 namespace xsmm {
 namespace {
@@ -352,6 +353,18 @@ __device__ __forceinline__ void spw_fold(const float2* __restrict__ meta, const 
   spw_apply<U>(s.e, brow0, acc);
 }
 
+// Which of the two batch kernels serves a batch: the gather kernel's time grows with the number of entries, the matrix-core
+// kernel's does not (measured on config 4: equal at 30 % density, 0.63 vs 0.86 ms at 5 %, 1.38 vs 1.00 ms at 50 %, 2.5 vs
+// 1.5 ms at 100 %). Both are launched, each looks at the entry counts of the same 16 items spread over the batch and
+// the one that is not wanted returns at once -- no host round trip, and the results do not depend on the choice (same bits).
+__device__ __forceinline__ bool spm_batch_is_dense(const uint16_t* __restrict__ rowidx, int rstride, int M, int K, long long batch)
+{
+  long long total = 0;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) total += rowidx[((batch * j) >> 4) * rstride + M];
+  return 100 * total >= 28LL * 16 * M * K;
+}
+
 constexpr int SPW_LDB = 64;    // LDS row stride of the B tile in floats (N <= 64)
 constexpr int SPW_META = 2560; // CSR entries per window (>= 16 rows * 64 columns... see host check: 16*K <= SPW_META)
 
@@ -395,9 +408,10 @@ template<int NB>
 __global__ __launch_bounds__(256, 4) // four work-groups per CU are what the LDS footprint allows: keep VGPRs <= 128
 void spmdm_compute_wg_kernel(long long batch, int M, int N, int K, float beta,
                              const uint16_t* __restrict__ rowidx, const uint16_t* __restrict__ colidx, const float* __restrict__ values,
-                             int rstride, long long cap, const float* __restrict__ b, float* __restrict__ c)
+                             int rstride, long long cap, const float* __restrict__ b, float* __restrict__ c, int paired)
 {
   extern __shared__ __align__(16) unsigned char spw_raw[];
+  if (0 != paired && spm_batch_is_dense(rowidx, rstride, M, K, batch)) return; // the matrix-core kernel launched alongside takes it
   const int tile = K * N;                                   // floats, multiple of 4
   float* const Bs = reinterpret_cast<float*>(spw_raw);      // [K][N]
   // B rows are padded to SPW_LDB = 64 floats in LDS: a row then starts on a 256-byte bank row, so the 16-byte slot of a
@@ -519,30 +533,41 @@ typedef float spm_f32x4 __attribute__((ext_vector_type(4)));
 #else
 # define SPM_BARRIER() spw_lds_barrier()
 #endif
-template<int NB, int NT>
+// word offset of column k inside a row of the blocked dense slice: (k >> 2) * 64 + (k & 3)
+__device__ __forceinline__ int spm_word(unsigned col) { return (int)(((col >> 2) << 6) | (col & 3)); }
+
+// FULL: M == K == 64 (the whole geometry is then known at compile time: N = 16 * NT on this path anyway)
+template<int NB, int NT, bool FULL>
 __global__ __launch_bounds__(256, 3)
-void spmdm_compute_mfma_kernel(long long batch, int M, int N, int K, float beta,
+void spmdm_compute_mfma_kernel(long long batch, int M_arg, int K_arg, float beta,
                                const uint16_t* __restrict__ rowidx, const uint16_t* __restrict__ colidx, const float* __restrict__ values,
-                               int rstride, long long cap, const float* __restrict__ b, float* __restrict__ c)
+                               int rstride, long long cap, const float* __restrict__ b, float* __restrict__ c, int paired)
 {
   extern __shared__ __align__(16) unsigned char spm_raw[];
+  if (0 != paired && !spm_batch_is_dense(rowidx, rstride, FULL ? 64 : M_arg, FULL ? 64 : K_arg, batch)) return; // the gather kernel takes it
   float* const As = reinterpret_cast<float*>(spm_raw);                 // 64 x 64, blocked (see above)
   float* const Bs = As + 64 * 64;                                      // K x (16 * NT), blocked
-  float2* const meta = reinterpret_cast<float2*>(Bs + 64 * 16 * NT);   // [SPM_META] {bitcast(column), value}
+  float2* const meta = reinterpret_cast<float2*>(Bs + 64 * 16 * NT);   // [SPM_META] {bitcast(word offset of the column inside a row of As), value}
   unsigned short* const ris = reinterpret_cast<unsigned short*>(meta + SPM_META); // [M + 1]
-  float* const spare = reinterpret_cast<float*>(ris + 72);                          // a word nobody reads (inactive scatter lanes)
+  float* const spare = reinterpret_cast<float*>(ris + 72) + (threadIdx.x & 63);     // a word per lane nobody reads (inactive scatter lanes; one shared word would be a 32-way bank conflict)
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
-  const int tile = K * N, nv4 = tile >> 2, n4 = N >> 2, ksteps = K >> 2;
+  const int M = FULL ? 64 : M_arg, K = FULL ? 64 : K_arg;
+  constexpr int N = 16 * NT, n4 = 4 * NT;
+  const int tile = K * N, nv4 = tile >> 2, ksteps = K >> 2;
   long long item = blockIdx.x;
   if (item >= batch) return;
   const long long G = gridDim.x;
   constexpr int NJ = SPM_META / 512 + 1;
-  sp_f32x4 rb[NB]; unsigned short rix = 0; unsigned cols[NJ]; sp_f32x2 vals[NJ];
-  auto fetch = [&](long long it, int nz) {
+  // Register-staged pipeline, two items deep: while item i is worked on out of LDS the operands of items i + G and i + 2G are
+  // in flight (one item ahead leaves the loads less than one pass -- about a microsecond -- to arrive, the memory system
+  // under this load answers in two to three). Two register sets, the pass body is instantiated once per set.
+  sp_f32x4 rb[2][NB]; unsigned short rix[2] = { 0, 0 }; unsigned cols[2][NJ]; sp_f32x2 vals[2][NJ];
+  auto fetch = [&](auto SET, long long it, int nz) {
+    constexpr int S = decltype(SET)::value;
     const sp_f32x4* const src = reinterpret_cast<const sp_f32x4*>(b + it * tile);
 #pragma unroll
-    for (int j = 0; j < NB; ++j) { const int i = 256 * j + t; if (i < nv4) rb[j] = __builtin_nontemporal_load(src + i); }
-    if (t <= M) rix = rowidx[it * rstride + t];
+    for (int j = 0; j < NB; ++j) { const int i = 256 * j + t; if (i < nv4) rb[S][j] = __builtin_nontemporal_load(src + i); }
+    if (t <= M) rix[S] = rowidx[it * rstride + t];
     const uint16_t* const ci = colidx + it * cap;
     const float* const va = values + it * cap;
     const int staged = nz < SPM_META ? nz : SPM_META;
@@ -550,15 +575,19 @@ void spmdm_compute_mfma_kernel(long long batch, int M, int N, int K, float beta,
     for (int j = 0; j < NJ; ++j) {
       const int e = 2 * (t + 256 * j);
       if (e < staged) {
-        cols[j] = __builtin_nontemporal_load(reinterpret_cast<const unsigned*>(ci + e));
-        vals[j] = __builtin_nontemporal_load(reinterpret_cast<const sp_f32x2*>(va + e));
+        cols[S][j] = __builtin_nontemporal_load(reinterpret_cast<const unsigned*>(ci + e));
+        vals[S][j] = __builtin_nontemporal_load(reinterpret_cast<const sp_f32x2*>(va + e));
       }
     }
   };
+  // entry counts travel one item further ahead than the operands: the CSR loads of an item need its count when they are issued
   int nnz = rowidx[item * rstride + M];
-  int nnz_next = (item + G < batch) ? (int)rowidx[(item + G) * rstride + M] : 0;
-  fetch(item, nnz);
-  for (; item < batch; item += G) {
+  int nnz1 = (item + G < batch) ? (int)rowidx[(item + G) * rstride + M] : 0;
+  int nnz2 = (item + 2 * G < batch) ? (int)rowidx[(item + 2 * G) * rstride + M] : 0;
+  fetch(std::integral_constant<int, 0>(), item, nnz);
+  if (item + G < batch) fetch(std::integral_constant<int, 1>(), item + G, nnz1);
+  auto pass = [&](auto SET) {
+    constexpr int S = decltype(SET)::value;
     float* const pc = c + item * (long long)M * N;
     // ---- (1) clear the dense slice, park B / row starts / CSR entries
 #pragma unroll
@@ -568,24 +597,24 @@ void spmdm_compute_mfma_kernel(long long batch, int M, int N, int K, float beta,
       const int i = 256 * j + t;
       if (i < nv4) {
         const int kr = i / n4, jc = i - kr * n4;
-        *reinterpret_cast<sp_f32x4*>(Bs + (((kr >> 2) * NT + (jc >> 2)) << 6) + ((kr & 3) << 4) + ((jc & 3) << 2)) = rb[j];
+        *reinterpret_cast<sp_f32x4*>(Bs + (((kr >> 2) * NT + (jc >> 2)) << 6) + ((kr & 3) << 4) + ((jc & 3) << 2)) = rb[S][j];
       }
     }
-    if (t <= M) ris[t] = rix;
+    if (t <= M) ris[t] = rix[S];
     {
       const int staged = nnz < SPM_META ? nnz : SPM_META;
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
         const int e = 2 * (t + 256 * j);
         if (e < staged) { // (an odd count stages one entry too many: within the slot's capacity, never read)
-          *reinterpret_cast<sp_f32x4*>(meta + e) = sp_f32x4{ __int_as_float((int)(cols[j] & 0xFFFFu)), vals[j][0], __int_as_float((int)(cols[j] >> 16)), vals[j][1] };
+          *reinterpret_cast<sp_f32x4*>(meta + e) = sp_f32x4{ __int_as_float(spm_word(cols[S][j] & 0xFFFFu)), vals[S][j][0], __int_as_float(spm_word(cols[S][j] >> 16)), vals[S][j][1] };
         }
       }
     }
-    // ---- next item's loads go out now
-    const long long next = item + G;
-    const int nnz_next2 = (next + G < batch) ? (int)rowidx[(next + G) * rstride + M] : 0;
-    if (next < batch) fetch(next, nnz_next);
+    // ---- the register set is free again: the loads of the item two passes ahead go out now
+    const long long ahead = item + 2 * G;
+    const int nnz3 = (ahead + G < batch) ? (int)rowidx[(ahead + G) * rstride + M] : 0;
+    if (ahead < batch) fetch(SET, ahead, nnz2);
     // C (beta != 0) is requested now and needed after the scatter
     const int mi = lane & 15, kq = lane >> 4, mrow = 16 * wave + mi;
     spm_f32x4 acc[NT];
@@ -600,7 +629,7 @@ void spmdm_compute_mfma_kernel(long long batch, int M, int N, int K, float beta,
     // compiler cannot tell that meta[] and As[] never overlap, a read-write-read chain would cost an LDS round trip per entry.
     {
       const int q = t & 15;
-      float2 ent[4][4]; int pb0[4], cnt[4];
+      float2 ent[2][4]; int pb0[4], cnt[4];
 #pragma unroll
       for (int ps = 0; ps < 4; ++ps) {
         const int r = 16 * ps + (t >> 4), rc = r < M ? r : M - 1;
@@ -609,22 +638,24 @@ void spmdm_compute_mfma_kernel(long long batch, int M, int N, int K, float beta,
         if (cnt[ps] > SPM_META) cnt[ps] = SPM_META; // (entries beyond the staged ones: below)
       }
 #pragma unroll
-      for (int ps = 0; ps < 4; ++ps) {
+      for (int half = 0; half < 2; ++half) { // (two rounds of 32 rows: all 64 at once costs 16 more registers -- spills)
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-          const int p = pb0[ps] + 16 * it;
-          ent[ps][it] = meta[p < SPM_META ? p : SPM_META - 1];
+        for (int ps = 2 * half; ps < 2 * half + 2; ++ps) {
+#pragma unroll
+          for (int it = 0; it < 4; ++it) {
+            const int p = pb0[ps] + 16 * it;
+            ent[ps & 1][it] = meta[p < SPM_META ? p : SPM_META - 1];
+          }
         }
-      }
 #pragma unroll
-      for (int ps = 0; ps < 4; ++ps) {
-        const int r = 16 * ps + (t >> 4);
-        float* const row = As + (((r >> 4) * 16) << 6) + ((r & 15) << 2); // + (k >> 2) * 64 + (k & 3)
+        for (int ps = 2 * half; ps < 2 * half + 2; ++ps) {
+          const int r = 16 * ps + (t >> 4);
+          float* const row = As + (((r >> 4) * 16) << 6) + ((r & 15) << 2); // + (k >> 2) * 64 + (k & 3)
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-          const int col = __float_as_int(ent[ps][it].x);
-          float* const dst = (pb0[ps] + 16 * it < cnt[ps]) ? (row + ((col >> 2) << 6) + (col & 3)) : spare;
-          *dst = ent[ps][it].y;
+          for (int it = 0; it < 4; ++it) {
+            float* const dst = (pb0[ps] + 16 * it < cnt[ps]) ? (row + __float_as_int(ent[ps & 1][it].x)) : spare;
+            *dst = ent[ps & 1][it].y;
+          }
         }
       }
       if (nnz > SPM_META) { // slices denser than 56 %: the tail comes straight from global memory
@@ -642,7 +673,7 @@ void spmdm_compute_mfma_kernel(long long batch, int M, int N, int K, float beta,
     SPM_BARRIER();
     // ---- (3) wave w multiplies rows [16 w, 16 w + 16) against all NT column tiles
     if (16 * wave < M) {
-      const int i = mi, m = mrow;
+      const int i = mi;
       if (0.f != beta && 1.f != beta) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[nt] = beta * acc[nt];
@@ -652,6 +683,7 @@ void spmdm_compute_mfma_kernel(long long batch, int M, int N, int K, float beta,
       float bop = pa[0], aop[NT];
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) aop[nt] = pb[nt << 6];
+#pragma unroll
       for (int s = 0; s < ksteps; ++s) {
         const float bcur = bop; float acur[NT];
 #pragma unroll
@@ -664,11 +696,28 @@ void spmdm_compute_mfma_kernel(long long batch, int M, int N, int K, float beta,
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[nt], bcur, acc[nt], 0, 0, 0);
       }
+      // C leaves through LDS: the wave's 16 rows of C are one contiguous piece of memory (16 * N floats), written as whole
+      // lines; straight from the accumulators every store would touch sixteen separate 64-byte pieces. The wave's own rows of
+      // As -- nobody else reads them -- serve as the buffer.
+      float* const Cs = As + ((wave * 16) << 6); // 1024 floats >= 16 * CLD
+      constexpr int CLD = (N < 64) ? N + 4 : N;  // rows 4 floats apart from a multiple of 16: the 16 lanes of a ds_write_b128 phase hit 16 different 16-byte slots (N = 64 has no room for it)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) __builtin_nontemporal_store(acc[nt], reinterpret_cast<spm_f32x4*>(pc + (size_t)m * N + 16 * nt + 4 * kq));
+      for (int nt = 0; nt < NT; ++nt) *reinterpret_cast<spm_f32x4*>(Cs + i * CLD + 16 * nt + 4 * kq) = acc[nt];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      float* const pw = pc + (size_t)(16 * wave) * N;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int piece = 64 * nt + lane, prow = piece / n4, pcol = piece - prow * n4; // 16 * N / 4 = 64 * NT pieces of 16 bytes
+        __builtin_nontemporal_store(*reinterpret_cast<const spm_f32x4*>(Cs + prow * CLD + 4 * pcol), reinterpret_cast<spm_f32x4*>(pw + 4 * piece));
+      }
     }
     SPM_BARRIER(); // the tiles are overwritten next
-    nnz = nnz_next; nnz_next = nnz_next2;
+    nnz = nnz1; nnz1 = nnz2; nnz2 = nnz3;
+  };
+  for (;;) {
+    pass(std::integral_constant<int, 0>()); item += G; if (item >= batch) break;
+    pass(std::integral_constant<int, 1>()); item += G; if (item >= batch) break;
   }
 }
 
@@ -758,28 +807,15 @@ int launch_spmdm_compute(const SpmdmGeom& g, int transb, int transc, float beta,
                          const float* values, const float* b, float* c, void* stream, const char** name)
 {
   const long long tile = (long long)g.k * g.n;
+  // XSMM_SPMDM_MFMA: 0 = gather kernel only, 1 = matrix-core kernel only (where the geometry fits), default = both, chosen on the device
   static const int mfma_env = []() { const char* e = getenv("XSMM_SPMDM_MFMA"); return (nullptr != e && 0 != *e) ? atoi(e) : -1; }();
-  const bool use_mfma = (0 <= mfma_env ? 0 != mfma_env : 0 != libxsmm_amd_get_mfma());
-  if (use_mfma && 0 == transb && 0 == transc && 0 < g.batch && g.m <= 64 && 0 == (g.m & 15) && g.k <= 64 && 0 == (g.k & 3)
-      && g.n <= 64 && 0 == (g.n & 15) && 0 == (g.cap & 7)) {
-    hipStream_t st = (hipStream_t)stream; // dense slice in LDS, matrix cores
-    const int nt = g.n / 16;
-    const size_t lds = (size_t)64 * 64 * 4 + (size_t)64 * 16 * nt * 4 + (size_t)SPM_META * 8 + 160; // + row starts (<= 65 x 2 bytes) + spare word
-    long long per_cu = (long long)(160 * 1024 / lds); if (per_cu > 3) per_cu = 3; if (per_cu < 1) per_cu = 1;
-    static const int bpc_env = []() { const char* e = getenv("XSMM_SPMDM_BPC"); return (nullptr != e && 0 != *e) ? atoi(e) : 0; }();
-    if (0 < bpc_env) per_cu = bpc_env;
-    const long long want = 256 * per_cu;
-    const unsigned grid = (unsigned)(g.batch < want ? g.batch : want);
-    *name = "spmdm_compute_mfma";
-#define XSMM_SPM(NB, NT) hipLaunchKernelGGL((spmdm_compute_mfma_kernel<NB, NT>), dim3(grid), dim3(256), lds, st, \
-      g.batch, g.m, g.n, g.k, beta, rowidx, colidx, values, g.rstride, (long long)g.cap, b, c)
-    if (1 == nt) XSMM_SPM(1, 1); else if (2 == nt) XSMM_SPM(2, 2); else if (3 == nt) XSMM_SPM(3, 3); else XSMM_SPM(4, 4);
-#undef XSMM_SPM
-    return (int)hipGetLastError();
-  }
-  if (0 == transb && 0 == transc && g.n <= 64 && 0 == (g.n & 3) && 16 * g.k <= SPW_META && (long long)g.k * SPW_LDB * 4 <= 49152 && 0 < g.batch
-      && g.m <= 255 && 0 == (g.cap & 7)) {
-    hipStream_t st = (hipStream_t)stream; // work-group-per-item LDS kernel
+  const bool gather_fits = (0 == transb && 0 == transc && g.n <= 64 && 0 == (g.n & 3) && 16 * g.k <= SPW_META && (long long)g.k * SPW_LDB * 4 <= 49152 && 0 < g.batch
+      && g.m <= 255 && 0 == (g.cap & 7));
+  const bool mfma_fits = ((0 <= mfma_env ? 0 != mfma_env : 0 != libxsmm_amd_get_mfma()) && 0 == transb && 0 == transc && 0 < g.batch
+      && g.m <= 64 && 0 == (g.m & 15) && g.k <= 64 && 0 == (g.k & 3) && g.n <= 64 && 0 == (g.n & 15) && 0 == (g.cap & 7));
+  const int paired = (mfma_fits && gather_fits && 0 > mfma_env) ? 1 : 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (gather_fits && (0 != paired || !mfma_fits)) { // work-group-per-item LDS kernel
     const size_t lds = (size_t)g.k * SPW_LDB * 4 + (size_t)SPW_META * 8 + (((size_t)g.m + 1) * 2 + 15) / 16 * 16;
     long long per_cu = (long long)(160 * 1024 / lds); if (per_cu > 8) per_cu = 8; if (per_cu < 1) per_cu = 1;
     const long long want = 256 * per_cu;
@@ -787,10 +823,26 @@ int launch_spmdm_compute(const SpmdmGeom& g, int transb, int transc, float beta,
     const int nb = (int)((tile / 4 + 255) / 256);
     *name = "spmdm_compute_wg_lds";
 #define XSMM_SPW(NB) hipLaunchKernelGGL((spmdm_compute_wg_kernel<NB>), dim3(grid), dim3(256), lds, st, \
-      g.batch, g.m, g.n, g.k, beta, rowidx, colidx, values, g.rstride, (long long)g.cap, b, c)
+      g.batch, g.m, g.n, g.k, beta, rowidx, colidx, values, g.rstride, (long long)g.cap, b, c, paired)
     if (nb <= 1) XSMM_SPW(1); else if (nb <= 2) XSMM_SPW(2); else if (nb <= 3) XSMM_SPW(3); else if (nb <= 4) XSMM_SPW(4);
     else if (nb <= 6) XSMM_SPW(6); else if (nb <= 8) XSMM_SPW(8); else XSMM_SPW(12);
 #undef XSMM_SPW
+    if (0 == paired) return (int)hipGetLastError();
+  }
+  if (mfma_fits) { // dense slice in LDS, matrix cores
+    const int nt = g.n / 16;
+    const size_t lds = (size_t)64 * 64 * 4 + (size_t)64 * 16 * nt * 4 + (size_t)SPM_META * 8 + 144 + 256; // + row starts (<= 65 x 2 bytes) + a spare word per lane
+    long long per_cu = (long long)(160 * 1024 / lds); if (per_cu > 3) per_cu = 3; if (per_cu < 1) per_cu = 1;
+    static const int bpc_env = []() { const char* e = getenv("XSMM_SPMDM_BPC"); return (nullptr != e && 0 != *e) ? atoi(e) : 0; }();
+    if (0 < bpc_env) per_cu = bpc_env;
+    const long long want = 256 * per_cu;
+    const unsigned grid = (unsigned)(g.batch < want ? g.batch : want);
+    *name = (0 != paired) ? "spmdm_compute_mfma|wg_lds" : "spmdm_compute_mfma";
+#define XSMM_SPM(NT, FULL) hipLaunchKernelGGL((spmdm_compute_mfma_kernel<NT, NT, FULL>), dim3(grid), dim3(256), lds, st, \
+      g.batch, g.m, g.k, beta, rowidx, colidx, values, g.rstride, (long long)g.cap, b, c, paired)
+    if (64 == g.m && 64 == g.k) { if (1 == nt) XSMM_SPM(1, true); else if (2 == nt) XSMM_SPM(2, true); else if (3 == nt) XSMM_SPM(3, true); else XSMM_SPM(4, true); }
+    else { if (1 == nt) XSMM_SPM(1, false); else if (2 == nt) XSMM_SPM(2, false); else if (3 == nt) XSMM_SPM(3, false); else XSMM_SPM(4, false); }
+#undef XSMM_SPM
     return (int)hipGetLastError();
   }
   return launch_spmdm_compute_generic(g.batch, g.m, g.n, g.k, g.m, g.k, 1, 1, transb, transc, beta, rowidx, colidx, values,

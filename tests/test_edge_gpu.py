@@ -87,7 +87,13 @@ def test_task_slices_wide_index_stride_and_negative_batch(xs, orc, torch_gpu):
                                          xs.dptr(dc), None, 1, 12, C.c_void_p(base), C.c_void_p(base + 4), C.c_void_p(base + 8),
                                          sign * batch, tid, nthreads)
             torch.cuda.synchronize()
-            assert np.array_equal(dc.cpu().numpy(), ref), (nthreads, sign)
+            out = dc.cpu().numpy()
+            if nthreads > 1 and sign > 0:
+                # several tasks, positive batchsize: other tasks may update the same C blocks concurrently (the reference locks per
+                # C, src/libxsmm_gemm.c:1366-1423), so every update is an atomic add of a product summed from zero: tolerance
+                assert np.max(np.abs(out - ref)) <= 1e-12 * np.max(np.abs(ref)), (nthreads, sign)
+            else:
+                assert np.array_equal(out, ref), (nthreads, sign)
     finally:
         xs.lib().libxsmm_amd_set_mfma(old)
 

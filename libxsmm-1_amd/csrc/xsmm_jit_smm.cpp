@@ -50,7 +50,12 @@ __device__ __forceinline__ void wave_lds_sync()
 }
 
 constexpr int M = XM, N = XN, K = XK;
-constexpr int AE = M * K, BE = K * N, CE = M * N;                  // elements per operand (tight leading dimensions)
+// XPACK items that follow each other in memory (tight strided batches) are handled by a wave at a time: their operands are
+// one contiguous piece (wider, fully used loads even when a single item is a few hundred bytes or not 16-byte sized), the
+// 64 lanes split into XPACK groups with one item each. The host passes strides and the count in units of XPACK items.
+constexpr int G = XPACK;
+constexpr int AE1 = M * K, BE1 = K * N, CE1 = M * N;               // elements per operand of one item (tight leading dimensions)
+constexpr int AE = G * AE1, BE = G * BE1, CE = G * CE1;            // ... of what a wave handles at a time
 constexpr int TS = (int)sizeof(T);
 #if (2 == XRUNS)
 // work-group form: 4 waves share one product; a wave owns NQ = ceil(N/4) columns of C, its 64 lanes are 16 (along m) x 4
@@ -60,9 +65,9 @@ constexpr int NQ = (N + 3) / 4;
 constexpr int TM = (M + TGM - 1) / TGM, TN = (NQ + TGN - 1) / TGN;
 constexpr int NPAD = 3 * NQ + TGN * TN;                            // highest column index a lane may touch, plus one
 #else
-// wave form: one wave per item, 8 x 8 lanes
+// wave form: one wave per item, 8 x 8 lanes (XPACK items: 64 / XPACK lanes each)
 constexpr int UT = 64;
-constexpr int TGM = 8, TGN = 8;
+constexpr int TGM = (G >= 4) ? ((G >= 16) ? 2 : 4) : 8, TGN = 64 / (G * TGM);
 constexpr int TM = (M + TGM - 1) / TGM, TN = (N + TGN - 1) / TGN;
 constexpr int NPAD = TGN * TN;
 #endif
@@ -75,9 +80,10 @@ constexpr int NLA = (AE + UT * VA - 1) / (UT * VA), NLB = (BE + UT * VB - 1) / (
 // B as [n][KP] (TRANS_B: [k][N]) with KP chosen so that the column groups of one instruction fall into different banks
 constexpr int pick_kp() { int kp = K; while (0 == (TN * kp * (TS / 4)) % 16) ++kp; return kp; }
 constexpr int KP = pick_kp();
-constexpr int AS_SIZE = ((K * M + TGM * TM + 3) / 4) * 4;
-constexpr int BS_SIZE = XTRANSB ? (((K * N + NPAD + 3) / 4) * 4) : ((NPAD * KP + 3) / 4) * 4;
-constexpr int CS_SIZE = ((CE + 3) / 4) * 4;
+constexpr int AS1 = ((K * M + TGM * TM + 3) / 4) * 4;                 // per item
+constexpr int BS1 = XTRANSB ? (((K * N + NPAD + 3) / 4) * 4) : ((NPAD * KP + 3) / 4) * 4;
+constexpr int AS_SIZE = G * AS1, BS_SIZE = G * BS1;
+constexpr int CS_SIZE = ((CE + 3) / 4) * 4;                          // the items' C blocks stay contiguous (flat copy in and out)
 constexpr int WAVE_LDS = AS_SIZE + BS_SIZE + CS_SIZE;                // elements (wave form)
 constexpr int WG_BUF = AS_SIZE + BS_SIZE;                            // elements per operand buffer (work-group form)
 constexpr int WG_NBUF = (2 * WG_BUF * TS <= 65536) ? 2 : 1;          // double-buffered when 64 KiB allow
@@ -111,14 +117,17 @@ __device__ __forceinline__ void park_ab(T* As, T* Bs, int lane, const T (&ra)[NL
 #pragma unroll
   for (int j = 0; j < NLA; ++j) {
 #pragma unroll
-    for (int q = 0; q < VA; ++q) { const int e = (UT * j + lane) * VA + q; if (e < AE) As[e] = ra[j][q]; }
+    for (int q = 0; q < VA; ++q) { const int e = (UT * j + lane) * VA + q; if (e < AE) As[(1 == G) ? e : ((e / AE1) * AS1 + (e % AE1))] = ra[j][q]; }
   }
 #pragma unroll
   for (int j = 0; j < NLB; ++j) {
 #pragma unroll
     for (int q = 0; q < VB; ++q) {
       const int e = (UT * j + lane) * VB + q;
-      if (e < BE) { if (XTRANSB) Bs[e] = rb[j][q]; else Bs[(e / K) * KP + (e % K)] = rb[j][q]; }
+      if (e < BE) {
+        const int g = (1 == G) ? 0 : (e / BE1), r = (1 == G) ? e : (e % BE1);
+        if (XTRANSB) Bs[g * BS1 + r] = rb[j][q]; else Bs[g * BS1 + (r / K) * KP + (r % K)] = rb[j][q];
+      }
     }
   }
 }
@@ -203,13 +212,15 @@ __device__ __forceinline__ void acc_from_c(const T* Cs, int tx, int ty, T (&acc)
   }
 }
 // C leaves through LDS so that the stores are flat and coalesced
-__device__ __forceinline__ void store_c(T* Cs, T* pc, int lane, int tx, int ty, const T (&acc)[TM][TN])
+// (Ci: this lane's item inside the wave's C buffer Cs; the two are the same unless XPACK > 1)
+__device__ __forceinline__ void store_c(T* Cs, T* pc, int lane, int tx, int ty, const T (&acc)[TM][TN], T* Ci = nullptr)
 {
+  if (nullptr == Ci) Ci = Cs;
   wave_lds_sync();
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
-    for (int j = 0; j < TN; ++j) { const int m = tx * TM + i, n = ty * TN + j; if (m < M && n < N) Cs[n * M + m] = acc[i][j]; }
+    for (int j = 0; j < TN; ++j) { const int m = tx * TM + i, n = ty * TN + j; if (m < M && n < N) Ci[n * M + m] = acc[i][j]; }
   }
   wave_lds_sync();
 #pragma unroll
@@ -410,7 +421,8 @@ extern "C" __global__ __launch_bounds__(64 * XWAVES) void xsmm_smm_op(DevAddr ad
 {
   __shared__ __attribute__((aligned(16))) T lds[XWAVES * WAVE_LDS];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int tx = lane & 7, ty = lane >> 3;
+  constexpr int LPI = 64 / G;                      // lanes per item
+  const int grp = lane / LPI, tx = (lane % LPI) % TGM, ty = (lane % LPI) / TGM;
   T* const As = lds + wave * WAVE_LDS;
   T* const Bs = As + AS_SIZE;
   T* const Cs = Bs + BS_SIZE;
@@ -498,9 +510,9 @@ extern "C" __global__ __launch_bounds__(64 * XWAVES) void xsmm_smm_op(DevAddr ad
     }
     wave_lds_sync();
     T acc[TM][TN];
-    acc_from_c(Cs, tx, ty, acc, XBETA0);
-    multiply(As, Bs, tx, ty * TN, acc);
-    store_c(Cs, pc, lane, tx, ty, acc);
+    acc_from_c(Cs + grp * CE1, tx, ty, acc, XBETA0);
+    multiply(As + grp * AS1, Bs + grp * BS1, tx, ty * TN, acc);
+    store_c(Cs, pc, lane, tx, ty, acc, Cs + grp * CE1);
   }
 #endif
 }
@@ -656,7 +668,7 @@ std::unordered_map<SmmKey, JitKernel*, SmmKeyHash> g_smm_cache; // nullptr value
 
 } // namespace
 
-static int smm_jit_waves(int typesize, int m, int n, int k, int flags);
+static int smm_jit_waves(int typesize, int m, int n, int k, int flags, int pack = 1);
 
 // k-chunk of the work-group-per-item form: the largest of 32/16/8 whose two LDS buffers fit 64 KiB (0: none does)
 static size_t smm_jit_big_buf(int typesize, int m, int n, int kc, int flags)
@@ -687,6 +699,10 @@ static int smm_jit_depth(int typesize, int m, int n, int k, int variant)
   return (0 < env && env <= 8) ? env : 1;
 }
 
+// items per wave pass, encoded in the variant as log2 << 8
+static int smm_jit_pack_of(int variant) { return 1 << ((variant >> 8) & 7); }
+static int smm_jit_pack_bits(int pack) { int l = 0; while ((1 << l) < pack) ++l; return l << 8; }
+
 std::string gen_smm_source(int typesize, int m, int n, int k, int flags, int variant)
 {
   std::string s = "// generated by libxsmm-amd (dense SMM kernel, shape baked in)\n";
@@ -699,7 +715,9 @@ std::string gen_smm_source(int typesize, int m, int n, int k, int flags, int var
     s += SMM_JIT_BIG_BODY;
     return s;
   }
-  s += "#define XWAVES " + std::to_string(smm_jit_waves(typesize, m, n, k, flags)) + "\n";
+  const int pack = smm_jit_pack_of(variant);
+  s += "#define XPACK " + std::to_string(pack) + "\n";   // items per wave pass (streaming form of tight strided batches)
+  s += "#define XWAVES " + std::to_string(smm_jit_waves(typesize, m, n, k, flags, pack)) + "\n";
   s += std::string("#define XSCALAR ") + ((variant & SMM_JIT_SCALAR) ? "1" : "0") + "\n"; // element-wide loads/stores only
   // runs of equal C accumulate in registers: 1 = a wave per run, 2 = a work-group per run (long runs)
   s += std::string("#define XRUNS ") + ((variant & SMM_JIT_WGRUNS) ? "2" : ((variant & SMM_JIT_RUNS) ? "1" : "0")) + "\n";
@@ -717,20 +735,21 @@ std::string gen_smm_source(int typesize, int m, int n, int k, int flags, int var
 }
 
 // LDS bytes one wave of the generated kernel needs (mirrors the constexpr arithmetic of the source)
-static size_t smm_jit_wave_lds(int typesize, int m, int n, int k, int flags)
+static size_t smm_jit_wave_lds(int typesize, int m, int n, int k, int flags, int pack = 1)
 {
-  const int tm = (m + 7) / 8, tn = (n + 7) / 8;
+  const int tgm = (pack >= 4) ? ((pack >= 16) ? 2 : 4) : 8, tgn = 64 / (pack * tgm);
+  const int tm = (m + tgm - 1) / tgm, tn = (n + tgn - 1) / tgn;
   int kp = k; while (0 == (tn * kp * (typesize / 4)) % 16) ++kp;
-  const size_t as = ((size_t)(k * m + 8 * tm + 3) / 4) * 4;
-  const size_t bs = (flags & LIBXSMM_GEMM_FLAG_TRANS_B) ? (((size_t)(k * n + 8 * tn + 3) / 4) * 4) : ((((size_t)8 * tn) * kp + 3) / 4) * 4;
-  const size_t cs = ((size_t)(m * n + 3) / 4) * 4;
-  return (as + bs + cs) * typesize;
+  const size_t as = ((size_t)(k * m + tgm * tm + 3) / 4) * 4;
+  const size_t bs = (flags & LIBXSMM_GEMM_FLAG_TRANS_B) ? (((size_t)(k * n + tgn * tn + 3) / 4) * 4) : ((((size_t)tgn * tn) * kp + 3) / 4) * 4;
+  const size_t cs = ((size_t)(pack * m * n + 3) / 4) * 4;
+  return (pack * (as + bs) + cs) * typesize;
 }
 
 // wavefronts per work-group: as many (4, 2, 1) as fit 64 KiB of static LDS; 0 if even one wave does not fit
-static int smm_jit_waves(int typesize, int m, int n, int k, int flags)
+static int smm_jit_waves(int typesize, int m, int n, int k, int flags, int pack)
 {
-  const size_t w = smm_jit_wave_lds(typesize, m, n, k, flags);
+  const size_t w = smm_jit_wave_lds(typesize, m, n, k, flags, pack);
   return (4 * w <= 65536) ? 4 : ((2 * w <= 65536) ? 2 : ((w <= 65536) ? 1 : 0));
 }
 
@@ -833,8 +852,13 @@ static int smm_jit_launch_variant(const SmmBatch& s, int variant, void* stream)
     if (blocks < 1) blocks = 1;
     return jit_launch_raw(k, (unsigned)blocks, 256u, &ad, sizeof(ad), &batch, stream);
   }
-  const int waves = smm_jit_waves(s.typesize, s.m, s.n, s.k, s.flags);
-  const size_t lds = (size_t)waves * smm_jit_wave_lds(s.typesize, s.m, s.n, s.k, s.flags);
+  const int pack = smm_jit_pack_of(variant);
+  if (1 < pack) { // the launch covers batch / pack groups of `pack` consecutive items (the caller handles the remainder)
+    ad.sa *= pack; ad.sb *= pack; ad.sc *= pack; batch /= pack;
+    if (0 == batch) return 0;
+  }
+  const int waves = smm_jit_waves(s.typesize, s.m, s.n, s.k, s.flags, pack);
+  const size_t lds = (size_t)waves * smm_jit_wave_lds(s.typesize, s.m, s.n, s.k, s.flags, pack);
   long long per_cu = (long long)((160 * 1024) / (lds ? lds : 1));
   if (per_cu * waves > 16) per_cu = 16 / waves; // the streaming rate peaks around 12-16 waves per CU
   if (per_cu < 1) per_cu = 1;
@@ -848,6 +872,28 @@ static int smm_jit_launch_variant(const SmmBatch& s, int variant, void* stream)
   return jit_launch_raw(k, (unsigned)blocks, 64u * (unsigned)waves, &ad, sizeof(ad), &batch, stream);
 }
 
+// Items a wave handles at a time. Only for batches laid out back to back (strided, tight, the "wide" flavour): a small or
+// oddly sized item (5^3 doubles are 1000 bytes, 13^3 are 1352) leaves most of a wave's lanes and of every load instruction
+// idle. Developer knob: XSMM_SMMJIT_PACK.
+static int smm_jit_pack(const SmmBatch& s, int width)
+{
+  static const int env = []() { const char* e = getenv("XSMM_SMMJIT_PACK"); return (nullptr != e && 0 != *e) ? atoi(e) : 0; }();
+  if (0 != width || ADDR_STRIDED != s.mode || 0 == s.sa || 0 == s.sb || 0 == s.sc) return 1;
+  int pack = 1;
+  if (0 < env) pack = env;
+  else { // measured on MI355X (tools/bench_dense.py, XSMM_SMMJIT_PACK sweep): items of 6 KB and more gain nothing; below, as
+    // many as make up 16 KB -- f64 5^3: 22 -> 69 % of the HBM peak, 8^3: 43 -> 72 %, 13^3: 61 -> 67 %; f32 5^3: 13 -> 58 %, 8^3: 25 -> 72 %
+    const size_t item = ((size_t)s.m * s.k + (size_t)s.k * s.n + (size_t)s.m * s.n) * s.typesize;
+    if (item < 6000) while (pack < 16 && 2 * pack * item <= 16384) pack *= 2;
+  }
+  if (pack > 16) pack = 16;
+  while (0 != (pack & (pack - 1))) --pack; // power of two
+  // operands of `pack` items in flight per lane (registers) and in LDS
+  while (1 < pack && ((size_t)pack * ((size_t)s.m * s.k + (size_t)s.k * s.n + (size_t)s.m * s.n) * s.typesize > 24576
+                   || 0 == smm_jit_waves(s.typesize, s.m, s.n, s.k, s.flags, pack))) pack /= 2;
+  return pack;
+}
+
 int launch_smm_jit(const SmmBatch& s, void* stream, const char** name)
 { // returns -1 when no specialised kernel is available
   const int width = smm_jit_width_variant(s);
@@ -858,6 +904,19 @@ int launch_smm_jit(const SmmBatch& s, void* stream, const char** name)
   }
   if (SYNC_NONE == s.sync) { // every item owns its C
     *name = f64 ? "smm_f64_jit_shape" : "smm_f32_jit_shape";
+    const int pack = smm_jit_pack(s, width);
+    if (1 < pack) { // groups of `pack` consecutive items per wave, then the few items that are left
+      const int e = smm_jit_launch_variant(s, width | smm_jit_pack_bits(pack), stream);
+      if (0 == e) {
+        const long long done = (s.batch / pack) * pack;
+        if (done == s.batch) return 0;
+        SmmBatch rest = s;
+        rest.a = (const char*)s.a + done * s.sa * s.typesize; rest.b = (const char*)s.b + done * s.sb * s.typesize;
+        rest.c = (char*)s.c + done * s.sc * s.typesize; rest.batch = s.batch - done;
+        return smm_jit_launch_variant(rest, SMM_JIT_SCALAR, stream);
+      }
+      if (0 < e) return e; // (< 0: the packed flavour did not compile -- one item per wave)
+    }
     return smm_jit_launch_variant(s, width, stream);
   }
   static const int wg_env = []() { const char* e = getenv("XSMM_SMMJIT_WG"); return (nullptr != e && 0 != *e) ? atoi(e) : 1; }(); // developer knob

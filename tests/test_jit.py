@@ -39,6 +39,14 @@ def test_generated_sources_compile_for_gfx950(xs):
                     src = buf.value.decode()
                     assert "#define XM %d" % m in src and "xsmm_smm_op" in src
                     assert "#define XRUNS %d" % (2 if variant & 4 else (variant >> 1) & 1) in src
+    # several consecutive items per wave (variant bits 8..10 = log2 of the count): small and oddly sized shapes of tight strided batches
+    for prec in (xs.F64, xs.F32):
+        for (m, n, k), packs in (((5, 5, 5), (1, 2, 3, 4)), ((8, 8, 8), (1, 2)), ((13, 13, 13), (1, 2)), ((23, 23, 23), (1,)), ((5, 7, 3), (3,))):
+            for beta, flags in ((1.0, 0), (0.0, xs.FLAG_TRANS_B)):
+                blob, d = xs.descriptor(prec, m, n, k, beta=beta, flags=flags)
+                for lg in packs:
+                    assert 0 == L.libxsmm_amd_smm_kernel_source(d, lg << 8, buf, len(buf), 1), (prec, m, n, k, beta, flags, lg)
+                    assert "#define XPACK %d\n" % (1 << lg) in buf.value.decode()
     # fixed-sparsity operator
     rng = np.random.default_rng(0)
     M, K = 35, 35

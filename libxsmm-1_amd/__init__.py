@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("LIBXSMM_AMD_LIBRARY", os.path.join(_HERE, "lib", "lib
 CSRC = os.path.join(_HERE, "csrc")
 
 # enum values (include/libxsmm.h; reference include/libxsmm_typedefs.h:158-213)
-F64, F32 = 0, 1
+F64, F32, BF16, I32, I16 = 0, 1, 2, 4, 5  # libxsmm_gemm_precision (include/libxsmm.h)
 FLAG_TRANS_A, FLAG_TRANS_B, FLAG_BETA_0, FLAG_BATCH_REDUCE = 1, 2, 16, 256
 
 c_int_p = C.POINTER(C.c_int)

@@ -613,6 +613,14 @@ LIBXSMM_API int libxsmm_amd_gemm_batch_strided(const libxsmm_gemm_descriptor* de
     return EXIT_FAILURE;
   }
   if (0 == batchsize) return EXIT_SUCCESS;
+  const Kernel* const k = kernel_from_pointer(reinterpret_cast<const void*>(kernel.xmm));
+  if (nullptr != k && KC_LOWP == k->kclass) { // i16 / bf16 inputs: independent C operands (strides in elements of the respective type)
+    if (0 == stride_c && 1 < batchsize) return EXIT_FAILURE;
+    if (LIBXSMM_GEMM_PRECISION_I16 == LIBXSMM_GETENUM_INP(k->desc.datatype) && LIBXSMM_GEMM_PRECISION_F32 == LIBXSMM_GETENUM_OUT(k->desc.datatype)) return EXIT_FAILURE; // no way to pass the scaling factor
+    SmmBatch s = lowp_from_descriptor(k->desc, 1.f);
+    s.mode = ADDR_STRIDED; s.a = a; s.b = b; s.c = c; s.sa = stride_a; s.sb = stride_b; s.sc = stride_c; s.batch = batchsize; s.sync = SYNC_NONE;
+    return 0 == lowp_launch(s) ? EXIT_SUCCESS : EXIT_FAILURE;
+  }
   SmmBatch s = from_descriptor(*descriptor);
   s.mode = ADDR_STRIDED; s.a = a; s.b = b; s.c = c; s.sa = stride_a; s.sb = stride_b; s.sc = stride_c; s.batch = batchsize;
   s.sync = (0 == stride_c && 0 == (s.flags & LIBXSMM_GEMM_FLAG_BETA_0) && 1 < batchsize) ? SYNC_RUNS : SYNC_NONE;

@@ -185,3 +185,20 @@ def test_low_precision_batches(xs, orc, torch_gpu, kind):
     torch.cuda.synchronize()
     got = dc.cpu().numpy(); got = got.view(np.uint16) if kind == 3 else got
     assert np.array_equal(got.view(np.uint8), ref.view(np.uint8))
+    # contiguous items: libxsmm_amd_gemm_batch_strided on a low-precision descriptor (strides in elements of each operand's type)
+    dc = torch.from_numpy(c.view(np.int16) if kind == 3 else c).cuda()
+    ident = (np.arange(batch) * m * k).astype(np.int64)  # (reference values for unpermuted operands)
+    ref2 = c.copy()
+    for i in range(batch):
+        assert 0 == orc.gemm_lowp(kind, 0, m, n, k, m, k, m, a[i * m * k:(i + 1) * m * k], b[i * k * n:(i + 1) * k * n], ref2[i * m * n:(i + 1) * m * n], 1.0)
+    blob = xs.DescriptorBlob()
+    L.libxsmm_gemm_descriptor_dinit2.restype = C.c_void_p
+    L.libxsmm_gemm_descriptor_dinit2.argtypes = [C.c_void_p] + [C.c_int] * 8 + [C.c_double, C.c_double, C.c_int, C.c_int]
+    ip, op = {0: (xs.I16, xs.I32), 2: (xs.BF16, xs.F32), 3: (xs.BF16, xs.BF16)}[kind]
+    desc = L.libxsmm_gemm_descriptor_dinit2(C.byref(blob), ip, op, m, n, k, m, k, m, 1.0, 1.0, 0, 0)
+    assert desc and len(ident) == batch
+    assert 0 == L.libxsmm_amd_gemm_batch_strided(C.c_void_p(desc), da.data_ptr(), db.data_ptr(), dc.data_ptr(), m * k, k * n, m * n, batch)
+    torch.cuda.synchronize()
+    assert xs.last_kernel().endswith("_lowp")
+    got = dc.cpu().numpy(); got = got.view(np.uint16) if kind == 3 else got
+    assert np.array_equal(got.view(np.uint8), ref2.view(np.uint8))

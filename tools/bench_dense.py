@@ -42,6 +42,41 @@ def run(dtype, m, n, k, mfma, beta=1.0):
     del a, b, c
 
 
+def run_lowp(kind, m, n, k):
+    """kind: 'bf16f32' | 'i16i32' | 'bf16'; A in pairs of k, tight leading dimensions, beta = 1"""
+    import ctypes as C
+    osz = 2 if kind == "bf16" else 4
+    per_item = 2 * (m * k + k * n) + 2 * osz * m * n
+    batch = int(min(TARGET_BYTES / per_item, 4e6))
+    a = torch.randint(-100, 100, (batch * m * k,), device="cuda", dtype=torch.int16, generator=g)
+    b = torch.randint(-100, 100, (batch * k * n,), device="cuda", dtype=torch.int16, generator=g)
+    if kind != "i16i32":  # small bf16 values: 0x3C00..0x3FFF are 2^-7 .. 2
+        a = (a.abs() % 1024 + 0x3C00).to(torch.int16); b = (b.abs() % 1024 + 0x3C00).to(torch.int16)
+    c = torch.zeros(batch * m * n, device="cuda", dtype=torch.int16 if kind == "bf16" else torch.int32)
+    ip, op = {"bf16f32": (xs.BF16, xs.F32), "i16i32": (xs.I16, xs.I32), "bf16": (xs.BF16, xs.BF16)}[kind]
+    blob = xs.DescriptorBlob()
+    L.libxsmm_gemm_descriptor_dinit2.restype = C.c_void_p
+    L.libxsmm_gemm_descriptor_dinit2.argtypes = [C.c_void_p] + [C.c_int] * 8 + [C.c_double, C.c_double, C.c_int, C.c_int]
+    desc = L.libxsmm_gemm_descriptor_dinit2(C.byref(blob), ip, op, m, n, k, m, k, m, 1.0, 1.0, 0, 0)
+    times = []
+    for it in range(reps + 2):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        assert 0 == L.libxsmm_amd_gemm_batch_strided(desc, xs.dptr(a), xs.dptr(b), xs.dptr(c), m * k, k * n, m * n, batch)
+        e1.record(); torch.cuda.synchronize()
+        if it >= 2:
+            times.append(e0.elapsed_time(e1))
+    t = min(times); gbs = batch * per_item / t / 1e6
+    print("%-7s %2dx%2dx%2d beta=1 %-22s batch=%8d  %.3f ms  %6.0f GB/s (%4.1f%% of 8 TB/s)  %7.0f GFLOP/s"
+          % (kind, m, n, k, xs.last_kernel(), batch, t, gbs, gbs / 80.0, 2.0 * m * n * k * batch / t / 1e6))
+
+
+if which == "lowp":
+    for kind in ("bf16f32", "i16i32", "bf16"):
+        for (m, n, k) in ((32, 32, 32), (16, 16, 16), (64, 64, 64)):
+            run_lowp(kind, m, n, k)
+    sys.exit(0)
+
 shapes = [(13, 13, 13), (23, 23, 23), (32, 32, 32), (13, 23, 32), (32, 13, 23), (64, 64, 64), (8, 8, 8), (16, 16, 16), (5, 5, 5)]
 if os.environ.get("DENSE_SHAPES"):  # e.g. DENSE_SHAPES=5x5x5,13x13x13
     shapes = [tuple(int(v) for v in t.split("x")) for t in os.environ["DENSE_SHAPES"].split(",")]

@@ -9,8 +9,8 @@
 // stores carry the non-temporal hint.
 //   "fma"  variant: 4x4 register tile per lane, v_fma_f32, k ascending -- bit-identical to the reference's
 //                   per-element fma chain.
-//   "mfma" variants: v_mfma_f32_32x32x2_f32; the two k of one instruction are (s, 16+s), i.e. the chain per C
-//                   element runs k = 0,16,1,17,...; same products, different association (tolerance parity).
+//   "mfma" variants: v_mfma_f32_32x32x2_f32, a k-ordered fmaf chain; the two k of instruction s are (2s, 2s+1), so the
+//                   chain per C element runs k = 0,1,2,...: bit-identical to the "fma" variant and the reference's chain.
 #include "smm_common.cuh"
 
 namespace xsmm {
@@ -131,8 +131,8 @@ void smm32_f32_fma_kernel(DevAddr ad, long long batch)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// MFMA variant with v_mfma_f32_32x32x2_f32; per instruction lane l supplies k = 16*(l>>5) + s for both operands:
-//   A[m = l&31][k] from the linear LDS image, B[k][n = l&31] as four 16-byte reads of the swizzled image.
+// MFMA variant with v_mfma_f32_32x32x2_f32; per instruction (step s) lane l supplies k = 2s + (l>>5) for both operands:
+//   A[m = l&31][k] from the linear LDS image, B[k][n = l&31] out of eight 16-byte reads of the swizzled image.
 // D[i=n][j=m] (B as a-operand): register r of lane l is C[n = (r&3)+8(r>>2)+4(l>>5)][m = l&31], so every C access is a
 // dword per lane, two full 128-byte rows per wave instruction. (The transposed operand order, where C moves as four
 // 16-byte pieces per lane, was measured 15-40 % slower and has been removed.)
@@ -172,13 +172,16 @@ void smm32_f32_mfma_kernel(DevAddr ad, long long batch)
       if (!BETA0) load_c(addr_c<float>(ad, next) + coff);
     }
     wave_lds_sync();
-    f32x4 bt[4]; // B[16*hi + 4t + e][n = lo]
+    // The instruction is a k-ordered fmaf chain (one rounding per product): with the two k of step s being 2s and 2s + 1 every
+    // C element receives fma(A[m,k], B[k,n], acc) for k = 0, 1, ..., 31 -- the reference's chain, bit for bit.
+    f32x4 bt[8]; // B[4t + e][n = lo]: the whole column (both halves of the wave read the same words: broadcast)
 #pragma unroll
-    for (int t = 0; t < 4; ++t) bt[t] = *reinterpret_cast<const f32x4*>(Bs + 4 * (lo * 8 + ((4 * hi + t) ^ ((lo >> 1) & 7))));
+    for (int t = 0; t < 8; ++t) bt[t] = *reinterpret_cast<const f32x4*>(Bs + 4 * (lo * 8 + (t ^ ((lo >> 1) & 7))));
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
-      const float av = As[(16 * hi + s) * 32 + lo]; // A[m = lo][k = 16*hi + s]
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bt[s >> 2][s & 3], av, acc, 0, 0, 0);
+      const float av = As[(2 * s + hi) * 32 + lo]; // A[m = lo][k = 2s + hi]
+      const float bv = (0 != hi) ? bt[s >> 1][2 * (s & 1) + 1] : bt[s >> 1][2 * (s & 1)]; // B[k = 2s + hi][n = lo]
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bv, av, acc, 0, 0, 0);
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) st1<NT, GLB>(pc + ((r & 3) + 8 * (r >> 2)) * 32, acc[r]);

@@ -170,3 +170,64 @@ def test_full_size_config2_properties(xs, orc, torch_gpu, mfma):
             assert np.array_equal(got, ref)
     finally:
         L.libxsmm_amd_set_mfma(old)
+
+
+# ---- the reference's own GEMM test table (tests/gemm.c:75-82: 36 cases incl. empty dimensions, n = 13824 / 65792, k = 1742,
+# leading dimensions up to 9216; transposes NN, NT, TN, TT as in :84-88 with the dimension folding of :150-161) --------------------
+GEMM_C_M = [0, 1, 0, 0, 1, 1, 2, 3, 3, 1, 8, 64, 64, 16, 80, 80, 80, 80, 16, 260, 260, 260, 260, 350, 350, 350, 350, 350, 5, 10, 12, 20, 32, 9, 13, 5]
+GEMM_C_N = [0, 0, 1, 0, 1, 2, 2, 3, 1, 3, 1, 8, 239, 13824, 1, 3, 5, 7, 65792, 1, 3, 5, 7, 16, 1, 25, 4, 9, 13, 1, 10, 6, 33, 9, 13, 5]
+GEMM_C_K = [0, 0, 0, 1, 1, 2, 2, 3, 2, 2, 0, 64, 64, 16, 1, 3, 6, 10, 16, 1, 3, 6, 10, 20, 1, 35, 4, 10, 70, 1, 12, 6, 192, 1742, 13, 5]
+GEMM_C_LDA = [1, 1, 1, 1, 1, 1, 2, 3, 3, 1, 8, 64, 64, 16, 80, 80, 80, 80, 16, 260, 260, 260, 260, 350, 350, 350, 350, 350, 5, 22, 22, 22, 32, 9, 13, 5]
+GEMM_C_LDB = [1, 1, 1, 1, 1, 2, 2, 3, 2, 2, 8, 9216, 240, 16, 1, 3, 5, 5, 16, 1, 3, 5, 7, 35, 35, 35, 35, 35, 70, 1, 20, 8, 2048, 1742, 13, 5]
+GEMM_C_LDC = [1, 1, 1, 1, 1, 1, 2, 3, 3, 1, 8, 4096, 240, 16, 80, 80, 80, 80, 16, 260, 260, 260, 260, 350, 350, 350, 350, 350, 5, 22, 12, 20, 2048, 9, 13, 5]
+GEMM_C_BETA = [0, 0, 0, 0, 1, 1, 1, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 1, 0, 1, 0, 1, 0, 1, 1]
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_reference_gemm_table(xs, orc, torch_gpu, dtype):
+    """Every case of the reference's tests/gemm.c through libxsmm_?gemm on device memory: inputs by LIBXSMM_MATINIT (seeds 42 / 24
+    over the flat maximum-size buffers, :137-138), C all-ones bytes (NaN) for beta = 0 and zero otherwise (:162-175), all four
+    transpose pairs. The reference compares with a BLAS gold (absent here): the gold is numpy in float64."""
+    torch = torch_gpu
+    L = xs.lib()
+    T = len(GEMM_C_M)
+    lda = [max(GEMM_C_LDA[i], GEMM_C_M[i]) for i in range(T)]; ldb = [max(GEMM_C_LDB[i], GEMM_C_K[i]) for i in range(T)]
+    ldc = [max(GEMM_C_LDC[i], GEMM_C_M[i]) for i in range(T)]
+    size_a = max(lda[i] * GEMM_C_K[i] for i in range(T)); size_b = max(ldb[i] * GEMM_C_N[i] for i in range(T))
+    size_c = max(ldc[i] * GEMM_C_N[i] for i in range(T))
+    a = orc.matinit(42, size_a, 1, size_a, 1.0, dtype); b = orc.matinit(24, size_b, 1, size_b, 1.0, dtype)
+    da, db = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    gemm = L.libxsmm_dgemm if dtype == np.float64 else L.libxsmm_sgemm
+    ct = C.c_double if dtype == np.float64 else C.c_float
+    eps = np.finfo(dtype).eps
+    for i in range(T):
+        for ta, tb in ("NN", "NT", "TN", "TT"):
+            mi, ni, ki = GEMM_C_M[i], GEMM_C_N[i], GEMM_C_K[i]
+            if ta != "N" and tb == "N":
+                mi = ki = min(mi, ki)
+            elif ta == "N" and tb != "N":
+                ki = ni = min(ki, ni)
+            elif ta != "N" and tb != "N":
+                mi = ni = ki = min(mi, ni, ki)
+            beta = float(GEMM_C_BETA[i])
+            c = np.zeros(size_c, dtype=dtype)
+            if beta == 0.0:
+                c.view(np.uint8)[:] = 0xFF
+            dc = torch.from_numpy(c).cuda()
+            im, i_n, ik, ila, ilb, ilc = (C.c_int(v) for v in (mi, ni, ki, lda[i], ldb[i], ldc[i]))
+            al, be = ct(1.0), ct(beta)
+            gemm(ta.encode(), tb.encode(), C.byref(im), C.byref(i_n), C.byref(ik), C.byref(al), xs.dptr(da), C.byref(ila), xs.dptr(db), C.byref(ilb),
+                 C.byref(be), xs.dptr(dc), C.byref(ilc))
+            torch.cuda.synchronize()
+            out = dc.cpu().numpy()
+            if mi == 0 or ni == 0:
+                assert np.array_equal(out.view(np.uint8), c.view(np.uint8)), (i, ta, tb)  # nothing to do, nothing touched
+                continue
+            A = (a[:lda[i] * ki].reshape(ki, lda[i])[:, :mi].T if ta == "N" else a[:lda[i] * mi].reshape(mi, lda[i])[:, :ki]).astype(np.float64)
+            B = (b[:ldb[i] * ni].reshape(ni, ldb[i])[:, :ki].T if tb == "N" else b[:ldb[i] * ki].reshape(ki, ldb[i])[:, :ni]).astype(np.float64)
+            gold = A @ B  # (beta = 1 starts from zeros)
+            got = out[:ldc[i] * ni].reshape(ni, ldc[i])[:, :mi].T.astype(np.float64)
+            scale = max(np.max(np.abs(A), initial=0.0) * np.max(np.abs(B), initial=0.0) * max(ki, 1), 1e-300)
+            assert np.max(np.abs(got - gold), initial=0.0) <= 4 * eps * scale, (i, ta, tb, mi, ni, ki)
+            pad = out[:ldc[i] * ni].reshape(ni, ldc[i])[:, mi:]
+            assert np.array_equal(pad.view(np.uint8), c[:ldc[i] * ni].reshape(ni, ldc[i])[:, mi:].view(np.uint8)), (i, ta, tb)  # padding rows untouched

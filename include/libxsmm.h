@@ -693,6 +693,32 @@ LIBXSMM_API void libxsmm_gemm_print2(void* ostream, libxsmm_gemm_precision iprec
 #define LIBXSMM_MMDISPATCH_SYMBOL(TYPE) LIBXSMM_CONCATENATE(libxsmm_, LIBXSMM_TPREFIX(TYPE, mmdispatch))
 #define LIBXSMM_XGEMM_SYMBOL(TYPE) LIBXSMM_CONCATENATE(libxsmm_, LIBXSMM_TPREFIX(TYPE, gemm))
 #define LIBXSMM_XBLAS_SYMBOL(TYPE) LIBXSMM_CONCATENATE(libxsmm_blas_, LIBXSMM_TPREFIX(TYPE, gemm))
+#define LIBXSMM_TPREFIX_doubledouble d
+#define LIBXSMM_TPREFIX_floatfloat s
+#define LIBXSMM_TPREFIX_shortfloat ws
+#define LIBXSMM_TPREFIX_shortint wi
+#define LIBXSMM_TPREFIX2(ITYPE, OTYPE, FUNCTION) LIBXSMM_CONCATENATE(LIBXSMM_CONCATENATE(LIBXSMM_TPREFIX_, LIBXSMM_CONCATENATE(ITYPE, OTYPE)), FUNCTION)
+#define LIBXSMM_MMFUNCTION_TYPE2(ITYPE, OTYPE) LIBXSMM_CONCATENATE(libxsmm_, LIBXSMM_TPREFIX2(ITYPE, OTYPE, mmfunction))
+#define LIBXSMM_MMDISPATCH_SYMBOL2(ITYPE, OTYPE) LIBXSMM_CONCATENATE(libxsmm_, LIBXSMM_TPREFIX2(ITYPE, OTYPE, mmdispatch))
+#if defined(__cplusplus)
+# define LIBXSMM_EXTERN extern "C"
+#else
+# define LIBXSMM_EXTERN extern
+#endif
+#define LIBXSMM_BLAS_INIT /* (the reference pins its BLAS to one thread here) */
+/* include/libxsmm_generator.h:36-41: what the SMM kernels cover (everything else is the BLAS domain of libxsmm_?gemm) */
+#define LIBXSMM_GEMM_NO_BYPASS(FLAGS, ALPHA, BETA) ( \
+  0 == ((FLAGS) & (LIBXSMM_GEMM_FLAG_TRANS_A)) && (LIBXSMM_FEQ(1, ALPHA) /*|| LIBXSMM_FEQ(-1, ALPHA)*/) && \
+  (LIBXSMM_FEQ(1, BETA) || LIBXSMM_FEQ(0, BETA)))
+#define LIBXSMM_GEMM_NO_BYPASS_DIMS(M, N, K) (0x7FFFFFFF >= (M) && 0x7FFFFFFF >= (N) && 0x7FFFFFFF >= (K))
+/* include/libxsmm_macros.h:407-440 */
+#define LIBXSMM_DELTA(T0, T1) ((T0) < (T1) ? ((T1) - (T0)) : ((T0) - (T1)))
+#define LIBXSMM_ROUNDX(TYPE, A) ((TYPE)((long long)(0 <= (A) ? ((double)(A) + 0.5) : ((double)(A) - 0.5))))
+#define LIBXSMM_ROUND(A) round(A)
+#define LIBXSMM_ROUNDF(A) roundf(A)
+#define LIBXSMM_EXP2F(A) exp2f(A)
+#define LIBXSMM_SQRTF(A) sqrtf(A)
+#define LIBXSMM_TANHF(A) tanhf(A)
 #define LIBXSMM_YGEMM_SYMBOL(TYPE) LIBXSMM_XGEMM_SYMBOL(TYPE) /* (the reference appends _omp when OpenMP is on: one device path here) */
 #define LIBXSMM_FSYMBOL(SYMBOL) LIBXSMM_CONCATENATE(SYMBOL, _)
 #define LIBXSMM_BLAS_SYMBOL(TYPE, KIND) LIBXSMM_FSYMBOL(LIBXSMM_TPREFIX(TYPE, KIND))

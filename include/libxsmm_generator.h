@@ -1,0 +1,6 @@
+/* Compatibility header: the reference splits its interface over several headers (include/libxsmm_generator.h there); everything
+ * this engine provides is declared in libxsmm.h. */
+#ifndef LIBXSMM_GENERATOR_H_COMPAT
+#define LIBXSMM_GENERATOR_H_COMPAT
+#include "libxsmm.h"
+#endif

@@ -232,6 +232,8 @@ LIBXSMM_API void libxsmm_matdiff_clear(libxsmm_matdiff_info* info)
 LIBXSMM_API int libxsmm_matdiff(libxsmm_matdiff_info* info, libxsmm_datatype datatype, libxsmm_blasint m, libxsmm_blasint n,
   const void* ref, const void* tst, const libxsmm_blasint* ldref, const libxsmm_blasint* ldtst)
 {
+  bool swapped = false; // statistics of a single set: src/libxsmm_math.c:54,161-172
+  if (nullptr == ref && nullptr != tst) { ref = tst; tst = nullptr; swapped = true; }
   if (nullptr == info || nullptr == ref || (LIBXSMM_DATATYPE_F64 != datatype && LIBXSMM_DATATYPE_F32 != datatype) || m < 0 || n < 0) return EXIT_FAILURE;
   const libxsmm_blasint ldr = (nullptr != ldref ? *ldref : m), ldt = (nullptr != ldtst ? *ldtst : m);
   auto at = [datatype](const void* p, size_t i) { return LIBXSMM_DATATYPE_F64 == datatype ? static_cast<const double*>(p)[i] : (double)static_cast<const float*>(p)[i]; };
@@ -274,10 +276,23 @@ LIBXSMM_API int libxsmm_matdiff(libxsmm_matdiff_info* info, libxsmm_datatype dat
   info->normf_rel = (0 < sumsq_ref ? std::sqrt(sumsq_d / sumsq_ref) : std::sqrt(sumsq_d));
   info->l2_abs = std::sqrt(sumsq_d); info->l2_rel = std::sqrt(info->l2_rel);
   const double cnt = (double)m * n;
-  if (0 < cnt) {
+  if (0 < cnt) { // src/template/libxsmm_matdiff.tpl.c:153-154,185-196,232-233
     info->avg_ref = info->l1_ref / cnt; info->avg_tst = info->l1_tst / cnt;
+    double vr = 0, vt = 0;
+    for (libxsmm_blasint j = 0; j < n; ++j) {
+      for (libxsmm_blasint i = 0; i < m; ++i) {
+        const double r = at(ref, (size_t)j * ldr + i) - info->avg_ref, t = (nullptr != tst ? at(tst, (size_t)j * ldt + i) : 0.0) - info->avg_tst;
+        vr += r * r; vt += t * t;
+      }
+    }
+    info->var_ref = vr / cnt; info->var_tst = vt / cnt;
   }
   if (0 > info->m && 0 == info->linf_abs) { info->m = -1; info->n = -1; }
+  if (swapped) {
+    info->min_tst = info->min_ref; info->min_ref = 0; info->max_tst = info->max_ref; info->max_ref = 0;
+    info->avg_tst = info->avg_ref; info->avg_ref = 0; info->var_tst = info->var_ref; info->var_ref = 0;
+    info->l1_tst = info->l1_ref; info->l1_ref = 0;
+  }
   return EXIT_SUCCESS;
 }
 
@@ -291,8 +306,10 @@ LIBXSMM_API void libxsmm_matdiff_reduce(libxsmm_matdiff_info* output, const libx
   if (output->linf_rel < input->linf_rel) output->linf_rel = input->linf_rel;
   if (output->l2_abs < input->l2_abs) output->l2_abs = input->l2_abs;
   if (output->l2_rel < input->l2_rel) output->l2_rel = input->l2_rel;
-  if (output->l1_ref < input->l1_ref) output->l1_ref = input->l1_ref;
-  if (output->l1_tst < input->l1_tst) output->l1_tst = input->l1_tst;
+  if (output->var_ref < input->var_ref) output->var_ref = input->var_ref;
+  if (output->var_tst < input->var_tst) output->var_tst = input->var_tst;
+  output->avg_ref = 0.5 * (output->avg_ref + input->avg_ref); output->avg_tst = 0.5 * (output->avg_tst + input->avg_tst);
+  output->l1_ref += input->l1_ref; output->l1_tst += input->l1_tst;
   if (input->min_ref < output->min_ref) output->min_ref = input->min_ref;
   if (input->max_ref > output->max_ref) output->max_ref = input->max_ref;
   if (input->min_tst < output->min_tst) output->min_tst = input->min_tst;

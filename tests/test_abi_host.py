@@ -169,6 +169,28 @@ def test_reference_sample_programs_compile_and_link_unchanged(xs, tmp_path):
         assert res.returncode == 0, (srcs, res.stderr[-3000:])
 
 
+@pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="the reference tree is only present in the build container")
+def test_reference_unit_tests_pass_against_this_library(xs, tmp_path):
+    """The reference's own unit tests for the parts of the interface that need no device -- tests/gemmflags.c (transpose flag
+    macros), tests/vla.c (array views), tests/rng.c (distribution of libxsmm_rng_*), tests/matdiff.c, tests/threadsafety.c
+    (concurrent dispatch, registry, release) and tests/headeronly.c (+_aux: one registry across translation units) -- are
+    compiled from where they lie against include/ and libxsmm.so and RUN here; tests/gemm.c (needs the GPU to run) is compiled
+    and linked with the BLAS wrapper. Nothing of the reference is copied or modified."""
+    libdir = os.path.dirname(xs.LIB_PATH)
+    T = os.path.join(REFERENCE, "tests")
+    base = ["gcc", "-std=gnu99", "-O0", "-fopenmp", "-I", os.path.join(ROOT, "include")]
+    link = ["-L", libdir, "-lxsmm", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-lm"]
+    for name, extra, run in (("gemmflags", [], True), ("vla", [], True), ("rng", [], True), ("matdiff", [], True), ("threadsafety", [], True),
+                             ("headeronly", [os.path.join(T, "headeronly_aux.c")], True),
+                             ("gemm", ["-Wl,--wrap=dgemm_,--wrap=sgemm_"], False)):
+        exe = tmp_path / name
+        res = subprocess.run(base + [os.path.join(T, name + ".c")] + extra + ["-o", str(exe)] + link, capture_output=True, text=True)
+        assert res.returncode == 0, (name, res.stderr[-3000:])
+        if run:
+            res = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+            assert res.returncode == 0, (name, res.returncode, res.stdout[-1000:], res.stderr[-1000:])
+
+
 def test_descriptor_rules(xs):
     """include/libxsmm_generator.h:36-39: NULL unless alpha == 1, beta in {0,1}, no TRANS_A; beta == 0 sets FLAG_BETA_0."""
     L = xs.lib()

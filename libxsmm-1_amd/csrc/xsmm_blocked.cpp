@@ -177,6 +177,19 @@ void bgemm_run(const libxsmm_blocked_gemm_handle* h, const void* a, const void* 
   s.use_mfma = libxsmm_amd_get_mfma(); s.alpha = 1; s.beta = 1;
   const char* name = "";
   int e = launch_smm_special(s, device().stream, &name);
+  if (e < 0) {
+    // The work list is a sequence of runs (all k blocks of a C block follow each other). The reference sums a run into a
+    // thread-local block and adds that to C under a lock (tpl :95-103): the order of the partial sums is open, so the
+    // shape-specialised run kernels may cut few long runs into segments; the verdict on the runs is
+    // taken on the device like for any index batch.
+    int* const d_flags = flag_slot();
+    SmmBatch j = s;
+    if (nullptr != d_flags && 0 == launch_c_order_check(j, d_flags, device().stream)) {
+      j.sync = SYNC_DEVICE; j.devflags = d_flags; j.relaxed = 1; j.c_atomics = is_host_visible(dc) ? 0 : 1;
+      j.uniform_run = h->kb; // every C block's k blocks follow each other in the work list
+      if (smm_jit_eligible(j)) e = launch_smm_jit(j, device().stream, &name);
+    }
+  }
   if (e < 0) e = launch_smm_generic(s, device().stream, &name);
   note_launch(name);
   if (0 != e) { fprintf(stderr, "LIBXSMM-AMD ERROR: kernel launch failed (%s, hip error %d)\n", name, e); return; }

@@ -586,13 +586,16 @@ __device__ __forceinline__ void park_chunk(T* As, T* Bs, int ch, int t, const T 
   }
 }
 
-extern "C" __global__ __launch_bounds__(256) void xsmm_smm_op(DevAddr ad, long long batch)
+// runlen: the batch is a sequence of runs of `runlen` consecutive items that share one C (blocked GEMM: the k blocks of a C
+// block; 1: every item owns its C). A work-group keeps C in registers across a run: the chain of the sequential reference.
+extern "C" __global__ __launch_bounds__(256) void xsmm_smm_op(DevAddr ad, long long batch, long long runlen)
 {
   __shared__ __attribute__((aligned(16))) T lds[2 * BUF];
   const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
-  long long item = blockIdx.x;
-  if (item >= batch) return;
-  const long long G = gridDim.x;
+  const long long nruns = batch / runlen, G = gridDim.x;
+  long long run = blockIdx.x;
+  if (run >= nruns) return;
+  long long item = run * runlen, p = 0;
   T ra[NLA], rb[NLB], rc[TM][TN], acc[TM][TN];
   // software pipeline over (item, chunk): the registers hold the chunk after the one that is being multiplied
   load_chunk(resolve<const T>(ad.a, ad.ia, ad.sa, ad, item), resolve<const T>(ad.b, ad.ib, ad.sb, ad, item), 0, t, ra, rb);
@@ -605,23 +608,25 @@ extern "C" __global__ __launch_bounds__(256) void xsmm_smm_op(DevAddr ad, long l
     }
   }
   int buf = 0;
-  for (; item < batch; item += G) {
-    T* const pc = resolve<T>(ad.c, ad.ic, ad.sc, ad, item);
+  for (;;) {
+    if (0 == p) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+      for (int i = 0; i < TM; ++i) {
 #pragma unroll
-      for (int j = 0; j < TN; ++j) acc[i][j] = XBETA0 ? (T)0 : rc[i][j];
+        for (int j = 0; j < TN; ++j) acc[i][j] = XBETA0 ? (T)0 : rc[i][j];
+      }
     }
-    const long long next = item + G;
+    const bool same_run = (p + 1 < runlen), has_next = same_run || (run + G < nruns);
+    const long long next = same_run ? (item + 1) : ((run + G) * runlen);
 #pragma unroll 1
     for (int ch = 0; ch < NCH; ++ch) {
       T* const As = lds + buf * BUF;
       T* const Bs = As + AS;
       park_chunk(As, Bs, ch, t, ra, rb);
       if (ch + 1 < NCH) load_chunk(resolve<const T>(ad.a, ad.ia, ad.sa, ad, item), resolve<const T>(ad.b, ad.ib, ad.sb, ad, item), ch + 1, t, ra, rb);
-      else if (next < batch) { // first chunk and C of the next item
+      else if (has_next) { // first chunk of the next item, and its C if it opens a run
         load_chunk(resolve<const T>(ad.a, ad.ia, ad.sa, ad, next), resolve<const T>(ad.b, ad.ib, ad.sb, ad, next), 0, t, ra, rb);
-        if (!XBETA0) {
+        if (!XBETA0 && !same_run) {
           const XGLOBAL T* const gc = (const XGLOBAL T*)resolve<T>(ad.c, ad.ic, ad.sc, ad, next);
 #pragma unroll
           for (int j = 0; j < TN; ++j) {
@@ -647,12 +652,17 @@ extern "C" __global__ __launch_bounds__(256) void xsmm_smm_op(DevAddr ad, long l
       }
       buf ^= 1;
     }
-    XGLOBAL T* const gc = (XGLOBAL T*)pc;
+    if (!same_run) { // the run is complete
+      XGLOBAL T* const gc = (XGLOBAL T*)resolve<T>(ad.c, ad.ic, ad.sc, ad, item);
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
+      for (int j = 0; j < TN; ++j) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i) { const int m = tx * TM + i, n = ty * TN + j; if (m < M && n < N) __builtin_nontemporal_store(acc[i][j], gc + n * M + m); }
+        for (int i = 0; i < TM; ++i) { const int m = tx * TM + i, n = ty * TN + j; if (m < M && n < N) __builtin_nontemporal_store(acc[i][j], gc + n * M + m); }
+      }
     }
+    if (!has_next) break;
+    if (same_run) ++p; else { p = 0; run += G; }
+    item = next;
   }
 }
 )XSMM";
@@ -763,7 +773,8 @@ bool smm_jit_eligible(const SmmBatch& s)
   if (s.lda != s.m || s.ldc != s.m) return false;
   if (0 != (s.flags & LIBXSMM_GEMM_FLAG_TRANS_B) ? (s.ldb != s.n) : (s.ldb != s.k)) return false;
   if (s.m > 32 || s.n > 32) { // work-group-per-item form: 16x16 threads x (<=4x4) tile, K chunked; independent C only
-    if (s.m > 64 || s.n > 64 || s.k > 1024 || SYNC_NONE != s.sync) return false;
+    if (s.m > 64 || s.n > 64 || s.k > 1024) return false;
+    if (SYNC_NONE != s.sync && !(0 < s.uniform_run && 0 == s.batch % s.uniform_run)) return false; // shared C only as runs of a known, uniform length
     if (0 == smm_jit_big_kc(s.typesize, s.m, s.n, s.k, s.flags)) return false;
   }
   else {
@@ -835,10 +846,12 @@ static int smm_jit_launch_variant(const SmmBatch& s, int variant, void* stream)
     if (0 < occ && occ < per_cu) per_cu = occ;
     if (per_cu < 1) per_cu = 1;
     if (0 < bpc_env) per_cu = bpc_env;
-    long long blocks = batch;
+    long long runlen = (0 < s.uniform_run ? s.uniform_run : 1);
+    long long blocks = batch / runlen;
     if (blocks > 256 * per_cu) blocks = 256 * per_cu;
     if (blocks < 1) blocks = 1;
-    return jit_launch_raw(k, (unsigned)blocks, 256u, &ad, sizeof(ad), &batch, stream);
+    void* args[] = { &ad, &batch, &runlen };
+    return jit_launch_args(k, (unsigned)blocks, 256u, args, stream);
   }
   if (0 != (variant & SMM_JIT_WGRUNS)) { // work-groups of 256 threads, dealt chunks of 64 items
     const size_t buf = smm_jit_wg_buf(s.typesize, s.m, s.n, s.k, s.flags);
@@ -898,7 +911,7 @@ int launch_smm_jit(const SmmBatch& s, void* stream, const char** name)
 { // returns -1 when no specialised kernel is available
   const int width = smm_jit_width_variant(s);
   const bool f64 = (8 == s.typesize);
-  if (s.m > 32 || s.n > 32) { // (eligibility made sure of SYNC_NONE)
+  if (s.m > 32 || s.n > 32) { // (eligibility made sure of SYNC_NONE, or of runs of a uniform length)
     *name = f64 ? "smm_f64_jit_shape_wg" : "smm_f32_jit_shape_wg";
     return smm_jit_launch_variant(s, SMM_JIT_BIG, stream);
   }

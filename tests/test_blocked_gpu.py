@@ -6,6 +6,7 @@ reference only in association (device: chain continues from C; reference: thread
 held to the north_star tolerance.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -120,3 +121,52 @@ def test_blocked_permutations(xs, orc, torch_gpu, dtype, geom):
         assert 0 != L.libxsmm_blocked_gemm_transpose_b(None, xs.dptr(src), None, xs.dptr(hdst))
     finally:
         L.libxsmm_blocked_gemm_handle_destroy(h)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("geom", [(256, 192, 320, 32, 32, 32), (256, 128, 384, 64, 64, 64), (192, 192, 192, 48, 24, 16), (128, 128, 4096, 32, 32, 32)])
+def test_blocked_gemm_on_the_specialised_run_kernels(xs, torch_gpu, dtype, geom):
+    """Large block GEMMs run on the hiprtc-specialised run kernels (wave / work-group per C block, segments for few long runs,
+    the work-group-per-item form with uniform runs for blocks up to 64): forced here for small problems; compared with the
+    plain GEMM the reference's sample checks against (samples/blocked_gemm/blocked_gemm.c:181). (128 x 128 x 4096: 16 C
+    blocks with 128 k blocks each -- few long runs.)"""
+    torch = torch_gpu
+    m, n, k, bm, bn, bk = geom
+    ts = 8 if dtype == np.float64 else 4
+    prec = xs.F64 if ts == 8 else xs.F32
+    rng = np.random.default_rng(m + n + k + bm)
+    a = rng.uniform(-1, 1, m * k).astype(dtype); b = rng.uniform(-1, 1, k * n).astype(dtype); c = rng.uniform(-1, 1, m * n).astype(dtype)
+    L = xs.lib()
+    old_env = os.environ.get("LIBXSMM_AMD_JIT_MINBATCH")
+    os.environ["LIBXSMM_AMD_JIT_MINBATCH"] = "1"
+    old = L.libxsmm_amd_set_mfma(0)
+    try:
+        ibm, ibn, ibk, one, iorder = (C.c_int(v) for v in (bm, bn, bk, 1, 0))
+        al = (C.c_double if ts == 8 else C.c_float)(1.0); be = (C.c_double if ts == 8 else C.c_float)(1.0)
+        h = L.libxsmm_blocked_gemm_handle_create(1, prec, prec, m, n, k, C.byref(ibm), C.byref(ibn), C.byref(ibk),
+                                                 C.byref(one), C.byref(one), C.byref(one), C.byref(one), C.byref(al), C.byref(be), None, None, C.byref(iorder))
+        assert h
+        da, db, dc = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), torch.from_numpy(c).cuda()
+        ba, bb, bc = torch.empty_like(da), torch.empty_like(db), torch.empty_like(dc)
+        ldm, ldk = C.c_int(m), C.c_int(k)
+        assert 0 == L.libxsmm_blocked_gemm_copyin_a(h, xs.dptr(da), C.byref(ldm), xs.dptr(ba))
+        assert 0 == L.libxsmm_blocked_gemm_copyin_b(h, xs.dptr(db), C.byref(ldk), xs.dptr(bb))
+        assert 0 == L.libxsmm_blocked_gemm_copyin_c(h, xs.dptr(dc), C.byref(ldm), xs.dptr(bc))
+        L.libxsmm_blocked_gemm_st(h, xs.dptr(ba), xs.dptr(bb), xs.dptr(bc), 0, 0)
+        torch.cuda.synchronize()
+        assert "_jit_shape" in xs.last_kernel(), xs.last_kernel()
+        out = torch.empty_like(dc)
+        assert 0 == L.libxsmm_blocked_gemm_copyout_c(h, xs.dptr(bc), C.byref(ldm), xs.dptr(out))
+        torch.cuda.synchronize()
+        got = out.cpu().numpy().astype(np.float64)
+        L.libxsmm_blocked_gemm_handle_destroy(h)
+    finally:
+        L.libxsmm_amd_set_mfma(old)
+        if old_env is None:
+            del os.environ["LIBXSMM_AMD_JIT_MINBATCH"]
+        else:
+            os.environ["LIBXSMM_AMD_JIT_MINBATCH"] = old_env
+    A = a.reshape(k, m).T.astype(np.float64); B = b.reshape(n, k).T.astype(np.float64); Cm = c.reshape(n, m).T.astype(np.float64)
+    expect = A @ B + Cm
+    tol = np.finfo(dtype).eps * np.sqrt(k) * 8
+    assert np.max(np.abs(got.reshape(n, m).T - expect)) <= tol * np.max(np.abs(expect))

@@ -51,7 +51,13 @@ void smm_generic_kernel(DevAddr ad, int M, int N, int K, int lda, int ldb, int l
   const long long unit = (long long)blockIdx.x * PPB + slot;
   const long long nunits = (long long)gridDim.x * PPB;
 
-  for (long long item = unit; item < batch; item += nunits) {
+  // Run mode: only the head of a run works. Dealt round-robin, the heads of runs of a uniform length that divides the number
+  // of units (blocked GEMM: 32 k blocks per C block, 4096 units) would all land on the same few units -- every unit takes a
+  // contiguous slice of the batch instead (a run that starts in the slice is walked to its end, wherever that is).
+  const bool sliced = (SYNC_RUNS == sync);
+  const long long per = sliced ? ((batch + nunits - 1) / nunits) : 1;
+  const long long lo = sliced ? unit * per : unit, hi = sliced ? ((lo + per < batch) ? lo + per : batch) : batch, step = sliced ? 1 : nunits;
+  for (long long item = lo; item < hi; item += step) {
     T* const pc = addr_c<T>(ad, item);
     long long count = 1;
     if (SYNC_RUNS == sync) { // only the head of a run of equal C works; it walks the run in batch order

@@ -357,7 +357,12 @@ extern "C" __global__ __launch_bounds__(256) void xsmm_smm_op(DevAddr ad, long l
   }
   T ra[D][NLA][VA], rb[D][NLB][VB];
   int buf = 0;
-  for (long long chunk = (long long)blockIdx.x * 64; chunk < batch; chunk += (long long)gridDim.x * 64) {
+  // every work-group takes a contiguous range of chunks (dealt round-robin, runs of a uniform length of 128, 256, ... items
+  // would put all run heads into the chunks of every 2nd, 4th, ... work-group)
+  const long long nchunks = (batch + 63) / 64, cpw = (nchunks + gridDim.x - 1) / gridDim.x;
+  const long long c_end = ((long long)(blockIdx.x + 1) * cpw < nchunks) ? (long long)(blockIdx.x + 1) * cpw : nchunks;
+  for (long long ci = (long long)blockIdx.x * cpw; ci < c_end; ++ci) {
+    const long long chunk = ci * 64;
     unsigned long long heads; long long first, end;
     if (!chain_of_chunk(ad, chunk, lane, batch, heads, first, end)) continue; // identical in the four waves
     AddrWindow win; window_fill(win, ad, first, lane, end);
@@ -438,7 +443,11 @@ extern "C" __global__ __launch_bounds__(64 * XWAVES) void xsmm_smm_op(DevAddr ad
   if (XHASWG && nullptr != ad.flags && 0 == seg && 8LL * ad.flags[0] >= 7LL * batch) return; // runs of 8 and more on average: the work-group form owns this batch
   const long long step = (0 != seg ? seg : 64);
   T ra[D][NLA][VA], rb[D][NLB][VB], rc[NLC][VC];
-  for (long long chunk = w * step; chunk < batch; chunk += W * step) {
+  // every wave takes a contiguous range of chunks (see the work-group form)
+  const long long nchunks = (batch + step - 1) / step, cpw = (nchunks + W - 1) / W;
+  const long long c_end = ((w + 1) * cpw < nchunks) ? (w + 1) * cpw : nchunks;
+  for (long long ci = w * cpw; ci < c_end; ++ci) {
+    const long long chunk = ci * step;
     unsigned long long heads; long long first, end;
     if (0 != seg) { // a segment is walked from its first item, whoever opened the run it starts in
       heads = head_mask(ad, chunk, lane, batch) | 1ULL;

@@ -774,6 +774,11 @@ int launch_spmdm_create_blocks(int M, int K, int bm, int bk, int mb, int first_s
   hipStream_t st = (hipStream_t)stream;
   *name = "spmdm_create_slices_wave";
   const long long cap = (long long)bm * bk, rstride = (long long)bm + 1;
+  if (0 == first_slice && 1 < nslices) { // all slices of the matrix: one launch, a wavefront per slice (kb = id / mb, mb = id % mb)
+    hipLaunchKernelGGL(spmdm_create_kernel, dim3(grid_for(nslices, 4)), dim3(256), 0, st,
+      (long long)nslices, 0, 0, transa, a, 0LL, transa ? M : K, mb, bm, bk, M, K, rowidx, colidx, values, rstride, cap);
+    return (int)hipGetLastError();
+  }
   // the kernel numbers slices from 0: offset the outputs and let it skip the leading ids via the pointer arithmetic
   // (slice id is needed for kb/mb, so pass a shifted count and shift inside through a wrapper loop)
   for (int s = first_slice; s < first_slice + nslices; ++s) {

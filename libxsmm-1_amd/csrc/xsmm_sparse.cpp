@@ -5,6 +5,8 @@
 
 #include <cassert>
 #include <cstring>
+#include <mutex>
+#include <unordered_map>
 #include <vector>
 
 namespace xsmm {
@@ -224,10 +226,13 @@ LIBXSMM_API void libxsmm_spmdm_init(int M, int N, int K, int max_threads,
   *libxsmm_output_csr = slices;
 }
 
+namespace { void spmdm_forget(const void* device_block); }
+
 LIBXSMM_API void libxsmm_spmdm_destroy(libxsmm_spmdm_handle* handle)
 {
   if (nullptr == handle) return;
   if (device_ready()) (void)stream_sync();
+  spmdm_forget(handle->base_ptr_scratch_A);
   dev_free(handle->base_ptr_scratch_A); handle->base_ptr_scratch_A = nullptr;
   free(handle->base_ptr_scratch_B_scratch_C); handle->base_ptr_scratch_B_scratch_C = nullptr;
 }
@@ -264,26 +269,72 @@ const float* widen_bf16(const libxsmm_bfloat16* p, size_t elems, int slot_raw, i
   return wide;
 }
 
-void spmdm_create_block(const libxsmm_spmdm_handle* handle, int ta, const float* da, int block_id)
+// ---- sweeps over the blocks of one problem -----------------------------------------------------------------------------
+// The reference's interface hands out one block per call (a thread's share of an OpenMP loop, samples/spmdm/spmdm.c:74-112).
+// One block is a few work-groups: launched call by call on one stream, a 2048^3 problem took 26 ms to slice and 17 ms to
+// multiply. A caller that walks the blocks from one thread (nthreads == 1) with device-resident operands gets the WHOLE
+// problem launched when it asks for the first block of a sweep; the remaining block calls of that sweep (same operands, a
+// block not yet asked for) find their work done and return. Asking for a block a second time, or with other operands,
+// starts a new sweep. (Blocks nobody asks for are computed as well: their tiles of C hold the product, too.)
+struct SpmdmSweep {
+  bool active = false; const void* p0 = nullptr; const void* p1 = nullptr; int t0 = 0, t1 = 0; float beta = 0.f;
+  std::vector<char> done;
+  // true: block_id belongs to the running sweep (nothing to do); false: the caller must launch the whole problem now
+  bool covered(const void* q0, const void* q1, int u0, int u1, float be, int block_id, int nblocks)
+  {
+    if (active && q0 == p0 && q1 == p1 && u0 == t0 && u1 == t1 && be == beta && block_id < (int)done.size() && 0 == done[block_id]) {
+      done[block_id] = 1;
+      bool all = true; for (char d : done) all = all && (0 != d);
+      if (all) active = false;
+      return true;
+    }
+    p0 = q0; p1 = q1; t0 = u0; t1 = u1; beta = be;
+    done.assign((size_t)(0 < nblocks ? nblocks : 1), 0);
+    if (0 <= block_id && block_id < nblocks) done[block_id] = 1;
+    active = (1 < nblocks);
+    return false;
+  }
+};
+struct SpmdmSweeps { SpmdmSweep create, compute; };
+std::mutex g_sweep_lock;
+std::unordered_map<const void*, SpmdmSweeps> g_sweeps; // keyed by the handle's device block
+
+void spmdm_forget(const void* device_block) { std::lock_guard<std::mutex> guard(g_sweep_lock); g_sweeps.erase(device_block); }
+
+void spmdm_create_block(const libxsmm_spmdm_handle* handle, int ta, const float* da, int block_id, bool sweep = false)
 { // da: device-resident M x K (or K x M) fp32 matrix
   const size_t nslices = (size_t)handle->mb * handle->kb, cap = (size_t)handle->bm * handle->bk;
   float* const values = reinterpret_cast<float*>(handle->base_ptr_scratch_A);
   uint16_t* const colidx = reinterpret_cast<uint16_t*>(handle->base_ptr_scratch_A + nslices * cap * sizeof(float));
   uint16_t* const rowidx = colidx + nslices * cap;
   const char* name = "";
-  const int e = launch_spmdm_create_blocks(handle->m, handle->k, handle->bm, handle->bk, handle->mb, block_id, 1, ta, da,
+  int first = block_id, count = 1;
+  if (sweep) {
+    std::lock_guard<std::mutex> guard(g_sweep_lock);
+    SpmdmSweeps& w = g_sweeps[handle->base_ptr_scratch_A];
+    if (w.create.covered(da, nullptr, ta, 0, 0.f, block_id, (int)nslices)) return;
+    w.compute.active = false; // the slices change: whatever was multiplied belongs to the past
+    first = 0; count = (int)nslices;
+  }
+  const int e = launch_spmdm_create_blocks(handle->m, handle->k, handle->bm, handle->bk, handle->mb, first, count, ta, da,
     rowidx, colidx, values, device().stream, &name);
   note_launch(name);
   if (0 != e) fprintf(stderr, "LIBXSMM-AMD ERROR: kernel launch failed (%s, hip error %d)\n", name, e);
 }
 
 void spmdm_compute_block(const libxsmm_spmdm_handle* handle, int tb, int tc, float beta, libxsmm_CSR_sparseslice* a_sparse,
-                         const float* db, float* c, int block_id, bool sync_inputs)
+                         const float* db, float* c, int block_id, bool sync_inputs, bool sweep = false)
 { // db: device-resident fp32 B; c: device or host
   const int mb = block_id / handle->nb, nb = block_id % handle->nb; // compute tpl :38-39
-  const int m0 = mb * handle->bm, n0 = nb * handle->bn;
-  const int m1 = LIBXSMM_MIN(m0 + handle->bm, handle->m), n1 = LIBXSMM_MIN(n0 + handle->bn, handle->n);
+  int m0 = mb * handle->bm, n0 = nb * handle->bn;
+  int m1 = LIBXSMM_MIN(m0 + handle->bm, handle->m), n1 = LIBXSMM_MIN(n0 + handle->bn, handle->n);
   float* dc = c; const bool c_host = !is_device_ptr(c);
+  if (sweep && !c_host && !sync_inputs) {
+    std::lock_guard<std::mutex> guard(g_sweep_lock);
+    SpmdmSweeps& w = g_sweeps[handle->base_ptr_scratch_A];
+    if (w.compute.covered(db, c, tb, tc, beta, block_id, handle->mb * handle->nb)) return;
+    m0 = 0; n0 = 0; m1 = handle->m; n1 = handle->n; // the whole product
+  }
   const size_t celems = (size_t)handle->m * handle->n;
   if (c_host) {
     dc = static_cast<float*>(scratch(5, celems * sizeof(float)));
@@ -313,13 +364,13 @@ void spmdm_compute_block(const libxsmm_spmdm_handle* handle, int tb, int tc, flo
 LIBXSMM_API void libxsmm_spmdm_createSparseSlice_fp32_thread(const libxsmm_spmdm_handle* handle, char transa,
   const float* a, libxsmm_CSR_sparseslice* libxsmm_output_csr_a, int block_id, int tid, int nthreads)
 {
-  (void)tid; (void)nthreads;
+  (void)tid;
   if (nullptr == handle || nullptr == a || nullptr == libxsmm_output_csr_a || nullptr == handle->base_ptr_scratch_A) return;
   if (!device_ready()) { fail_no_device("libxsmm_spmdm_createSparseSlice_fp32_thread"); return; }
   bool ok = true;
   const float* const da = mirror_in(a, (size_t)handle->m * handle->k, 3, &ok);
   if (!ok) return;
-  spmdm_create_block(handle, ('T' == transa || 't' == transa), da, block_id);
+  spmdm_create_block(handle, ('T' == transa || 't' == transa), da, block_id, 1 == nthreads && da == a && !is_host_visible(a));
   if (da != a) (void)stream_sync(); // the staging buffer is reused by the next call
   else settle(a);
 }
@@ -341,13 +392,14 @@ LIBXSMM_API void libxsmm_spmdm_compute_fp32_thread(const libxsmm_spmdm_handle* h
   const float* alpha, libxsmm_CSR_sparseslice* a_sparse, const float* b, char transc, const float* beta, float* c,
   int block_id, int tid, int nthreads)
 {
-  (void)transa; (void)alpha; (void)tid; (void)nthreads; // alpha is ignored by the reference (include/libxsmm_spmdm.h:104)
+  (void)transa; (void)alpha; (void)tid; // alpha is ignored by the reference (include/libxsmm_spmdm.h:104)
   if (nullptr == handle || nullptr == a_sparse || nullptr == b || nullptr == c || nullptr == beta) return;
   if (!device_ready()) { fail_no_device("libxsmm_spmdm_compute_fp32_thread"); return; }
   bool ok = true;
   const float* const db = mirror_in(b, (size_t)handle->k * handle->n, 4, &ok);
   if (!ok) return;
-  spmdm_compute_block(handle, ('T' == transb || 't' == transb), ('T' == transc || 't' == transc), *beta, a_sparse, db, c, block_id, db != b);
+  spmdm_compute_block(handle, ('T' == transb || 't' == transb), ('T' == transc || 't' == transc), *beta, a_sparse, db, c, block_id, db != b,
+    1 == nthreads && db == b && !is_host_visible(b) && !is_host_visible(c));
 }
 
 LIBXSMM_API void libxsmm_spmdm_compute_bfloat16_thread(const libxsmm_spmdm_handle* handle, char transa, char transb,

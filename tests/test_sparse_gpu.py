@@ -278,3 +278,67 @@ def test_spmdm_batch_config4(xs, orc, torch_gpu, keep, variant):
         assert xs.last_kernel().startswith("spmdm_compute")
         assert np.array_equal(dc.cpu().numpy(), ref)
     L.libxsmm_amd_spmdm_batch_destroy(sb)
+
+
+def test_spmdm_block_sweeps(xs, orc, torch_gpu):
+    """The per-block interface walked from one thread: the whole problem is launched with the first block of a sweep and the
+    other block calls of that sweep return at once (csrc/xsmm_sparse.cpp). Checked here: a second sweep over the same
+    pointers after B changed recomputes; beta = 1 sweeps accumulate once per sweep; asking for a block twice starts a new
+    sweep; blocks in reverse order; new slices after A changed; several tasks (nthreads > 1) keep the per-block path."""
+    torch = torch_gpu
+    M, N, K = 301, 131, 263
+    a, b, c = spmdm_inputs(M, N, K, 0.85, 2, orc)
+    L = xs.lib()
+    h = xs.SpmdmHandle(); slices = C.POINTER(xs.CSRSlice)()
+    L.libxsmm_spmdm_init(M, N, K, 1, C.byref(h), C.byref(slices))
+    ncreate, ncomp = L.libxsmm_spmdm_get_num_createSparseSlice_blocks(C.byref(h)), L.libxsmm_spmdm_get_num_compute_blocks(C.byref(h))
+    assert ncreate > 1 and ncomp > 1
+    da, db, dc = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), torch.from_numpy(c).cuda()
+    alpha = C.c_float(1.0)
+
+    def create(order=None, nthreads=1):
+        for blk in (order if order is not None else range(ncreate)):
+            L.libxsmm_spmdm_createSparseSlice_fp32_thread(C.byref(h), b"N", xs.dptr(da), slices, blk, blk % nthreads, nthreads)
+
+    def compute(beta, order=None, nthreads=1):
+        be = C.c_float(beta)
+        for blk in (order if order is not None else range(ncomp)):
+            L.libxsmm_spmdm_compute_fp32_thread(C.byref(h), b"N", b"N", C.byref(alpha), slices, xs.dptr(db), b"N", C.byref(be), xs.dptr(dc), blk, blk % nthreads, nthreads)
+        torch.cuda.synchronize()
+        return dc.cpu().numpy()
+
+    def gold(a_, b_, c_, beta):
+        r = c_.copy(); orc.spmdm_exec(orc.FMA, M, N, K, 48, "N", "N", "N", beta, a_, b_, r); return r
+
+    create()
+    launches = L.libxsmm_amd_launch_count()
+    out = compute(0.0)
+    assert L.libxsmm_amd_launch_count() == launches + 1  # one launch for the whole sweep
+    assert np.array_equal(out, gold(a, b, c, 0.0))
+    # B changes in place, same pointers: the next sweep (block 0 asked for again) recomputes
+    b2 = (b * 0.5 + 0.25).astype(np.float32); db.copy_(torch.from_numpy(b2))
+    out = compute(0.0, order=list(reversed(range(ncomp))))
+    assert np.array_equal(out, gold(a, b2, c, 0.0))
+    # beta = 1: one accumulation per sweep
+    c1 = gold(a, b2, c, 0.0)
+    out = compute(1.0)
+    assert np.array_equal(out, gold(a, b2, c1, 1.0))
+    out = compute(1.0)
+    assert np.array_equal(out, gold(a, b2, gold(a, b2, c1, 1.0), 1.0))
+    # a sweep that is abandoned half way, then a full one
+    out = compute(0.0, order=[0, 1])
+    out = compute(0.0)
+    assert np.array_equal(out, gold(a, b2, c, 0.0))
+    # A changes: new slices, then the product must use them (a compute sweep may not survive new slices)
+    a2 = a.copy(); a2[::7] = 0.0; a2[3::11] *= 2.0; da.copy_(torch.from_numpy(a2))
+    out_before = compute(0.0)  # still the old slices
+    assert np.array_equal(out_before, gold(a, b2, c, 0.0))
+    create(order=list(reversed(range(ncreate))))
+    out = compute(0.0)
+    assert np.array_equal(out, gold(a2, b2, c, 0.0))
+    # several tasks: block by block
+    launches = L.libxsmm_amd_launch_count()
+    out = compute(0.0, nthreads=3)
+    assert L.libxsmm_amd_launch_count() == launches + ncomp
+    assert np.array_equal(out, gold(a2, b2, c, 0.0))
+    L.libxsmm_spmdm_destroy(C.byref(h))

@@ -125,6 +125,51 @@ int flag_slot_set(int* slot, int equal_pairs, int decreasing_pairs)
   return (int)e;
 }
 
+// Index arrays of a batch call that live in host memory (an unchanged caller's stride arrays): staged through a per-thread ring
+// of pinned buffers and copied with the copy engine, asynchronously -- the call does not wait for the GPU. A ring entry is
+// reused 8 calls later; by then the launch that read it (event recorded by index_upload_commit) is normally long done.
+namespace {
+struct IndexStage { void* host = nullptr; void* dev = nullptr; size_t size = 0; hipEvent_t done = nullptr; void* stream = nullptr; int state = 0; /* 1: filled, 2: committed */ };
+constexpr int INDEX_RING = 24;
+thread_local IndexStage tl_index_ring[INDEX_RING];
+thread_local unsigned tl_index_next = 0;
+}
+
+void* index_upload(const void* src, size_t bytes)
+{
+  IndexStage& e = tl_index_ring[tl_index_next++ % INDEX_RING];
+  if (2 == e.state) (void)hipEventSynchronize(e.done);
+  else if (1 == e.state) (void)hipStreamSynchronize((hipStream_t)e.stream); // filled but never committed (an error path)
+  e.state = 0;
+  if (e.size < bytes) {
+    if (nullptr != e.host) (void)hipHostFree(e.host);
+    if (nullptr != e.dev) (void)hipFree(e.dev);
+    e.host = e.dev = nullptr; e.size = 0;
+    const size_t want = bytes + bytes / 4 + 4096;
+    if (hipSuccess != hipHostMalloc(&e.host, want, hipHostMallocDefault) || hipSuccess != hipMalloc(&e.dev, want)) {
+      (void)hipGetLastError();
+      if (nullptr != e.host) (void)hipHostFree(e.host);
+      e.host = nullptr; e.dev = nullptr;
+      return nullptr;
+    }
+    e.size = want;
+  }
+  if (nullptr == e.done && hipSuccess != hipEventCreateWithFlags(&e.done, hipEventDisableTiming)) { (void)hipGetLastError(); return nullptr; }
+  memcpy(e.host, src, bytes);
+  e.stream = device().stream;
+  if (hipSuccess != hipMemcpyAsync(e.dev, e.host, bytes, hipMemcpyHostToDevice, (hipStream_t)e.stream)) { (void)hipGetLastError(); return nullptr; }
+  e.state = 1;
+  return e.dev;
+}
+
+void index_upload_commit()
+{ // the launches that read the staged arrays are queued: mark the point after which the entries may be overwritten
+  for (int i = 0; i < INDEX_RING; ++i) {
+    IndexStage& e = tl_index_ring[i];
+    if (1 == e.state) { if (hipSuccess == hipEventRecord(e.done, (hipStream_t)e.stream)) e.state = 2; else (void)hipGetLastError(); }
+  }
+}
+
 void* scratch(int slot, size_t bytes)
 {
   Scratch& s = tl_scratch[slot & 7];

@@ -105,8 +105,9 @@ const int* device_indexes(const int* idx, int index_stride, long long n, int slo
   if (nullptr == idx) return nullptr;
   if (is_device_ptr(idx)) return idx;
   const size_t bytes = (size_t)(n - 1) * index_stride + sizeof(int);
-  void* d = scratch(slot, bytes);
-  if (nullptr == d || 0 != h2d(d, idx, bytes)) { *ok = false; return nullptr; }
+  (void)slot;
+  void* const d = index_upload(idx, bytes); // pinned ring + asynchronous copy: the call does not wait for the GPU
+  if (nullptr == d) { *ok = false; return nullptr; }
   return static_cast<const int*>(d);
 }
 
@@ -133,8 +134,10 @@ int batch_execute(SmmBatch s, libxsmm_blasint index_base, libxsmm_blasint index_
       s.ia = device_indexes(sa, index_stride, n, 0, &ok);
       s.ib = device_indexes(sb, index_stride, n, 1, &ok);
       s.ic = device_indexes(sc, index_stride, n, 2, &ok);
-      if (!ok || 0 != choose_sync(s, nosync)) return EXIT_FAILURE;
-      return 0 == run_smm(s) ? EXIT_SUCCESS : EXIT_FAILURE;
+      if (!ok || 0 != choose_sync(s, nosync)) { index_upload_commit(); return EXIT_FAILURE; }
+      const int e = run_smm(s);
+      index_upload_commit();
+      return 0 == e ? EXIT_SUCCESS : EXIT_FAILURE;
     }
     // host operands (an unchanged CPU caller): stage the touched element ranges over PCIe
     if (is_device_ptr(sa) || is_device_ptr(sb) || is_device_ptr(sc)) {
@@ -157,8 +160,10 @@ int batch_execute(SmmBatch s, libxsmm_blasint index_base, libxsmm_blasint index_
     s.ia = device_indexes(sa, index_stride, n, 0, &ok);
     s.ib = device_indexes(sb, index_stride, n, 1, &ok);
     s.ic = device_indexes(sc, index_stride, n, 2, &ok);
-    if (!ok || 0 != choose_sync(s, nosync)) return EXIT_FAILURE;
-    if (0 != run_smm(s)) return EXIT_FAILURE;
+    if (!ok || 0 != choose_sync(s, nosync)) { index_upload_commit(); return EXIT_FAILURE; }
+    const int e = run_smm(s);
+    index_upload_commit();
+    if (0 != e) return EXIT_FAILURE;
     return 0 == d2h(hc, dc, ec * ts) ? EXIT_SUCCESS : EXIT_FAILURE;
   }
   // ---------------- arrays of pointers ----------------
@@ -455,7 +460,9 @@ LIBXSMM_API int libxsmm_mmbatch_kernel(libxsmm_xmmfunction kernel, libxsmm_blasi
       fprintf(stderr, "LIBXSMM-AMD ERROR: batches of low-precision products need operands the GPU can reach (libxsmm_malloc or device memory)\n");
       return EXIT_FAILURE;
     }
-    if (0 != lowp_launch(s)) return EXIT_FAILURE;
+    const int le = lowp_launch(s);
+    index_upload_commit();
+    if (0 != le) return EXIT_FAILURE;
     if (ADDR_INDEX == s.mode) settle(a, b, c);
     else (void)stream_sync();
     return EXIT_SUCCESS;

@@ -138,6 +138,8 @@ bool is_device_ptr(const void* p);
 bool is_host_visible(const void* p);      // pinned host or managed memory (processed in place, but the CPU reads it directly)
 void settle(const void* p0, const void* p1 = nullptr, const void* p2 = nullptr); // wait for the stream if an operand is host-visible
 int flag_slot_set(int* slot, int equal_pairs, int decreasing_pairs); // the verdict without a check kernel (0: ok)
+void* index_upload(const void* host_array, size_t bytes); // async copy of a host index array to the device (nullptr: failed)
+void index_upload_commit();                                // after the launches that read uploaded arrays were queued
 int* flag_slot();                         // device int[4] for one batch call's C-ordering verdict (nullptr: out of memory)
 void* dev_alloc(size_t bytes);
 void dev_free(void* p);

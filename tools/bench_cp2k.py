@@ -3,7 +3,7 @@
 shape, every u consecutive products of a group accumulating into one C block (samples/cp2k/cp2k.cpp:155,328-360).
 One libxsmm_gemm_batch call (index arrays) per shape group, all on the engine's stream.
 
-usage: python3 tools/bench_cp2k.py [products=524288] [reps=7] [omp=0]   (omp=1: libxsmm_gemm_batch_omp, order of the sums relaxed)
+usage: python3 tools/bench_cp2k.py [products=524288] [reps=7] [omp=0] [host_idx=0]   (omp=1: libxsmm_gemm_batch_omp, order of the sums relaxed)
 Algorithmic bytes (the reference's bwsize, cp2k.cpp:156): sum over products 8*(M*K+K*N) + sum over C blocks 2*8*M*N."""
 import importlib
 import math
@@ -19,6 +19,7 @@ L = xs.lib()
 products = int(sys.argv[1]) if len(sys.argv) > 1 else 524288
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 7
 OMP = bool(int(sys.argv[3])) if len(sys.argv) > 3 else False
+HOST_IDX = bool(int(sys.argv[4])) if len(sys.argv) > 4 else False  # index arrays in host memory, as an unchanged caller has them
 torch.cuda.set_device(0)
 g = torch.Generator(device="cuda"); g.manual_seed(1)
 L.libxsmm_amd_set_mfma(0)
@@ -36,6 +37,8 @@ for gi, (m, n, k) in enumerate(shapes):
     c = torch.zeros(nc * m * n, device="cuda", dtype=torch.float64)
     idx = torch.arange(s, device="cuda", dtype=torch.int64)
     ia = (idx * (m * k)).to(torch.int32); ib = (idx * (k * n)).to(torch.int32); ic = ((idx // u) * (m * n)).to(torch.int32)
+    if HOST_IDX:
+        ia, ib, ic = (x.cpu().numpy() for x in (ia, ib, ic))
     groups.append((m, n, k, s, a, b, c, ia, ib, ic))
     tot_bytes += s * 8.0 * (m * k + k * n) + nc * 16.0 * m * n
     tot_flops += 2.0 * m * n * k * s

@@ -24,8 +24,12 @@ template<int G> __device__ __forceinline__ void unit_sync()
 template<typename T, int TM, int TN, int TGM, int TGN, bool GENERAL>
 __global__ __launch_bounds__(256)
 void smm_generic_kernel(DevAddr ad, int M, int N, int K, int lda, int ldb, int ldc, int flags, int sync_arg,
-                        long long batch, int KC, int kshift, T alpha, T beta)
+                        long long batch_arg, int KC, int kshift, T alpha, T beta, int tiles_m, int tiles_n)
 {
+  // tiles_m * tiles_n > 1 (independent C only): a unit is one MP x NP tile of one item -- a single large product
+  // (libxsmm_?gemm, a relinked BLAS caller) spreads over the chip instead of running on one work-group
+  const int tiles = tiles_m * tiles_n;
+  const long long batch = batch_arg * tiles;
   int sync = sync_arg;
   if (SYNC_DEVICE == sync_arg) { // how C blocks repeat was established on the device (c_order_kernel, same stream)
     sync = (0 != ad.flags[1]) ? SYNC_ATOMIC : ((0 != ad.flags[0]) ? SYNC_RUNS : SYNC_NONE);
@@ -57,15 +61,19 @@ void smm_generic_kernel(DevAddr ad, int M, int N, int K, int lda, int ldb, int l
   const bool sliced = (SYNC_RUNS == sync);
   const long long per = sliced ? ((batch + nunits - 1) / nunits) : 1;
   const long long lo = sliced ? unit * per : unit, hi = sliced ? ((lo + per < batch) ? lo + per : batch) : batch, step = sliced ? 1 : nunits;
-  for (long long item = lo; item < hi; item += step) {
+  for (long long work = lo; work < hi; work += step) {
+    const long long item = (1 < tiles) ? work / tiles : work;
+    const int tile = (1 < tiles) ? (int)(work - item * tiles) : 0;
+    const int m_first = (1 < tiles) ? (tile % tiles_m) * MP : 0, m_last = (1 < tiles) ? m_first + MP : M;
+    const int n_first = (1 < tiles) ? (tile / tiles_m) * NP : 0, n_last = (1 < tiles) ? n_first + NP : N;
     T* const pc = addr_c<T>(ad, item);
     long long count = 1;
     if (SYNC_RUNS == sync) { // only the head of a run of equal C works; it walks the run in batch order
       if (0 < item && addr_c<T>(ad, item - 1) == pc) continue;
       while (item + count < batch && addr_c<T>(ad, item + count) == pc) ++count;
     }
-    for (int m0 = 0; m0 < M; m0 += MP) {
-      for (int n0 = 0; n0 < N; n0 += NP) {
+    for (int m0 = m_first; m0 < M && m0 < m_last; m0 += MP) {
+      for (int n0 = n_first; n0 < N && n0 < n_last; n0 += NP) {
         T acc[TM][TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -200,13 +208,16 @@ int launch_generic_t(const SmmBatch& s, hipStream_t stream)
   const size_t smem = slot_elems * sizeof(T) * PPB;
   int kshift = 0;
   while ((1 << kshift) < KC && (1 << kshift) < G) ++kshift; // lanes along k when staging B
-  const long long units = s.batch;
+  // independent C operands and more than one tile per item: tiles are units of their own
+  int tiles_m = 1, tiles_n = 1;
+  if (SYNC_NONE == s.sync && (s.m > MP || s.n > NP)) { tiles_m = (s.m + MP - 1) / MP; tiles_n = (s.n + NP - 1) / NP; }
+  const long long units = s.batch * tiles_m * tiles_n;
   long long blocks = (units + PPB - 1) / PPB;
   const long long maxblocks = 256LL * 16; // 256 CUs, enough resident groups; units stride over the batch
   if (blocks > maxblocks) blocks = maxblocks;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL((smm_generic_kernel<T, TM, TM, TGM, TGM, GENERAL>), dim3((unsigned)blocks), dim3(256), smem, stream,
-    make_addr(s), s.m, s.n, s.k, s.lda, s.ldb, s.ldc, s.flags, s.sync, s.batch, KC, kshift, (T)s.alpha, (T)s.beta);
+    make_addr(s), s.m, s.n, s.k, s.lda, s.ldb, s.ldc, s.flags, s.sync, s.batch, KC, kshift, (T)s.alpha, (T)s.beta, tiles_m, tiles_n);
   return (int)hipGetLastError();
 }
 

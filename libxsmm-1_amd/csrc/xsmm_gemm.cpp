@@ -191,14 +191,16 @@ int batch_execute(SmmBatch s, libxsmm_blasint index_base, libxsmm_blasint index_
     for (size_t i = 0; i < na; ++i) ta[i] = *reinterpret_cast<const void* const*>(pa + da * (long long)i);
     for (size_t i = 0; i < nb; ++i) tb[i] = *reinterpret_cast<const void* const*>(pb + db * (long long)i);
     for (size_t i = 0; i < nc; ++i) tc[i] = *reinterpret_cast<void* const*>(pc + dc * (long long)i);
-    void* const xa = scratch(0, na * sizeof(void*)); void* const xb = scratch(1, nb * sizeof(void*)); void* const xc = scratch(2, nc * sizeof(void*));
-    if (nullptr == xa || nullptr == xb || nullptr == xc) return EXIT_FAILURE;
-    if (0 != h2d(xa, ta.data(), na * sizeof(void*)) || 0 != h2d(xb, tb.data(), nb * sizeof(void*)) || 0 != h2d(xc, tc.data(), nc * sizeof(void*))) return EXIT_FAILURE;
-    if (0 != stream_sync()) return EXIT_FAILURE; // the temporaries go out of scope
+    // (pinned ring + asynchronous copies: the temporaries are copied before this returns, the call does not wait for the GPU)
+    void* const xa = index_upload(ta.data(), na * sizeof(void*)); void* const xb = index_upload(tb.data(), nb * sizeof(void*));
+    void* const xc = index_upload(tc.data(), nc * sizeof(void*));
+    if (nullptr == xa || nullptr == xb || nullptr == xc) { index_upload_commit(); return EXIT_FAILURE; }
     s.a = xa; s.b = xb; s.c = xc;
     s.sa = (0 != da ? (long long)sizeof(void*) : 0); s.sb = (0 != db ? (long long)sizeof(void*) : 0); s.sc = (0 != dc ? (long long)sizeof(void*) : 0);
-    if (0 != choose_sync(s, nosync)) return EXIT_FAILURE;
-    return 0 == run_smm(s) ? EXIT_SUCCESS : EXIT_FAILURE;
+    if (0 != choose_sync(s, nosync)) { index_upload_commit(); return EXIT_FAILURE; }
+    const int e = run_smm(s);
+    index_upload_commit();
+    return 0 == e ? EXIT_SUCCESS : EXIT_FAILURE;
   }
   // host matrices behind host pointer arrays: pack every operand into a dense device buffer, keep aliasing of C
   {

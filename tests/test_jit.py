@@ -337,3 +337,40 @@ def test_batch_calls_are_graph_capturable(xs, orc, torch_gpu):
         for _ in range(3):  # warm-up + two replays (capturing itself does not execute)
             assert 0 == orc.gemm_batch_idx(orc.FMA, 0, m, n, k, m, k, m, a, b, ref, 0, sa, sb, sc, batch)
         assert np.array_equal(dev[2].cpu().numpy(), ref)
+
+
+@pytest.mark.gpu
+def test_code_objects_are_cached_on_disk(xs, torch_gpu, tmp_path):
+    """hiprtc output is kept under $LIBXSMM_AMD_CACHE: a second process loads the code objects instead of compiling (same
+    results); LIBXSMM_AMD_CACHE=0 writes nothing."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = (
+        "import importlib, sys, numpy as np, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "xs = importlib.import_module('libxsmm-1_amd'); L = xs.lib(); L.libxsmm_amd_set_mfma(0)\n"
+        "m, n, k, batch = 13, 9, 11, 20000\n"
+        "g = torch.Generator(device='cuda'); g.manual_seed(3)\n"
+        "a = torch.rand(batch*m*k, device='cuda', dtype=torch.float64, generator=g); b = torch.rand(batch*k*n, device='cuda', dtype=torch.float64, generator=g)\n"
+        "c = torch.zeros(batch*m*n, device='cuda', dtype=torch.float64)\n"
+        "blob, d = xs.descriptor(xs.F64, m, n, k)\n"
+        "assert 0 == L.libxsmm_amd_gemm_batch_strided(d, xs.dptr(a), xs.dptr(b), xs.dptr(c), m*k, k*n, m*n, batch)\n"
+        "torch.cuda.synchronize(); assert 'jit' in xs.last_kernel(), xs.last_kernel()\n"
+        "print('%%.17g' %% float(c.sum().item()))\n" % root)
+    cache = tmp_path / "cache"
+    outs = []
+    for _ in range(2):
+        env = dict(os.environ, LIBXSMM_AMD_CACHE=str(cache))
+        res = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, env=env, timeout=300)
+        assert res.returncode == 0, res.stderr[-2000:]
+        outs.append(res.stdout.strip().splitlines()[-1])
+        files = sorted(os.listdir(cache))
+        assert files and all(f.endswith(".hsaco") for f in files), files
+    assert outs[0] == outs[1]
+    nfiles = len(os.listdir(cache))
+    off = tmp_path / "off"
+    env = dict(os.environ, LIBXSMM_AMD_CACHE="0", HOME=str(off))
+    res = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, env=env, timeout=300)
+    assert res.returncode == 0 and res.stdout.strip().splitlines()[-1] == outs[0]
+    assert len(os.listdir(cache)) == nfiles and not (off / ".cache" / "libxsmm-amd").exists()

@@ -54,8 +54,14 @@ constexpr int M = XM, N = XN, K = XK;
 // one contiguous piece (wider, fully used loads even when a single item is a few hundred bytes or not 16-byte sized), the
 // 64 lanes split into XPACK groups with one item each. The host passes strides and the count in units of XPACK items.
 constexpr int G = XPACK;
-constexpr int AE1 = M * K, BE1 = K * N, CE1 = M * N;               // elements per operand of one item (tight leading dimensions)
-constexpr int AE = G * AE1, BE = G * BE1, CE = G * CE1;            // ... of what a wave handles at a time
+// Leading dimensions as in memory. LDS always holds the tight images; only the transfers know about the gaps: an operand is
+// fetched as the one span of memory it occupies (gaps included), elements in the gaps are dropped on the way into LDS and
+// never written on the way out.
+constexpr int LDA = XLDA, LDB = XLDB, LDC = XLDC;
+constexpr bool TIGHT_A = (LDA == M), TIGHT_B = (LDB == (XTRANSB ? N : K)), TIGHT_C = (LDC == M);
+constexpr int AE1 = LDA * (K - 1) + M, BE1 = XTRANSB ? (LDB * (K - 1) + N) : (LDB * (N - 1) + K), CE1 = LDC * (N - 1) + M; // span of one item's operand
+constexpr int CT1 = M * N;                                          // tight C image of one item
+constexpr int AE = G * AE1, BE = G * BE1, CE = G * CE1;            // ... of what a wave handles at a time (G > 1: tight only)
 constexpr int TS = (int)sizeof(T);
 #if (2 == XRUNS)
 // work-group form: 4 waves share one product; a wave owns NQ = ceil(N/4) columns of C, its 64 lanes are 16 (along m) x 4
@@ -74,7 +80,7 @@ constexpr int NPAD = TGN * TN;
 // widest access (in elements) that every item of a strided batch is aligned for
 constexpr int vw(int elems) { return (0 == (elems * TS) % 16) ? 16 / TS : ((0 == (elems * TS) % 8) ? 8 / TS : 1); }
 // XSCALAR: index/pointer batches guarantee element alignment only
-constexpr int VA = XSCALAR ? 1 : vw(AE), VB = XSCALAR ? 1 : vw(BE), VC = XSCALAR ? 1 : vw(CE);
+constexpr int VA = XSCALAR ? 1 : vw(AE), VB = XSCALAR ? 1 : vw(BE), VC = (XSCALAR || !TIGHT_C) ? 1 : vw(CE);
 constexpr int NLA = (AE + UT * VA - 1) / (UT * VA), NLB = (BE + UT * VB - 1) / (UT * VB), NLC = (CE + UT * VC - 1) / (UT * VC);
 // LDS strides: A as [k][M] (lanes with equal ty read the same words, lanes with different tx adjacent ones);
 // B as [n][KP] (TRANS_B: [k][N]) with KP chosen so that the column groups of one instruction fall into different banks
@@ -83,7 +89,7 @@ constexpr int KP = pick_kp();
 constexpr int AS1 = ((K * M + TGM * TM + 3) / 4) * 4;                 // per item
 constexpr int BS1 = XTRANSB ? (((K * N + NPAD + 3) / 4) * 4) : ((NPAD * KP + 3) / 4) * 4;
 constexpr int AS_SIZE = G * AS1, BS_SIZE = G * BS1;
-constexpr int CS_SIZE = ((CE + 3) / 4) * 4;                          // the items' C blocks stay contiguous (flat copy in and out)
+constexpr int CS_SIZE = ((G * CT1 + 3) / 4) * 4;                     // the items' C blocks stay contiguous (flat copy in and out)
 constexpr int WAVE_LDS = AS_SIZE + BS_SIZE + CS_SIZE;                // elements (wave form)
 constexpr int WG_BUF = AS_SIZE + BS_SIZE;                            // elements per operand buffer (work-group form)
 constexpr int WG_NBUF = (2 * WG_BUF * TS <= 65536) ? 2 : 1;          // double-buffered when 64 KiB allow
@@ -117,7 +123,13 @@ __device__ __forceinline__ void park_ab(T* As, T* Bs, int lane, const T (&ra)[NL
 #pragma unroll
   for (int j = 0; j < NLA; ++j) {
 #pragma unroll
-    for (int q = 0; q < VA; ++q) { const int e = (UT * j + lane) * VA + q; if (e < AE) As[(1 == G) ? e : ((e / AE1) * AS1 + (e % AE1))] = ra[j][q]; }
+    for (int q = 0; q < VA; ++q) {
+      const int e = (UT * j + lane) * VA + q;
+      if (e < AE) {
+        if (TIGHT_A) As[(1 == G) ? e : ((e / AE1) * AS1 + (e % AE1))] = ra[j][q];
+        else { const int k = e / LDA, m = e - k * LDA; if (m < M) As[k * M + m] = ra[j][q]; }
+      }
+    }
   }
 #pragma unroll
   for (int j = 0; j < NLB; ++j) {
@@ -126,7 +138,8 @@ __device__ __forceinline__ void park_ab(T* As, T* Bs, int lane, const T (&ra)[NL
       const int e = (UT * j + lane) * VB + q;
       if (e < BE) {
         const int g = (1 == G) ? 0 : (e / BE1), r = (1 == G) ? e : (e % BE1);
-        if (XTRANSB) Bs[g * BS1 + r] = rb[j][q]; else Bs[g * BS1 + (r / K) * KP + (r % K)] = rb[j][q];
+        if (XTRANSB) { if (TIGHT_B) Bs[g * BS1 + r] = rb[j][q]; else { const int k = r / LDB, n = r - k * LDB; if (n < N) Bs[k * N + n] = rb[j][q]; } }
+        else { const int n = r / LDB, k = r - n * LDB; if (k < K) Bs[g * BS1 + n * KP + k] = rb[j][q]; }
       }
     }
   }
@@ -136,7 +149,10 @@ __device__ __forceinline__ void park_c(T* Cs, int lane, const T (&rc)[NLC][VC])
 #pragma unroll
   for (int j = 0; j < NLC; ++j) {
 #pragma unroll
-    for (int q = 0; q < VC; ++q) { const int e = (64 * j + lane) * VC + q; if (e < CE) Cs[e] = rc[j][q]; }
+    for (int q = 0; q < VC; ++q) {
+      const int e = (64 * j + lane) * VC + q;
+      if (e < CE) { if (TIGHT_C) Cs[e] = rc[j][q]; else { const int n = e / LDC, m = e - n * LDC; if (m < M) Cs[n * M + m] = rc[j][q]; } }
+    }
   }
 }
 // acc(i,j) = fma(A(m,k), B(k,n), acc(i,j)) for k ascending: the reference's per-element chain
@@ -227,7 +243,8 @@ __device__ __forceinline__ void store_c(T* Cs, T* pc, int lane, int tx, int ty, 
   for (int j = 0; j < NLC; ++j) {
     const int e = (64 * j + lane) * VC;
     if (e < CE) {
-      if constexpr (1 == VC) __builtin_nontemporal_store(Cs[e], (XGLOBAL T*)pc + e);
+      if constexpr (!TIGHT_C) { const int n = e / LDC, m = e - n * LDC; if (m < M) __builtin_nontemporal_store(Cs[n * M + m], (XGLOBAL T*)pc + e); } // (VC == 1)
+      else if constexpr (1 == VC) __builtin_nontemporal_store(Cs[e], (XGLOBAL T*)pc + e);
       else __builtin_nontemporal_store(*reinterpret_cast<const typename Vec<VC>::type*>(Cs + e), reinterpret_cast<XGLOBAL typename Vec<VC>::type*>((XGLOBAL T*)pc + e));
     }
   }
@@ -247,7 +264,7 @@ __device__ __forceinline__ void atomic_c(T* Cs, T* pc, int lane, int tx, int ty,
     for (int j = 0; j < TN; ++j) { const int m = tx * TM + i, n = ty * TN + j; if (m < M && n < N) Cs[n * M + m] = acc[i][j]; }
   }
   wave_lds_sync();
-  for (int e = lane; e < M * N; e += 64) xatomic_add(pc + e, Cs[e]);
+  for (int e = lane; e < M * N; e += 64) xatomic_add(pc + (TIGHT_C ? e : ((e / M) * LDC + (e % M))), Cs[e]);
   wave_lds_sync();
 }
 #endif
@@ -386,7 +403,7 @@ extern "C" __global__ __launch_bounds__(256) void xsmm_smm_op(DevAddr ad, long l
 #pragma unroll
               for (int ii = 0; ii < TM; ++ii) {
 #pragma unroll
-                for (int j = 0; j < TN; ++j) { const int m = tx * TM + ii, n = ncol0 + j; if (m < M && ty * TN + j < NQ && n < N) ((XGLOBAL T*)pc)[n * M + m] = acc[ii][j]; }
+                for (int j = 0; j < TN; ++j) { const int m = tx * TM + ii, n = ncol0 + j; if (m < M && ty * TN + j < NQ && n < N) ((XGLOBAL T*)pc)[n * LDC + m] = acc[ii][j]; }
               }
             }
             pc = resolve<T>(ad.c, ad.ic, ad.sc, ad, i);
@@ -395,7 +412,7 @@ extern "C" __global__ __launch_bounds__(256) void xsmm_smm_op(DevAddr ad, long l
 #pragma unroll
               for (int j = 0; j < TN; ++j) {
                 const int m = tx * TM + ii, n = ncol0 + j;
-                acc[ii][j] = (!XBETA0 && m < M && ty * TN + j < NQ && n < N) ? ((const XGLOBAL T*)pc)[n * M + m] : (T)0;
+                acc[ii][j] = (!XBETA0 && m < M && ty * TN + j < NQ && n < N) ? ((const XGLOBAL T*)pc)[n * LDC + m] : (T)0;
               }
             }
           }
@@ -417,7 +434,7 @@ extern "C" __global__ __launch_bounds__(256) void xsmm_smm_op(DevAddr ad, long l
 #pragma unroll
     for (int ii = 0; ii < TM; ++ii) {
 #pragma unroll
-      for (int j = 0; j < TN; ++j) { const int m = tx * TM + ii, n = ncol0 + j; if (m < M && ty * TN + j < NQ && n < N) ((XGLOBAL T*)pc)[n * M + m] = acc[ii][j]; }
+      for (int j = 0; j < TN; ++j) { const int m = tx * TM + ii, n = ncol0 + j; if (m < M && ty * TN + j < NQ && n < N) ((XGLOBAL T*)pc)[n * LDC + m] = acc[ii][j]; }
     }
   }
 }
@@ -519,9 +536,9 @@ extern "C" __global__ __launch_bounds__(64 * XWAVES) void xsmm_smm_op(DevAddr ad
     }
     wave_lds_sync();
     T acc[TM][TN];
-    acc_from_c(Cs + grp * CE1, tx, ty, acc, XBETA0);
+    acc_from_c(Cs + grp * CT1, tx, ty, acc, XBETA0);
     multiply(As + grp * AS1, Bs + grp * BS1, tx, ty * TN, acc);
-    store_c(Cs, pc, lane, tx, ty, acc, Cs + grp * CE1);
+    store_c(Cs, pc, lane, tx, ty, acc, Cs + grp * CT1);
   }
 #endif
 }
@@ -677,10 +694,11 @@ extern "C" __global__ __launch_bounds__(256) void xsmm_smm_op(DevAddr ad, long l
 )XSMM";
 
 struct SmmKey {
-  int typesize, m, n, k, flags, variant;
-  bool operator==(const SmmKey& o) const { return typesize == o.typesize && m == o.m && n == o.n && k == o.k && flags == o.flags && variant == o.variant; }
+  int typesize, m, n, k, flags, variant, lda, ldb, ldc;
+  bool operator==(const SmmKey& o) const { return typesize == o.typesize && m == o.m && n == o.n && k == o.k && flags == o.flags && variant == o.variant
+                                               && lda == o.lda && ldb == o.ldb && ldc == o.ldc; }
 };
-struct SmmKeyHash { size_t operator()(const SmmKey& k) const { return (size_t)((((k.m * 131 + k.n) * 131 + k.k) * 8 + k.flags * 2 + (k.typesize == 8)) * 64 + k.variant); } };
+struct SmmKeyHash { size_t operator()(const SmmKey& k) const { return (size_t)(((((k.m * 131 + k.n) * 131 + k.k) * 8 + k.flags * 2 + (k.typesize == 8)) * 64 + k.variant) * 31 + k.lda * 7 + k.ldb * 3 + k.ldc); } };
 
 std::mutex g_smm_lock;
 std::unordered_map<SmmKey, JitKernel*, SmmKeyHash> g_smm_cache; // nullptr value: compilation failed, do not retry
@@ -722,8 +740,11 @@ static int smm_jit_depth(int typesize, int m, int n, int k, int variant)
 static int smm_jit_pack_of(int variant) { return 1 << ((variant >> 8) & 7); }
 static int smm_jit_pack_bits(int pack) { int l = 0; while ((1 << l) < pack) ++l; return l << 8; }
 
-std::string gen_smm_source(int typesize, int m, int n, int k, int flags, int variant)
+std::string gen_smm_source(int typesize, int m, int n, int k, int flags, int variant, int lda, int ldb, int ldc)
 {
+  if (lda <= 0) lda = m;
+  if (ldb <= 0) ldb = (flags & LIBXSMM_GEMM_FLAG_TRANS_B) ? n : k;
+  if (ldc <= 0) ldc = m;
   std::string s = "// generated by libxsmm-amd (dense SMM kernel, shape baked in)\n";
   s += std::string("typedef ") + (8 == typesize ? "double" : "float") + " T;\n";
   s += "#define XM " + std::to_string(m) + "\n#define XN " + std::to_string(n) + "\n#define XK " + std::to_string(k) + "\n";
@@ -735,6 +756,7 @@ std::string gen_smm_source(int typesize, int m, int n, int k, int flags, int var
     return s;
   }
   const int pack = smm_jit_pack_of(variant);
+  s += "#define XLDA " + std::to_string(lda) + "\n#define XLDB " + std::to_string(ldb) + "\n#define XLDC " + std::to_string(ldc) + "\n"; // leading dimensions in memory
   s += "#define XPACK " + std::to_string(pack) + "\n";   // items per wave pass (streaming form of tight strided batches)
   s += "#define XWAVES " + std::to_string(smm_jit_waves(typesize, m, n, k, flags, pack)) + "\n";
   s += std::string("#define XSCALAR ") + ((variant & SMM_JIT_SCALAR) ? "1" : "0") + "\n"; // element-wide loads/stores only
@@ -779,8 +801,14 @@ bool smm_jit_eligible(const SmmBatch& s)
   if (!enabled || 0 != s.general || SYNC_ATOMIC == s.sync) return false;
   if (SYNC_NONE != s.sync && 0 != (s.flags & LIBXSMM_GEMM_FLAG_BETA_0)) return false; // (never chosen: beta == 0 needs no care)
   if (SYNC_DEVICE == s.sync && 0 == s.c_atomics) return false;  // the generic kernel's compare-and-swap path serves mapped host memory
-  if (s.lda != s.m || s.ldc != s.m) return false;
-  if (0 != (s.flags & LIBXSMM_GEMM_FLAG_TRANS_B) ? (s.ldb != s.n) : (s.ldb != s.k)) return false;
+  const bool tight = (s.lda == s.m && s.ldc == s.m && (0 != (s.flags & LIBXSMM_GEMM_FLAG_TRANS_B) ? (s.ldb == s.n) : (s.ldb == s.k)));
+  if (!tight) { // leading dimensions with gaps: the wave forms fetch an operand's whole span -- as long as the gaps stay moderate
+    if (s.m > 32 || s.n > 32) return false;
+    const long long span = (long long)s.lda * (s.k - 1) + s.m + (long long)s.ldb * ((0 != (s.flags & LIBXSMM_GEMM_FLAG_TRANS_B) ? s.k : s.n) - 1)
+                         + (0 != (s.flags & LIBXSMM_GEMM_FLAG_TRANS_B) ? s.n : s.k) + (long long)s.ldc * (s.n - 1) + s.m;
+    const long long used = (long long)s.m * s.k + (long long)s.k * s.n + (long long)s.m * s.n;
+    if (2 * used < span || span * s.typesize > 40960) return false;
+  }
   if (s.m > 32 || s.n > 32) { // work-group-per-item form: 16x16 threads x (<=4x4) tile, K chunked; independent C only
     if (s.m > 64 || s.n > 64 || s.k > 1024) return false;
     if (SYNC_NONE != s.sync && !(0 < s.uniform_run && 0 == s.batch % s.uniform_run)) return false; // shared C only as runs of a known, uniform length
@@ -827,7 +855,7 @@ static JitKernel* smm_jit_get(const SmmKey& key)
   auto it = g_smm_cache.find(key);
   if (it != g_smm_cache.end()) return it->second;
   std::string log;
-  JitKernel* const k = jit_compile(gen_smm_source(key.typesize, key.m, key.n, key.k, key.flags, key.variant), "xsmm_smm_op", &log);
+  JitKernel* const k = jit_compile(gen_smm_source(key.typesize, key.m, key.n, key.k, key.flags, key.variant, key.lda, key.ldb, key.ldc), "xsmm_smm_op", &log);
   if (nullptr == k && 0 != verbosity()) fprintf(stderr, "LIBXSMM WARNING: SMM JIT failed (%s); using the pre-compiled kernel\n", log.c_str());
   g_smm_cache.emplace(key, k);
   return k;
@@ -836,7 +864,7 @@ static JitKernel* smm_jit_get(const SmmKey& key)
 // one launch of one flavour; -1 when the kernel is not available
 static int smm_jit_launch_variant(const SmmBatch& s, int variant, void* stream)
 {
-  const SmmKey key = { s.typesize, s.m, s.n, s.k, s.flags & (LIBXSMM_GEMM_FLAG_BETA_0 | LIBXSMM_GEMM_FLAG_TRANS_B), variant };
+  const SmmKey key = { s.typesize, s.m, s.n, s.k, s.flags & (LIBXSMM_GEMM_FLAG_BETA_0 | LIBXSMM_GEMM_FLAG_TRANS_B), variant, s.lda, s.ldb, s.ldc };
   JitKernel* const k = smm_jit_get(key);
   if (nullptr == k) return -1;
   struct { const char* a; const char* b; char* c; const char* ia; const char* ib; const char* ic; long long sa, sb, sc; int index_base, index_stride, mode; const int* flags; } ad;
@@ -943,7 +971,8 @@ int launch_smm_jit(const SmmBatch& s, void* stream, const char** name)
   }
   static const int wg_env = []() { const char* e = getenv("XSMM_SMMJIT_WG"); return (nullptr != e && 0 != *e) ? atoi(e) : 1; }(); // developer knob
   // the work-group form pays off once a product's operands are large (measured on CP2K stacks: 32^3 f64 yes, 23^3 no)
-  const bool wg_fits = (0 != wg_env && smm_jit_wg_buf(s.typesize, s.m, s.n, s.k, s.flags) <= 65536
+  const bool tight = (s.lda == s.m && s.ldc == s.m && (0 != (s.flags & LIBXSMM_GEMM_FLAG_TRANS_B) ? (s.ldb == s.n) : (s.ldb == s.k)));
+  const bool wg_fits = (tight && 0 != wg_env && smm_jit_wg_buf(s.typesize, s.m, s.n, s.k, s.flags) <= 65536
                      && (2 == wg_env || (size_t)s.typesize * ((size_t)s.m * s.k + (size_t)s.k * s.n) >= 12288));
   if (SYNC_RUNS == s.sync) { // the host knows that C repeats in runs (one C for the whole batch, batch-reduce): long runs
     if (wg_fits) {

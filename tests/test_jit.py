@@ -374,3 +374,48 @@ def test_code_objects_are_cached_on_disk(xs, torch_gpu, tmp_path):
     res = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, env=env, timeout=300)
     assert res.returncode == 0 and res.stdout.strip().splitlines()[-1] == outs[0]
     assert len(os.listdir(cache)) == nfiles and not (off / ".cache" / "libxsmm-amd").exists()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("shape", [(23, 23, 23, 24, 24, 24), (13, 9, 17, 16, 20, 13), (32, 32, 32, 40, 32, 48), (5, 7, 3, 8, 8, 8), (16, 31, 35, 16, 35, 24)])
+def test_jit_leading_dimensions_with_gaps(xs, orc, torch_gpu, dtype, shape):
+    """Leading dimensions larger than the matrix (tests/gemm.c rows such as m=10,lda=22 / ldc=12..20): the specialised wave forms
+    fetch an operand's span and drop the gaps; rows between m and ldc are never written (checked with NaN-poisoned and
+    sentinel-filled gaps), beta = 0 and 1, TRANS_B, strided batches and index batches with runs."""
+    torch = torch_gpu
+    m, n, k, lda, ldb, ldc = shape
+    batch = 333
+    rng = np.random.default_rng(m * 5 + n * 3 + k + lda)
+    prec = xs.F64 if dtype == np.float64 else xs.F32
+    asz, csz = lda * k, ldc * n
+    with _JitForced(xs):
+        for beta, transb in ((1.0, False), (0.0, False), (1.0, True)):
+            ldb_ = max(ldb, n) if transb else ldb
+            bsz = ldb_ * (k if transb else n)
+            a = rng.uniform(-1, 1, batch * asz).astype(dtype); b = rng.uniform(-1, 1, batch * bsz).astype(dtype)
+            c = rng.uniform(-1, 1, batch * csz).astype(dtype)
+            if beta == 0.0:
+                cc = c.reshape(batch, n, ldc); cc[:, :, :m] = np.nan  # C itself is not read; the gaps keep their values
+            flags = (xs.FLAG_TRANS_B if transb else 0)
+            oflags = (orc.FLAG_BETA_0 if beta == 0.0 else 0) | (orc.FLAG_TRANS_B if transb else 0)
+            ref = c.copy()
+            orc.gemm_batch_strided(orc.FMA, oflags, m, n, k, lda, ldb_, ldc, a, b, ref, asz, bsz, csz, batch, 4)
+            da, db, dc = (torch.from_numpy(x).cuda() for x in (a, b, c))
+            blob, d = xs.descriptor(prec, m, n, k, lda, ldb_, ldc, 1.0, beta, flags, 0)
+            assert 0 == xs.lib().libxsmm_amd_gemm_batch_strided(d, xs.dptr(da), xs.dptr(db), xs.dptr(dc), asz, bsz, csz, batch)
+            torch.cuda.synchronize()
+            assert "_jit_shape" in xs.last_kernel(), xs.last_kernel()
+            assert np.array_equal(dc.cpu().numpy().view(np.uint8), ref.view(np.uint8)), (beta, transb)
+        # index batch with runs of equal C (sorted block ids), gaps in C
+        nc = 17
+        a = rng.uniform(-1, 1, batch * asz).astype(dtype); b = rng.uniform(-1, 1, batch * ldb * n).astype(dtype); c = rng.uniform(-1, 1, nc * csz).astype(dtype)
+        cidx = np.sort(rng.integers(0, nc, batch))
+        sa = (rng.permutation(batch) * asz).astype(np.int32); sb = (np.arange(batch) * ldb * n).astype(np.int32); sc = (cidx * csz).astype(np.int32)
+        ref = c.copy()
+        assert 0 == orc.gemm_batch_idx(orc.FMA, 0, m, n, k, lda, ldb, ldc, a, b, ref, 0, sa, sb, sc, batch)
+        da, db, dc = (torch.from_numpy(x).cuda() for x in (a, b, c))
+        xs.gemm_batch(prec, "N", "N", m, n, k, 1.0, da, lda, db, ldb, 1.0, dc, ldc, 0, 4, sa, sb, sc, batch)
+        torch.cuda.synchronize()
+        assert "_jit_shape_runs" in xs.last_kernel(), xs.last_kernel()
+        assert np.array_equal(dc.cpu().numpy().view(np.uint8), ref.view(np.uint8))

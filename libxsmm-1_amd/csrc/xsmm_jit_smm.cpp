@@ -803,13 +803,13 @@ bool smm_jit_eligible(const SmmBatch& s)
   if (SYNC_DEVICE == s.sync && 0 == s.c_atomics) return false;  // the generic kernel's compare-and-swap path serves mapped host memory
   const bool tight = (s.lda == s.m && s.ldc == s.m && (0 != (s.flags & LIBXSMM_GEMM_FLAG_TRANS_B) ? (s.ldb == s.n) : (s.ldb == s.k)));
   if (!tight) { // leading dimensions with gaps: the wave forms fetch an operand's whole span -- as long as the gaps stay moderate
-    if (s.m > 32 || s.n > 32) return false;
+    if (s.m > 32 || s.n > 32 || s.k > 64) return false;
     const long long span = (long long)s.lda * (s.k - 1) + s.m + (long long)s.ldb * ((0 != (s.flags & LIBXSMM_GEMM_FLAG_TRANS_B) ? s.k : s.n) - 1)
                          + (0 != (s.flags & LIBXSMM_GEMM_FLAG_TRANS_B) ? s.n : s.k) + (long long)s.ldc * (s.n - 1) + s.m;
     const long long used = (long long)s.m * s.k + (long long)s.k * s.n + (long long)s.m * s.n;
     if (2 * used < span || span * s.typesize > 40960) return false;
   }
-  if (s.m > 32 || s.n > 32) { // work-group-per-item form: 16x16 threads x (<=4x4) tile, K chunked; independent C only
+  if (s.m > 32 || s.n > 32 || s.k > 64) { // work-group-per-item form: 16x16 threads x (<=4x4) tile, K chunked (also small M, N with a long K)
     if (s.m > 64 || s.n > 64 || s.k > 1024) return false;
     if (SYNC_NONE != s.sync && !(0 < s.uniform_run && 0 == s.batch % s.uniform_run)) return false; // shared C only as runs of a known, uniform length
     if (0 == smm_jit_big_kc(s.typesize, s.m, s.n, s.k, s.flags)) return false;
@@ -948,7 +948,7 @@ int launch_smm_jit(const SmmBatch& s, void* stream, const char** name)
 { // returns -1 when no specialised kernel is available
   const int width = smm_jit_width_variant(s);
   const bool f64 = (8 == s.typesize);
-  if (s.m > 32 || s.n > 32) { // (eligibility made sure of SYNC_NONE, or of runs of a uniform length)
+  if (s.m > 32 || s.n > 32 || s.k > 64) { // (eligibility made sure of SYNC_NONE, or of runs of a uniform length)
     *name = f64 ? "smm_f64_jit_shape_wg" : "smm_f32_jit_shape_wg";
     return smm_jit_launch_variant(s, SMM_JIT_BIG, stream);
   }

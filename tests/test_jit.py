@@ -260,7 +260,7 @@ def test_jit_stands_down_for_out_of_order_repeats(xs, orc, torch_gpu, dtype):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
-@pytest.mark.parametrize("shape", [(64, 64, 64), (48, 40, 56), (33, 64, 17), (64, 33, 100), (40, 8, 5)])
+@pytest.mark.parametrize("shape", [(64, 64, 64), (48, 40, 56), (33, 64, 17), (64, 33, 100), (40, 8, 5), (23, 23, 70), (8, 8, 200)])
 def test_jit_work_group_form_for_shapes_up_to_64(xs, orc, torch_gpu, dtype, shape):
     """32 < M or N <= 64: one work-group per item, K in chunks through LDS (any K): the k-ascending fma chain continues
     across the chunks, so the result is still the oracle's, bit for bit. Strided and index batches, beta 0/1, TRANS_B."""

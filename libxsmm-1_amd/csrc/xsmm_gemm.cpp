@@ -10,6 +10,7 @@
 
 #include <cstring>
 #include <mutex>
+#include <unordered_map>
 #include <vector>
 
 namespace xsmm {
@@ -209,32 +210,37 @@ int batch_execute(SmmBatch s, libxsmm_blasint index_base, libxsmm_blasint index_
     char* const bb = static_cast<char*>(scratch(4, nb * szb * ts));
     if (nullptr == ba || nullptr == bb) return EXIT_FAILURE;
     std::vector<const void*> ta(na), tb(nb); std::vector<void*> tc(nc);
+    // one host image and one copy per operand array (a copy per matrix is a driver call per matrix: 10^5 recorded calls took seconds)
+    std::vector<char> ha(na * sza * ts), hb(nb * szb * ts), hc;
     for (size_t i = 0; i < na; ++i) {
-      const void* src = *reinterpret_cast<const void* const*>(pa + da * (long long)i);
-      if (0 != h2d(ba + i * sza * ts, src, sza * ts)) return EXIT_FAILURE;
+      memcpy(ha.data() + i * sza * ts, *reinterpret_cast<const void* const*>(pa + da * (long long)i), sza * ts);
       ta[i] = ba + i * sza * ts;
     }
     for (size_t i = 0; i < nb; ++i) {
-      const void* src = *reinterpret_cast<const void* const*>(pb + db * (long long)i);
-      if (0 != h2d(bb + i * szb * ts, src, szb * ts)) return EXIT_FAILURE;
+      memcpy(hb.data() + i * szb * ts, *reinterpret_cast<const void* const*>(pb + db * (long long)i), szb * ts);
       tb[i] = bb + i * szb * ts;
     }
+    if (0 != h2d(ba, ha.data(), ha.size()) || 0 != h2d(bb, hb.data(), hb.size())) return EXIT_FAILURE;
     // distinct host C matrices get distinct device copies; repeated pointers share one
     std::vector<void*> uniq; std::vector<size_t> slot_of(nc);
     {
-      std::vector<std::pair<void*, size_t>> seen; seen.reserve(nc);
+      std::unordered_map<void*, size_t> seen; seen.reserve(nc);
       for (size_t i = 0; i < nc; ++i) {
-        void* hc = *reinterpret_cast<void* const*>(pc + dc * (long long)i);
-        size_t j = 0;
-        // consecutive duplicates are the common case (CP2K stacks); fall back to a linear search otherwise
-        if (!uniq.empty() && uniq.back() == hc) j = uniq.size() - 1;
-        else { for (j = 0; j < uniq.size(); ++j) if (uniq[j] == hc) break; if (j == uniq.size()) uniq.push_back(hc); }
+        void* const hp = *reinterpret_cast<void* const*>(pc + dc * (long long)i);
+        size_t j;
+        if (!uniq.empty() && uniq.back() == hp) j = uniq.size() - 1; // consecutive duplicates are the common case (CP2K stacks)
+        else {
+          const auto it = seen.find(hp);
+          if (it != seen.end()) j = it->second; else { j = uniq.size(); uniq.push_back(hp); seen.emplace(hp, j); }
+        }
         slot_of[i] = j;
       }
     }
     char* const bc = static_cast<char*>(scratch(5, uniq.size() * szc * ts));
     if (nullptr == bc) return EXIT_FAILURE;
-    for (size_t j = 0; j < uniq.size(); ++j) if (0 != h2d(bc + j * szc * ts, uniq[j], szc * ts)) return EXIT_FAILURE;
+    hc.resize(uniq.size() * szc * ts);
+    for (size_t j = 0; j < uniq.size(); ++j) memcpy(hc.data() + j * szc * ts, uniq[j], szc * ts);
+    if (0 != h2d(bc, hc.data(), hc.size())) return EXIT_FAILURE;
     for (size_t i = 0; i < nc; ++i) tc[i] = bc + slot_of[i] * szc * ts;
     void* const xa = scratch(0, na * sizeof(void*)); void* const xb = scratch(1, nb * sizeof(void*)); void* const xc = scratch(2, nc * sizeof(void*));
     if (nullptr == xa || nullptr == xb || nullptr == xc) return EXIT_FAILURE;
@@ -244,7 +250,8 @@ int batch_execute(SmmBatch s, libxsmm_blasint index_base, libxsmm_blasint index_
     s.sa = (0 != da ? (long long)sizeof(void*) : 0); s.sb = (0 != db ? (long long)sizeof(void*) : 0); s.sc = (0 != dc ? (long long)sizeof(void*) : 0);
     if (0 != choose_sync(s, nosync)) return EXIT_FAILURE;
     if (0 != run_smm(s)) return EXIT_FAILURE;
-    for (size_t j = 0; j < uniq.size(); ++j) if (0 != d2h(uniq[j], bc + j * szc * ts, szc * ts)) return EXIT_FAILURE;
+    if (0 != d2h(hc.data(), bc, hc.size())) return EXIT_FAILURE; // (synchronises)
+    for (size_t j = 0; j < uniq.size(); ++j) memcpy(uniq[j], hc.data() + j * szc * ts, szc * ts);
     return EXIT_SUCCESS;
   }
 }

@@ -382,6 +382,7 @@ void call_kernel(Kernel* k, const void* a, const void* b, void* c, const void* x
     if (0 == count) return;
     const libxsmm_blasint ptrsize = (libxsmm_blasint)sizeof(void*);
     SmmBatch s = from_descriptor(k->desc);
+    s.jit_always = 1; // a batch-reduce kernel is dispatched once and called over and over with short batches
     void* cc = c;
     // one run: every product lands in the same C (stride_c == NULL), accumulated in batch order
     (void)batch_execute(s, 0, 0, &ptrsize, &ptrsize, nullptr, a, b, &cc, 0, (long long)count, false);

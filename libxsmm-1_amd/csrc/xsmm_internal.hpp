@@ -61,6 +61,7 @@ struct SmmBatch {
   int lowp; float scf;      // low-precision kernels (kernels/smm_lowp.hip): 1 i16->i32, 2 i16->f32 (times scf), 3 bf16->f32, 4 bf16->bf16; 0: f32/f64
   int shared_across_calls;  // != 0: other tasks of the same libxsmm_mmbatch update the same C blocks concurrently (ntasks > 1): atomics
   long long uniform_run;    // > 0: the batch consists of runs of exactly this many consecutive items per C (blocked GEMM work lists)
+  int jit_always;           // != 0: specialise with hiprtc whatever the batch size (batch-reduce kernels: short batches, called over and over)
   int relaxed;              // != 0: sums into a shared C may be formed in any order (the caller's reference path is multi-threaded)
   int use_mfma;             // policy bit (0: scalar FMA only)
   // general form used by the BLAS-like fallback (libxsmm_?gemm with alpha/beta/trans outside the SMM domain)

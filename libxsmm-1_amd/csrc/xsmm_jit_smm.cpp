@@ -820,7 +820,7 @@ bool smm_jit_eligible(const SmmBatch& s)
   }
   const char* const env_min = getenv("LIBXSMM_AMD_JIT_MINBATCH");
   const long long min_batch = (nullptr != env_min && 0 != *env_min) ? atoll(env_min) : 16384LL;
-  if (s.batch < min_batch) return false;                                      // compile time must be worth it
+  if (s.batch < min_batch && 0 == s.jit_always) return false;                 // compile time must be worth it
   return true;
 }
 

@@ -130,3 +130,52 @@ def test_spmdm_batches_fuzz(xs, orc, torch_gpu, chunk):
             assert np.array_equal(out.view(np.uint8), ref.view(np.uint8)), (chunk, it, M, N, K, batch, density, ta, tb, tc, beta, xs.last_kernel())
     finally:
         L.libxsmm_amd_set_mfma(old_mfma)
+
+
+@pytest.mark.parametrize("chunk", range(2))
+def test_fsspmdm_fuzz(xs, orc, torch_gpu, chunk):
+    """fsspmdm over random operators (shape, density, lda), precisions, beta, panel counts; the specialised operator kernel and
+    (LIBXSMM_AMD_JIT=0) the generic CSR kernel -- both follow the oracle's per-element chain bit for bit (rows without
+    non-zeros excluded for beta = 0: the reference's two code paths disagree there)."""
+    import ctypes as C
+    torch = torch_gpu
+    L = xs.lib()
+    rng = np.random.default_rng(4242 + chunk)
+    old_jit = os.environ.get("LIBXSMM_AMD_JIT")
+    try:
+        for it in range(10):
+            dtype = np.float64 if rng.random() < 0.5 else np.float32
+            M, K = int(rng.integers(1, 60)), int(rng.integers(1, 60))
+            N = 16 * int(rng.integers(1, 8)); panels = int(rng.integers(1, 9))
+            lda = K + int(rng.integers(0, 4))
+            density = float(rng.choice([0.05, 0.15, 0.5, 1.0]))
+            beta = float(rng.choice([0.0, 1.0]))
+            if rng.random() < 0.3:
+                os.environ["LIBXSMM_AMD_JIT"] = "0"
+            else:
+                os.environ.pop("LIBXSMM_AMD_JIT", None)
+            A = np.zeros((M, lda), dtype=dtype)
+            A[:, :K] = np.where(rng.random((M, K)) < density, rng.uniform(-1, 1, (M, K)), 0.0)
+            ntot = N * panels
+            B = rng.uniform(-1, 1, (K, ntot)).astype(dtype); Cin = rng.uniform(-1, 1, (M, ntot)).astype(dtype)
+            ref = Cin.copy()
+            h = orc.Fsspmdm(A, M, N, K, lda, ntot, ntot, 1.0, beta, have_avx512=False)  # dense fallback: the plain chain for every row
+            for p in range(panels):
+                h.execute(B.reshape(-1)[p * N:], ref.reshape(-1)[p * N:])
+            h.close()
+            create = L.libxsmm_dfsspmdm_create if dtype == np.float64 else L.libxsmm_sfsspmdm_create
+            execb = L.libxsmm_amd_dfsspmdm_execute_batch if dtype == np.float64 else L.libxsmm_amd_sfsspmdm_execute_batch
+            destroy = L.libxsmm_dfsspmdm_destroy if dtype == np.float64 else L.libxsmm_sfsspmdm_destroy
+            hd = create(M, N, K, lda, ntot, ntot, 1.0, beta, xs.dptr(A))
+            assert hd
+            dB, dC = torch.from_numpy(B).cuda(), torch.from_numpy(Cin).cuda()
+            assert 0 == execb(hd, xs.dptr(dB), xs.dptr(dC), panels)
+            torch.cuda.synchronize()
+            out = dC.cpu().numpy()
+            destroy(hd)
+            assert np.array_equal(out.view(np.uint8), ref.view(np.uint8)), (chunk, it, dtype.__name__, M, N, K, lda, density, beta, panels, xs.last_kernel())
+    finally:
+        if old_jit is None:
+            os.environ.pop("LIBXSMM_AMD_JIT", None)
+        else:
+            os.environ["LIBXSMM_AMD_JIT"] = old_jit

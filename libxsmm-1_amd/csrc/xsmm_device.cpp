@@ -2,6 +2,8 @@
 // scratch memory and staging copies. Host-only translation unit (HIP runtime API, no kernels).
 #include "xsmm_internal.hpp"
 
+#include <dlfcn.h>
+
 #include <hip/hip_runtime_api.h>
 
 #include <atomic>
@@ -98,6 +100,54 @@ void note_launch(const char* name)
 {
   tl_last_kernel = (nullptr != name ? name : "");
   g_launches.fetch_add(1, std::memory_order_relaxed);
+}
+
+// ---- library GEMM for products far outside the SMM domain ---------------------------------------------------------------
+// libxsmm_?gemm (and a BLAS caller relinked with --wrap) may be handed one large product. The reference passes those to
+// the BLAS it is linked with (src/libxsmm_gemm.c: libxsmm_blas_?gemm); here rocBLAS plays that role: loaded on first use
+// (no link-time dependency), one handle per calling thread, the engine's stream. -1: not available (the tiled generic
+// kernel serves the call then).
+namespace {
+struct RocBlas {
+  void* lib = nullptr;
+  int (*create)(void**) = nullptr;
+  int (*set_stream)(void*, hipStream_t) = nullptr;
+  int (*dgemm)(void*, int, int, int, int, int, const double*, const double*, int, const double*, int, const double*, double*, int) = nullptr;
+  int (*sgemm)(void*, int, int, int, int, int, const float*, const float*, int, const float*, int, const float*, float*, int) = nullptr;
+  bool ok = false;
+};
+RocBlas& rocblas()
+{
+  static RocBlas r;
+  static std::once_flag once;
+  std::call_once(once, []() {
+    const char* const env = getenv("LIBXSMM_AMD_BLAS"); // 0: never use the library GEMM
+    if (nullptr != env && 0 == atoi(env)) return;
+    r.lib = dlopen("librocblas.so", RTLD_NOW | RTLD_LOCAL);
+    if (nullptr == r.lib) r.lib = dlopen("/opt/rocm/lib/librocblas.so", RTLD_NOW | RTLD_LOCAL);
+    if (nullptr == r.lib) return;
+    r.create = reinterpret_cast<decltype(r.create)>(dlsym(r.lib, "rocblas_create_handle"));
+    r.set_stream = reinterpret_cast<decltype(r.set_stream)>(dlsym(r.lib, "rocblas_set_stream"));
+    r.dgemm = reinterpret_cast<decltype(r.dgemm)>(dlsym(r.lib, "rocblas_dgemm"));
+    r.sgemm = reinterpret_cast<decltype(r.sgemm)>(dlsym(r.lib, "rocblas_sgemm"));
+    r.ok = (nullptr != r.create && nullptr != r.set_stream && nullptr != r.dgemm && nullptr != r.sgemm);
+  });
+  return r;
+}
+thread_local void* tl_rocblas_handle = nullptr;
+}
+
+int library_gemm(int typesize, int transa, int transb, int m, int n, int k, double alpha, const void* a, int lda,
+                 const void* b, int ldb, double beta, void* c, int ldc)
+{
+  RocBlas& r = rocblas();
+  if (!r.ok) return -1;
+  if (nullptr == tl_rocblas_handle && 0 != r.create(&tl_rocblas_handle)) { tl_rocblas_handle = nullptr; return -1; }
+  if (0 != r.set_stream(tl_rocblas_handle, (hipStream_t)device().stream)) return -1;
+  const int ta = transa ? 112 : 111, tb = transb ? 112 : 111; // rocblas_operation_transpose / _none
+  if (8 == typesize) return 0 == r.dgemm(tl_rocblas_handle, ta, tb, m, n, k, &alpha, static_cast<const double*>(a), lda, static_cast<const double*>(b), ldb, &beta, static_cast<double*>(c), ldc) ? 0 : 1;
+  const float al = (float)alpha, be = (float)beta;
+  return 0 == r.sgemm(tl_rocblas_handle, ta, tb, m, n, k, &al, static_cast<const float*>(a), lda, static_cast<const float*>(b), ldb, &be, static_cast<float*>(c), ldc) ? 0 : 1;
 }
 
 int* flag_slot()

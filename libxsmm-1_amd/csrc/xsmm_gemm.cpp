@@ -273,6 +273,13 @@ int single_execute(SmmBatch s, const void* a, const void* b, void* c)
   if (!device_ready()) { fail_no_device("a dispatched SMM kernel"); return EXIT_FAILURE; }
   s.mode = ADDR_STRIDED; s.batch = 1; s.sa = s.sb = s.sc = 0; s.sync = SYNC_NONE;
   if (is_device_ptr(a) && is_device_ptr(b) && is_device_ptr(c)) {
+    // one product far outside the SMM domain: the plain library GEMM (what the reference hands to its BLAS)
+    if (2.0 * s.m * s.n * s.k >= 2.0 * 256 * 256 * 256 && s.m >= 64 && s.n >= 64 && s.k >= 32) {
+      const double al = (0 != s.general ? s.alpha : 1.0), be = (0 != s.general ? s.beta : ((s.flags & LIBXSMM_GEMM_FLAG_BETA_0) ? 0.0 : 1.0));
+      const int e = library_gemm(s.typesize, 0 != s.general && 0 != (s.flags & LIBXSMM_GEMM_FLAG_TRANS_A), 0 != (s.flags & LIBXSMM_GEMM_FLAG_TRANS_B),
+        s.m, s.n, s.k, al, a, s.lda, b, s.ldb, be, c, s.ldc);
+      if (0 == e) { note_launch(8 == s.typesize ? "rocblas_dgemm" : "rocblas_sgemm"); settle(a, b, c); return EXIT_SUCCESS; }
+    }
     s.a = a; s.b = b; s.c = c;
     return 0 == run_smm(s) ? EXIT_SUCCESS : EXIT_FAILURE;
   }

@@ -141,6 +141,8 @@ void settle(const void* p0, const void* p1 = nullptr, const void* p2 = nullptr);
 int flag_slot_set(int* slot, int equal_pairs, int decreasing_pairs); // the verdict without a check kernel (0: ok)
 void* index_upload(const void* host_array, size_t bytes); // async copy of a host index array to the device (nullptr: failed)
 void index_upload_commit();                                // after the launches that read uploaded arrays were queued
+int library_gemm(int typesize, int transa, int transb, int m, int n, int k, double alpha, const void* a, int lda,
+                 const void* b, int ldb, double beta, void* c, int ldc); // rocBLAS on the engine's stream; -1: not available
 int* flag_slot();                         // device int[4] for one batch call's C-ordering verdict (nullptr: out of memory)
 void* dev_alloc(size_t bytes);
 void dev_free(void* p);

@@ -11,10 +11,10 @@ timeout -k 10 300 bash tools/pmc_spmdm.sh
 # the callers and data formats either side of the hot path: blocked GEMM, one large GEMM, the per-block spmdm interface,
 # SOA kernels, the generic kernel next to the specialised ones, low-precision kernels
 (for a in "2048 32 f32" "2048 32 f64" "2048 64 f32" "2048 64 f64" "4096 32 f32"; do timeout -k 10 100 python3 tools/bench_blocked.py $a 2>&1 | tail -n 1; done;
- timeout -k 10 200 python3 tools/bench_gemm_single.py 256 1024 2048 4096;
+ timeout -k 10 200 python3 tools/bench_gemm_single.py 256 1024 2048 4096; LIBXSMM_AMD_BLAS=0 timeout -k 10 200 python3 tools/bench_gemm_single.py 2048;
  timeout -k 10 200 python3 tools/bench_spmdm_api.py 2048 0.15 2;
  timeout -k 10 200 python3 tools/bench_soa.py;
  timeout -k 10 200 python3 tools/bench_generic.py;
  timeout -k 10 200 python3 tools/bench_dense.py lowp 5;
- timeout -k 10 100 python3 tools/bench_host.py) 2>&1 | grep -v amdgpu.ids > gpurun_out/other_paths.txt
+ timeout -k 10 100 python3 tools/bench_host.py; timeout -k 10 100 python3 tools/bench_misc.py | tail -n 1; timeout -k 10 100 python3 tools/bench_autobatch.py | tail -n 1) 2>&1 | grep -v amdgpu.ids > gpurun_out/other_paths.txt
 tail -n 4 gpurun_out/dense_shapes.txt gpurun_out/sparse_phases.txt gpurun_out/cp2k_stacks.txt

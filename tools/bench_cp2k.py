@@ -84,6 +84,27 @@ for nstreams in (0, 4, 8, 27):
     t = sorted(times)[len(times) // 2]
     print("cp2k stacks%s, %2d streams: kernels %s  median %.3f ms (min %.3f)  %.0f GB/s (%.1f%% of 8 TB/s)  %.0f GFLOP/s"
           % (" (omp entry)" if OMP else "", nstreams if nstreams else 1, sorted(names), t, min(times), tot_bytes / t / 1e6, tot_bytes / t / 1e6 / 80.0, tot_flops / t / 1e6))
+# the 27 calls captured once in a HIP graph and replayed (device index arrays only: no host work is left in the replay)
+if not HOST_IDX:
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        L.libxsmm_amd_set_stream(C.c_void_p(side.cuda_stream))
+        one_pass([])  # warm-up on the capture stream
+        side.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            one_pass([])
+        times = []
+        for it in range(reps + 2):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(side); graph.replay(); e1.record(side); side.synchronize()
+            if it >= 2:
+                times.append(e0.elapsed_time(e1))
+    L.libxsmm_amd_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    t = sorted(times)[len(times) // 2]
+    print("cp2k stacks%s, hipGraph replay of the 27 calls: median %.3f ms (min %.3f)  %.0f GB/s (%.1f%% of 8 TB/s)"
+          % (" (omp entry)" if OMP else "", t, min(times), tot_bytes / t / 1e6, tot_bytes / t / 1e6 / 80.0))
 # per-group breakdown (each group alone, synchronised)
 for (m, n, k, s, a, b, c, ia, ib, ic) in groups[::13]:
     ts = []

@@ -109,6 +109,7 @@ enum { SMM_JIT_SCALAR = 1, SMM_JIT_RUNS = 2, SMM_JIT_WGRUNS = 4, SMM_JIT_HASWG =
 std::string gen_smm_source(int typesize, int m, int n, int k, int flags, int variant, int lda = 0, int ldb = 0, int ldc = 0); // (0: tight)
 bool smm_jit_eligible(const SmmBatch& s);
 int launch_smm_jit(const SmmBatch& s, void* stream, const char** name); // -1: not available
+int launch_smm_jit_lowp(const SmmBatch& s, void* stream, const char** name); // 16-bit inputs on the specialised streaming form; -1: not applicable
 
 // spmdm batch
 struct SpmdmGeom {

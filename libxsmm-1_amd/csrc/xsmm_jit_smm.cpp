@@ -42,6 +42,7 @@ template<typename P> __device__ __forceinline__ P* resolve(const char* base, con
 }
 __device__ __forceinline__ float xfma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ double xfma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ int xfma(int a, int b, int c) { return (int)((unsigned)a * (unsigned)b + (unsigned)c); } // i16 x i16 + i32, wrapping (a 32-bit multiply: quarter rate; the sign-extended 16-bit spelling compiled to something four times slower still)
 __device__ __forceinline__ void wave_lds_sync()
 {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -155,6 +156,53 @@ __device__ __forceinline__ void park_c(T* Cs, int lane, const T (&rc)[NLC][VC])
     }
   }
 }
+#if XLOWP
+// 16-bit inputs (XLOWP 1: i16, T = int; 3: bf16, T = float), stored as the reference's low-precision kernels expect them: A in
+// pairs of k (a[(k/2)*M*2 + m*2 + k%2]), B column-major -- both are sequences of 32-bit k pairs. They are fetched as such and
+// widened on the way into LDS, where the images are the ones of the fp32 / int kernels; everything after that is shared.
+constexpr int PA = (M * K) / 2, PB = (K * N) / 2;                  // k pairs per operand (K is even)
+constexpr int VPA = (0 == (PA * 4) % 16 && !XSCALAR) ? 4 : 1, VPB = (0 == (PB * 4) % 16 && !XSCALAR) ? 4 : 1;
+constexpr int NPA = (PA + 64 * VPA - 1) / (64 * VPA), NPB = (PB + 64 * VPB - 1) / (64 * VPB);
+template<int V> struct PVec { typedef unsigned type __attribute__((ext_vector_type(V))); };
+template<> struct PVec<1> { typedef unsigned type; };
+template<int V, int NL, int E> __device__ __forceinline__ void load_pairs(const unsigned* p, int lane, unsigned (&r)[NL][V])
+{
+  const XGLOBAL unsigned* const g = (const XGLOBAL unsigned*)p;
+#pragma unroll
+  for (int j = 0; j < NL; ++j) {
+    const int e = (64 * j + lane) * V;
+    if (e < E) {
+      if constexpr (1 == V) r[j][0] = __builtin_nontemporal_load(g + e);
+      else {
+        const typename PVec<V>::type v = __builtin_nontemporal_load(reinterpret_cast<const XGLOBAL typename PVec<V>::type*>(g + e));
+#pragma unroll
+        for (int q = 0; q < V; ++q) r[j][q] = v[q];
+      }
+    }
+  }
+}
+__device__ __forceinline__ T widen_lo(unsigned p) { return (1 == XLOWP) ? (T)(int)(short)(p & 0xFFFFu) : (T)__uint_as_float(p << 16); }
+__device__ __forceinline__ T widen_hi(unsigned p) { return (1 == XLOWP) ? (T)(int)(short)(p >> 16) : (T)__uint_as_float(p & 0xFFFF0000u); }
+__device__ __forceinline__ void park_pairs(T* As, T* Bs, int lane, const unsigned (&ra)[NPA][VPA], const unsigned (&rb)[NPB][VPB])
+{
+#pragma unroll
+  for (int j = 0; j < NPA; ++j) {
+#pragma unroll
+    for (int q = 0; q < VPA; ++q) {
+      const int e = (64 * j + lane) * VPA + q;
+      if (e < PA) { const int sp = e / M, m = e - sp * M; As[(2 * sp) * M + m] = widen_lo(ra[j][q]); As[(2 * sp + 1) * M + m] = widen_hi(ra[j][q]); }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NPB; ++j) {
+#pragma unroll
+    for (int q = 0; q < VPB; ++q) {
+      const int e = (64 * j + lane) * VPB + q;
+      if (e < PB) { const int n = e / (K / 2), sp = e - n * (K / 2); Bs[n * KP + 2 * sp] = widen_lo(rb[j][q]); Bs[n * KP + 2 * sp + 1] = widen_hi(rb[j][q]); }
+    }
+  }
+}
+#endif
 // acc(i,j) = fma(A(m,k), B(k,n), acc(i,j)) for k ascending: the reference's per-element chain
 __device__ __forceinline__ void multiply(const T* As, const T* Bs, int tx, int ncol0, T (&acc)[TM][TN])
 {
@@ -519,19 +567,34 @@ extern "C" __global__ __launch_bounds__(64 * XWAVES) void xsmm_smm_op(DevAddr ad
   }
 #else
   if (w >= batch) return;
+#if XLOWP
+  unsigned ra[NPA][VPA], rb[NPB][VPB]; T rc[NLC][VC];
+  load_pairs<VPA, NPA, PA>(resolve<const unsigned>(ad.a, ad.ia, ad.sa, ad, w), lane, ra);
+  load_pairs<VPB, NPB, PB>(resolve<const unsigned>(ad.b, ad.ib, ad.sb, ad, w), lane, rb);
+#else
   T ra[NLA][VA], rb[NLB][VB], rc[NLC][VC];
   load_flat<VA, NLA, AE>(resolve<const T>(ad.a, ad.ia, ad.sa, ad, w), lane, ra);
   load_flat<VB, NLB, BE>(resolve<const T>(ad.b, ad.ib, ad.sb, ad, w), lane, rb);
+#endif
   if (!XBETA0) load_flat<VC, NLC, CE>(resolve<const T>(ad.c, ad.ic, ad.sc, ad, w), lane, rc);
   for (long long item = w; item < batch; item += W) {
     T* const pc = resolve<T>(ad.c, ad.ic, ad.sc, ad, item);
+#if XLOWP
+    park_pairs(As, Bs, lane, ra, rb);
+#else
     park_ab(As, Bs, lane, ra, rb);
+#endif
     if (!XBETA0) park_c(Cs, lane, rc);
     // ---- next item's loads go out before this item's arithmetic
     const long long next = item + W;
     if (next < batch) {
+#if XLOWP
+      load_pairs<VPA, NPA, PA>(resolve<const unsigned>(ad.a, ad.ia, ad.sa, ad, next), lane, ra);
+      load_pairs<VPB, NPB, PB>(resolve<const unsigned>(ad.b, ad.ib, ad.sb, ad, next), lane, rb);
+#else
       load_flat<VA, NLA, AE>(resolve<const T>(ad.a, ad.ia, ad.sa, ad, next), lane, ra);
       load_flat<VB, NLB, BE>(resolve<const T>(ad.b, ad.ib, ad.sb, ad, next), lane, rb);
+#endif
       if (!XBETA0) load_flat<VC, NLC, CE>(resolve<const T>(ad.c, ad.ic, ad.sc, ad, next), lane, rc);
     }
     wave_lds_sync();
@@ -746,7 +809,9 @@ std::string gen_smm_source(int typesize, int m, int n, int k, int flags, int var
   if (ldb <= 0) ldb = (flags & LIBXSMM_GEMM_FLAG_TRANS_B) ? n : k;
   if (ldc <= 0) ldc = m;
   std::string s = "// generated by libxsmm-amd (dense SMM kernel, shape baked in)\n";
-  s += std::string("typedef ") + (8 == typesize ? "double" : "float") + " T;\n";
+  const int lowp = (variant >> 11) & 3; // 16-bit inputs: 1 = i16 -> i32, 3 = bf16 -> f32 (0: none)
+  s += std::string("typedef ") + (8 == typesize ? "double" : (1 == lowp ? "int" : "float")) + " T;\n";
+  s += "#define XLOWP " + std::to_string(lowp) + "\n";
   s += "#define XM " + std::to_string(m) + "\n#define XN " + std::to_string(n) + "\n#define XK " + std::to_string(k) + "\n";
   s += std::string("#define XBETA0 ") + ((flags & LIBXSMM_GEMM_FLAG_BETA_0) ? "1" : "0") + "\n";
   s += std::string("#define XTRANSB ") + ((flags & LIBXSMM_GEMM_FLAG_TRANS_B) ? "1" : "0") + "\n";
@@ -942,6 +1007,27 @@ static int smm_jit_pack(const SmmBatch& s, int width)
   while (1 < pack && ((size_t)pack * ((size_t)s.m * s.k + (size_t)s.k * s.n + (size_t)s.m * s.n) * s.typesize > 24576
                    || 0 == smm_jit_waves(s.typesize, s.m, s.n, s.k, s.flags, pack))) pack /= 2;
   return pack;
+}
+
+// 16-bit inputs (args.lowp 1: i16 -> i32, 3: bf16 -> f32): strided batches of tightly packed items with independent C go through
+// the streaming form of the specialised kernel (the inputs are widened on their way into LDS). -1: not applicable.
+int launch_smm_jit_lowp(const SmmBatch& s, void* stream, const char** name)
+{
+  const char* const env_jit = getenv("LIBXSMM_AMD_JIT");
+  if (nullptr != env_jit && 0 == atoi(env_jit)) return -1;
+  if ((1 != s.lowp && 3 != s.lowp) || ADDR_STRIDED != s.mode || 0 != (s.flags & LIBXSMM_GEMM_FLAG_TRANS_B)) return -1;
+  if (s.m > 32 || s.n > 32 || s.k > 64 || 0 != (s.k & 1) || s.lda != s.m || s.ldb != s.k || s.ldc != s.m) return -1;
+  if (s.sa != (long long)s.m * s.k || s.sb != (long long)s.k * s.n || s.sc != (long long)s.m * s.n) return -1;
+  const char* const env_min = getenv("LIBXSMM_AMD_JIT_MINBATCH");
+  if (s.batch < ((nullptr != env_min && 0 != *env_min) ? atoll(env_min) : 16384LL)) return -1;
+  if (0 == smm_jit_waves(4, s.m, s.n, s.k, s.flags)) return -1;
+  SmmBatch j = s;
+  j.typesize = 4; j.lowp = 0; j.sync = SYNC_NONE;
+  j.sa = s.sa / 2; j.sb = s.sb / 2; // the kernel addresses A and B as 32-bit k pairs
+  const uintptr_t bits = reinterpret_cast<uintptr_t>(s.a) | reinterpret_cast<uintptr_t>(s.b) | reinterpret_cast<uintptr_t>(s.c);
+  const int variant = ((0 == (bits & 15)) ? 0 : SMM_JIT_SCALAR) | (s.lowp << 11);
+  *name = (1 == s.lowp) ? "smm_i16i32_jit_shape_lowp" : "smm_bf16f32_jit_shape_lowp";
+  return smm_jit_launch_variant(j, variant, stream);
 }
 
 int launch_smm_jit(const SmmBatch& s, void* stream, const char** name)

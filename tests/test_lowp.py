@@ -197,8 +197,24 @@ def test_low_precision_batches(xs, orc, torch_gpu, kind):
     ip, op = {0: (xs.I16, xs.I32), 2: (xs.BF16, xs.F32), 3: (xs.BF16, xs.BF16)}[kind]
     desc = L.libxsmm_gemm_descriptor_dinit2(C.byref(blob), ip, op, m, n, k, m, k, m, 1.0, 1.0, 0, 0)
     assert desc and len(ident) == batch
-    assert 0 == L.libxsmm_amd_gemm_batch_strided(C.c_void_p(desc), da.data_ptr(), db.data_ptr(), dc.data_ptr(), m * k, k * n, m * n, batch)
-    torch.cuda.synchronize()
+    import os
+    for forced in (False, True):  # forced: the hiprtc-specialised streaming form (normally for batches >= 16384), i16 -> i32 and bf16 -> f32
+        old_env = os.environ.get("LIBXSMM_AMD_JIT_MINBATCH")
+        if forced:
+            os.environ["LIBXSMM_AMD_JIT_MINBATCH"] = "1"
+        try:
+            dc.copy_(torch.from_numpy(c.view(np.int16) if kind == 3 else c))
+            assert 0 == L.libxsmm_amd_gemm_batch_strided(C.c_void_p(desc), da.data_ptr(), db.data_ptr(), dc.data_ptr(), m * k, k * n, m * n, batch)
+            torch.cuda.synchronize()
+        finally:
+            if old_env is None:
+                os.environ.pop("LIBXSMM_AMD_JIT_MINBATCH", None)
+            else:
+                os.environ["LIBXSMM_AMD_JIT_MINBATCH"] = old_env
+        assert xs.last_kernel().endswith("_lowp")
+        assert ("_jit_shape_lowp" in xs.last_kernel()) == (forced and kind in (0, 2)), xs.last_kernel()
+        got = dc.cpu().numpy(); got = got.view(np.uint16) if kind == 3 else got
+        assert np.array_equal(got.view(np.uint8), ref2.view(np.uint8)), (kind, forced)
     assert xs.last_kernel().endswith("_lowp")
     got = dc.cpu().numpy(); got = got.view(np.uint16) if kind == 3 else got
     assert np.array_equal(got.view(np.uint8), ref2.view(np.uint8))

@@ -42,7 +42,8 @@ template<typename P> __device__ __forceinline__ P* resolve(const char* base, con
 }
 __device__ __forceinline__ float xfma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ double xfma(double a, double b, double c) { return __builtin_fma(a, b, c); }
-__device__ __forceinline__ int xfma(int a, int b, int c) { return (int)((unsigned)a * (unsigned)b + (unsigned)c); } // i16 x i16 + i32, wrapping (a 32-bit multiply: quarter rate; the sign-extended 16-bit spelling compiled to something four times slower still)
+typedef short xs16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int xfma(int a, int b, int c) { return __builtin_amdgcn_sdot2(__builtin_bit_cast(xs16x2, a), __builtin_bit_cast(xs16x2, b), c, false); } // two i16 x i16 products + i32, wrapping
 __device__ __forceinline__ void wave_lds_sync()
 {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -50,7 +51,8 @@ __device__ __forceinline__ void wave_lds_sync()
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-constexpr int M = XM, N = XN, K = XK;
+// (XLOWP 1, i16 -> i32: the k pairs stay packed -- one v_dot2_i32_i16 per pair -- so the kernel's k runs over pairs)
+constexpr int M = XM, N = XN, K = (1 == XLOWP) ? (XK / 2) : XK;
 // XPACK items that follow each other in memory (tight strided batches) are handled by a wave at a time: their operands are
 // one contiguous piece (wider, fully used loads even when a single item is a few hundred bytes or not 16-byte sized), the
 // 64 lanes split into XPACK groups with one item each. The host passes strides and the count in units of XPACK items.
@@ -160,7 +162,7 @@ __device__ __forceinline__ void park_c(T* Cs, int lane, const T (&rc)[NLC][VC])
 // 16-bit inputs (XLOWP 1: i16, T = int; 3: bf16, T = float), stored as the reference's low-precision kernels expect them: A in
 // pairs of k (a[(k/2)*M*2 + m*2 + k%2]), B column-major -- both are sequences of 32-bit k pairs. They are fetched as such and
 // widened on the way into LDS, where the images are the ones of the fp32 / int kernels; everything after that is shared.
-constexpr int PA = (M * K) / 2, PB = (K * N) / 2;                  // k pairs per operand (K is even)
+constexpr int PA = (M * XK) / 2, PB = (XK * N) / 2;                // k pairs per operand (XK is even)
 constexpr int VPA = (0 == (PA * 4) % 16 && !XSCALAR) ? 4 : 1, VPB = (0 == (PB * 4) % 16 && !XSCALAR) ? 4 : 1;
 constexpr int NPA = (PA + 64 * VPA - 1) / (64 * VPA), NPB = (PB + 64 * VPB - 1) / (64 * VPB);
 template<int V> struct PVec { typedef unsigned type __attribute__((ext_vector_type(V))); };
@@ -190,7 +192,11 @@ __device__ __forceinline__ void park_pairs(T* As, T* Bs, int lane, const unsigne
 #pragma unroll
     for (int q = 0; q < VPA; ++q) {
       const int e = (64 * j + lane) * VPA + q;
-      if (e < PA) { const int sp = e / M, m = e - sp * M; As[(2 * sp) * M + m] = widen_lo(ra[j][q]); As[(2 * sp + 1) * M + m] = widen_hi(ra[j][q]); }
+      if (e < PA) {
+        const int sp = e / M, m = e - sp * M;
+        if (1 == XLOWP) As[sp * M + m] = (T)ra[j][q]; // packed pair
+        else { As[(2 * sp) * M + m] = widen_lo(ra[j][q]); As[(2 * sp + 1) * M + m] = widen_hi(ra[j][q]); }
+      }
     }
   }
 #pragma unroll
@@ -198,7 +204,11 @@ __device__ __forceinline__ void park_pairs(T* As, T* Bs, int lane, const unsigne
 #pragma unroll
     for (int q = 0; q < VPB; ++q) {
       const int e = (64 * j + lane) * VPB + q;
-      if (e < PB) { const int n = e / (K / 2), sp = e - n * (K / 2); Bs[n * KP + 2 * sp] = widen_lo(rb[j][q]); Bs[n * KP + 2 * sp + 1] = widen_hi(rb[j][q]); }
+      if (e < PB) {
+        const int n = e / (XK / 2), sp = e - n * (XK / 2);
+        if (1 == XLOWP) Bs[n * KP + sp] = (T)rb[j][q];
+        else { Bs[n * KP + 2 * sp] = widen_lo(rb[j][q]); Bs[n * KP + 2 * sp + 1] = widen_hi(rb[j][q]); }
+      }
     }
   }
 }

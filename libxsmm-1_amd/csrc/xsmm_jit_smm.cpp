@@ -212,6 +212,50 @@ __device__ __forceinline__ void park_pairs(T* As, T* Bs, int lane, const unsigne
     }
   }
 }
+#if (2 == XLOWP)
+// bf16 -> bf16: C travels as 32-bit pairs of bf16 as well (M is a multiple of 16: a pair never straddles a column); the sums
+// are float, a result is the upper half of the float (truncation, as the reference's harness does)
+constexpr int PC = (M * N) / 2;
+constexpr int VPC = (0 == (PC * 4) % 16 && !XSCALAR) ? 4 : 1;
+constexpr int NPC = (PC + 64 * VPC - 1) / (64 * VPC);
+template<int V> __device__ __forceinline__ void store_pvec(const unsigned* v, XGLOBAL unsigned* dst)
+{
+  typename PVec<V>::type w;
+#pragma unroll
+  for (int q = 0; q < V; ++q) w[q] = v[q];
+  __builtin_nontemporal_store(w, reinterpret_cast<XGLOBAL typename PVec<V>::type*>(dst));
+}
+template<> __device__ __forceinline__ void store_pvec<1>(const unsigned* v, XGLOBAL unsigned* dst) { __builtin_nontemporal_store(v[0], dst); }
+__device__ __forceinline__ void park_c_pairs(T* Cs, int lane, const unsigned (&rc)[NPC][VPC])
+{
+#pragma unroll
+  for (int j = 0; j < NPC; ++j) {
+#pragma unroll
+    for (int q = 0; q < VPC; ++q) { const int e = (64 * j + lane) * VPC + q; if (e < PC) { Cs[2 * e] = widen_lo(rc[j][q]); Cs[2 * e + 1] = widen_hi(rc[j][q]); } }
+  }
+}
+__device__ __forceinline__ void store_c_pairs(T* Cs, unsigned* pc, int lane, int tx, int ty, const T (&acc)[TM][TN])
+{
+  wave_lds_sync();
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) { const int m = tx * TM + i, n = ty * TN + j; if (m < M && n < N) Cs[n * M + m] = acc[i][j]; }
+  }
+  wave_lds_sync();
+#pragma unroll
+  for (int j = 0; j < NPC; ++j) {
+    const int e = (64 * j + lane) * VPC;
+    if (e < PC) {
+      unsigned v[VPC];
+#pragma unroll
+      for (int q = 0; q < VPC; ++q) v[q] = (__float_as_uint(Cs[2 * (e + q)]) >> 16) | (__float_as_uint(Cs[2 * (e + q) + 1]) & 0xFFFF0000u);
+      store_pvec<VPC>(v, (XGLOBAL unsigned*)pc + e);
+    }
+  }
+  wave_lds_sync();
+}
+#endif
 #endif
 // acc(i,j) = fma(A(m,k), B(k,n), acc(i,j)) for k ascending: the reference's per-element chain
 __device__ __forceinline__ void multiply(const T* As, const T* Bs, int tx, int ncol0, T (&acc)[TM][TN])
@@ -578,7 +622,12 @@ extern "C" __global__ __launch_bounds__(64 * XWAVES) void xsmm_smm_op(DevAddr ad
 #else
   if (w >= batch) return;
 #if XLOWP
-  unsigned ra[NPA][VPA], rb[NPB][VPB]; T rc[NLC][VC];
+  unsigned ra[NPA][VPA], rb[NPB][VPB];
+#if (2 == XLOWP)
+  unsigned rc[NPC][VPC];
+#else
+  T rc[NLC][VC];
+#endif
   load_pairs<VPA, NPA, PA>(resolve<const unsigned>(ad.a, ad.ia, ad.sa, ad, w), lane, ra);
   load_pairs<VPB, NPB, PB>(resolve<const unsigned>(ad.b, ad.ib, ad.sb, ad, w), lane, rb);
 #else
@@ -586,15 +635,27 @@ extern "C" __global__ __launch_bounds__(64 * XWAVES) void xsmm_smm_op(DevAddr ad
   load_flat<VA, NLA, AE>(resolve<const T>(ad.a, ad.ia, ad.sa, ad, w), lane, ra);
   load_flat<VB, NLB, BE>(resolve<const T>(ad.b, ad.ib, ad.sb, ad, w), lane, rb);
 #endif
+#if (2 == XLOWP)
+  if (!XBETA0) load_pairs<VPC, NPC, PC>(resolve<const unsigned>(ad.c, ad.ic, ad.sc, ad, w), lane, rc);
+#else
   if (!XBETA0) load_flat<VC, NLC, CE>(resolve<const T>(ad.c, ad.ic, ad.sc, ad, w), lane, rc);
+#endif
   for (long long item = w; item < batch; item += W) {
+#if (2 == XLOWP)
+    unsigned* const pc = resolve<unsigned>(ad.c, ad.ic, ad.sc, ad, item);
+#else
     T* const pc = resolve<T>(ad.c, ad.ic, ad.sc, ad, item);
+#endif
 #if XLOWP
     park_pairs(As, Bs, lane, ra, rb);
 #else
     park_ab(As, Bs, lane, ra, rb);
 #endif
+#if (2 == XLOWP)
+    if (!XBETA0) park_c_pairs(Cs, lane, rc);
+#else
     if (!XBETA0) park_c(Cs, lane, rc);
+#endif
     // ---- next item's loads go out before this item's arithmetic
     const long long next = item + W;
     if (next < batch) {
@@ -605,13 +666,21 @@ extern "C" __global__ __launch_bounds__(64 * XWAVES) void xsmm_smm_op(DevAddr ad
       load_flat<VA, NLA, AE>(resolve<const T>(ad.a, ad.ia, ad.sa, ad, next), lane, ra);
       load_flat<VB, NLB, BE>(resolve<const T>(ad.b, ad.ib, ad.sb, ad, next), lane, rb);
 #endif
+#if (2 == XLOWP)
+      if (!XBETA0) load_pairs<VPC, NPC, PC>(resolve<const unsigned>(ad.c, ad.ic, ad.sc, ad, next), lane, rc);
+#else
       if (!XBETA0) load_flat<VC, NLC, CE>(resolve<const T>(ad.c, ad.ic, ad.sc, ad, next), lane, rc);
+#endif
     }
     wave_lds_sync();
     T acc[TM][TN];
     acc_from_c(Cs + grp * CT1, tx, ty, acc, XBETA0);
     multiply(As + grp * AS1, Bs + grp * BS1, tx, ty * TN, acc);
+#if (2 == XLOWP)
+    store_c_pairs(Cs, pc, lane, tx, ty, acc);
+#else
     store_c(Cs, pc, lane, tx, ty, acc, Cs + grp * CT1);
+#endif
   }
 #endif
 }
@@ -819,7 +888,7 @@ std::string gen_smm_source(int typesize, int m, int n, int k, int flags, int var
   if (ldb <= 0) ldb = (flags & LIBXSMM_GEMM_FLAG_TRANS_B) ? n : k;
   if (ldc <= 0) ldc = m;
   std::string s = "// generated by libxsmm-amd (dense SMM kernel, shape baked in)\n";
-  const int lowp = (variant >> 11) & 3; // 16-bit inputs: 1 = i16 -> i32, 3 = bf16 -> f32 (0: none)
+  const int lowp = (variant >> 11) & 3; // 16-bit inputs: 1 = i16 -> i32, 2 = bf16 -> bf16, 3 = bf16 -> f32 (0: none)
   s += std::string("typedef ") + (8 == typesize ? "double" : (1 == lowp ? "int" : "float")) + " T;\n";
   s += "#define XLOWP " + std::to_string(lowp) + "\n";
   s += "#define XM " + std::to_string(m) + "\n#define XN " + std::to_string(n) + "\n#define XK " + std::to_string(k) + "\n";
@@ -1025,7 +1094,8 @@ int launch_smm_jit_lowp(const SmmBatch& s, void* stream, const char** name)
 {
   const char* const env_jit = getenv("LIBXSMM_AMD_JIT");
   if (nullptr != env_jit && 0 == atoi(env_jit)) return -1;
-  if ((1 != s.lowp && 3 != s.lowp) || ADDR_STRIDED != s.mode || 0 != (s.flags & LIBXSMM_GEMM_FLAG_TRANS_B)) return -1;
+  if ((1 != s.lowp && 3 != s.lowp && 4 != s.lowp) || ADDR_STRIDED != s.mode || 0 != (s.flags & LIBXSMM_GEMM_FLAG_TRANS_B)) return -1;
+  if (4 == s.lowp && 0 != (s.m & 1)) return -1;
   if (s.m > 32 || s.n > 32 || s.k > 64 || 0 != (s.k & 1) || s.lda != s.m || s.ldb != s.k || s.ldc != s.m) return -1;
   if (s.sa != (long long)s.m * s.k || s.sb != (long long)s.k * s.n || s.sc != (long long)s.m * s.n) return -1;
   const char* const env_min = getenv("LIBXSMM_AMD_JIT_MINBATCH");
@@ -1034,9 +1104,10 @@ int launch_smm_jit_lowp(const SmmBatch& s, void* stream, const char** name)
   SmmBatch j = s;
   j.typesize = 4; j.lowp = 0; j.sync = SYNC_NONE;
   j.sa = s.sa / 2; j.sb = s.sb / 2; // the kernel addresses A and B as 32-bit k pairs
+  if (4 == s.lowp) j.sc = s.sc / 2;   // ... and a bf16 C as pairs along m
   const uintptr_t bits = reinterpret_cast<uintptr_t>(s.a) | reinterpret_cast<uintptr_t>(s.b) | reinterpret_cast<uintptr_t>(s.c);
-  const int variant = ((0 == (bits & 15)) ? 0 : SMM_JIT_SCALAR) | (s.lowp << 11);
-  *name = (1 == s.lowp) ? "smm_i16i32_jit_shape_lowp" : "smm_bf16f32_jit_shape_lowp";
+  const int variant = ((0 == (bits & 15)) ? 0 : SMM_JIT_SCALAR) | ((4 == s.lowp ? 2 : s.lowp) << 11); // XLOWP: 1 i16 -> i32, 2 bf16 -> bf16, 3 bf16 -> f32
+  *name = (1 == s.lowp) ? "smm_i16i32_jit_shape_lowp" : (4 == s.lowp ? "smm_bf16_jit_shape_lowp" : "smm_bf16f32_jit_shape_lowp");
   return smm_jit_launch_variant(j, variant, stream);
 }
 

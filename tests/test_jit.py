@@ -47,11 +47,11 @@ def test_generated_sources_compile_for_gfx950(xs):
                 for lg in packs:
                     assert 0 == L.libxsmm_amd_smm_kernel_source(d, lg << 8, buf, len(buf), 1), (prec, m, n, k, beta, flags, lg)
                     assert "#define XPACK %d\n" % (1 << lg) in buf.value.decode()
-    # 16-bit inputs widened on the way into LDS (variant bits 11..12: 1 = i16 -> i32, 3 = bf16 -> f32), wide and element-wide
+    # 16-bit inputs widened on the way into LDS (variant bits 11..12: 1 = i16 -> i32, 2 = bf16 -> bf16, 3 = bf16 -> f32), wide and element-wide
     for (m, n, k) in [(32, 32, 32), (16, 12, 24), (23, 9, 64)]:
         for beta in (1.0, 0.0):
             blob, d = xs.descriptor(xs.F32, m, n, k, beta=beta)
-            for variant in ((1 << 11), (3 << 11), (1 << 11) | 1, (3 << 11) | 1):
+            for variant in ((1 << 11), (2 << 11), (3 << 11), (1 << 11) | 1, (2 << 11) | 1, (3 << 11) | 1):
                 assert 0 == L.libxsmm_amd_smm_kernel_source(d, variant, buf, len(buf), 1), (m, n, k, beta, variant)
                 assert "#define XLOWP %d\n" % (variant >> 11) in buf.value.decode()
     # fixed-sparsity operator

@@ -198,7 +198,7 @@ def test_low_precision_batches(xs, orc, torch_gpu, kind):
     desc = L.libxsmm_gemm_descriptor_dinit2(C.byref(blob), ip, op, m, n, k, m, k, m, 1.0, 1.0, 0, 0)
     assert desc and len(ident) == batch
     import os
-    for forced in (False, True):  # forced: the hiprtc-specialised streaming form (normally for batches >= 16384), i16 -> i32 and bf16 -> f32
+    for forced in (False, True):  # forced: the hiprtc-specialised streaming form (normally for batches >= 16384)
         old_env = os.environ.get("LIBXSMM_AMD_JIT_MINBATCH")
         if forced:
             os.environ["LIBXSMM_AMD_JIT_MINBATCH"] = "1"
@@ -212,7 +212,7 @@ def test_low_precision_batches(xs, orc, torch_gpu, kind):
             else:
                 os.environ["LIBXSMM_AMD_JIT_MINBATCH"] = old_env
         assert xs.last_kernel().endswith("_lowp")
-        assert ("_jit_shape_lowp" in xs.last_kernel()) == (forced and kind in (0, 2)), xs.last_kernel()
+        assert ("_jit_shape_lowp" in xs.last_kernel()) == forced, xs.last_kernel()
         got = dc.cpu().numpy(); got = got.view(np.uint16) if kind == 3 else got
         assert np.array_equal(got.view(np.uint8), ref2.view(np.uint8)), (kind, forced)
     assert xs.last_kernel().endswith("_lowp")

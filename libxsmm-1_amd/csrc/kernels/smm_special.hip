@@ -189,6 +189,82 @@ void smm32_f32_mfma_kernel(DevAddr ad, long long batch)
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// smm64: M=N=K=64, fp32, tight leading dimensions -- the largest member of the (M,N,K) <= 64 family, where the vector ALU
+// (8 flop per byte at 64^3) rather than HBM limits the register-tiled kernels. One work-group of four waves owns one item
+// at a time; wave (mq, nq) computes the 32x32 quadrant C[32mq.., 32nq..] with 32 v_mfma_f32_32x32x2_f32 whose k pairs are
+// (2s, 2s + 1): per C element the chain fma(A[m,k], B[k,n], acc), k = 0..63 -- the reference's order, bit for bit.
+// LDS images (16 KiB each, read conflict-free):
+//   A: word k*64 + (m ^ 32(k&1))  -- a wave reads A[32mq + lo][2s + hi]: the two half-waves land in opposite bank halves;
+//   B: 16-byte chunk (n, q = k/4) at n*16 + (q ^ (n&15)) -- a lane reads its own column, 16 lanes cover all bank groups.
+// The operands of the work-group's next item are loaded into registers before the arithmetic of the current one.
+// ---------------------------------------------------------------------------------------------------------------
+template<bool BETA0>
+__global__ __launch_bounds__(256, 4)
+void smm64_f32_mfma_kernel(DevAddr ad, long long batch)
+{
+  __shared__ __align__(16) float As[4096];
+  __shared__ __align__(16) float Bs[4096];
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63, lo = lane & 31, hi = lane >> 5;
+  const int mq = wave & 1, nq = wave >> 1;
+  const int m = 32 * mq + lo, n = 32 * nq + lo;
+  const int coff = (32 * nq + 4 * hi) * 64 + m; // lane's first C element
+  long long item = blockIdx.x;
+  if (item >= batch) return; // the whole work-group
+
+  f32x4 ra[4], rb[4];
+  float rc[16];
+  auto load_ab = [&](long long i) {
+    const float* const pa = addr_a<float>(ad, i);
+    const float* const pb = addr_b<float>(ad, i);
+    const bool ala = aligned16(pa), alb = aligned16(pb);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      ra[j] = ld4<true, false>(pa + 4 * (256 * j + t), ala);
+      rb[j] = ld4<true, false>(pb + 4 * (256 * j + t), alb);
+    }
+  };
+  auto load_c = [&](const float* pc) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rc[r] = ld1<true, false>(pc + ((r & 3) + 8 * (r >> 2)) * 64);
+  };
+  load_ab(item);
+  if (!BETA0) load_c(addr_c<float>(ad, item) + coff);
+  for (; item < batch; item += gridDim.x) {
+    float* const pc = addr_c<float>(ad, item) + coff;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = 256 * j + t, row = c >> 4, q = c & 15; // row: k of A, n of B
+      *reinterpret_cast<f32x4*>(As + row * 64 + ((4 * q) ^ ((row & 1) << 5))) = ra[j];
+      *reinterpret_cast<f32x4*>(Bs + row * 64 + 4 * (q ^ (row & 15))) = rb[j];
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = BETA0 ? 0.f : rc[r];
+    const long long next = item + gridDim.x;
+    if (next < batch) {
+      load_ab(next);
+      if (!BETA0) load_c(addr_c<float>(ad, next) + coff);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      f32x4 bt[8]; // B[32 half + 4u + e][n]
+#pragma unroll
+      for (int u = 0; u < 8; ++u) bt[u] = *reinterpret_cast<const f32x4*>(Bs + n * 64 + 4 * ((8 * half + u) ^ (n & 15)));
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const float av = As[(32 * half + 2 * s + hi) * 64 + (m ^ (hi << 5))]; // A[m][k = 32 half + 2s + hi]
+        const float bv = (0 != hi) ? bt[s >> 1][2 * (s & 1) + 1] : bt[s >> 1][2 * (s & 1)]; // B[k][n]
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bv, av, acc, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st1<true, false>(pc + ((r & 3) + 8 * (r >> 2)) * 64, acc[r]);
+    __syncthreads(); // all reads of the images are done before the next item is parked
+  }
+}
+
 // c[i] = a[i] + b[i] + c[i] in whole 4 KiB items per wave with the same prefetch structure as the SMM kernels: the
 // traffic mix of a beta=1 SMM batch (3 reads : 1 write) without arithmetic or LDS -- the measured ceiling the SMM
 // kernels are compared against (bench.py "stream_ceiling").
@@ -233,6 +309,12 @@ bool is_smm32_f32(const SmmBatch& s)
       && 0 == (s.flags & LIBXSMM_GEMM_FLAG_TRANS_B) && SYNC_NONE == s.sync && 0 == s.general;
 }
 
+bool is_smm64_f32(const SmmBatch& s)
+{
+  return 4 == s.typesize && 64 == s.m && 64 == s.n && 64 == s.k && 64 == s.lda && 64 == s.ldb && 64 == s.ldc
+      && 0 == (s.flags & LIBXSMM_GEMM_FLAG_TRANS_B) && SYNC_NONE == s.sync && 0 == s.general && 0 != s.use_mfma;
+}
+
 template<bool NT, bool GLB>
 int launch_smm32(const SmmBatch& s, hipStream_t st, unsigned blocks, const char** name)
 {
@@ -268,6 +350,18 @@ int launch_smm_special(const SmmBatch& s, void* stream, const char** name)
     if (blocks > resident) blocks = resident;
     if (1 == variant) return (0 != nt) ? launch_smm32<true, true>(s, st, (unsigned)blocks, name) : launch_smm32<false, true>(s, st, (unsigned)blocks, name);
     return (0 != nt) ? launch_smm32<true, false>(s, st, (unsigned)blocks, name) : launch_smm32<false, false>(s, st, (unsigned)blocks, name);
+  }
+  if (is_smm64_f32(s) && 0 != env_int("XSMM_SMM64_MFMA", 1)) {
+    const int bpc = env_int("XSMM_SMM64_BPC", 4);
+    long long blocks = s.batch;
+    const long long resident = 256LL * (bpc > 0 ? bpc : 3);
+    if (blocks > resident) blocks = resident;
+    if (blocks < 1) return -1;
+    const DevAddr ad = make_addr(s);
+    *name = "smm_f32_64x64x64_mfma";
+    if (0 != (s.flags & LIBXSMM_GEMM_FLAG_BETA_0)) hipLaunchKernelGGL((smm64_f32_mfma_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, st, ad, s.batch);
+    else hipLaunchKernelGGL((smm64_f32_mfma_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, st, ad, s.batch);
+    return (int)hipGetLastError();
   }
   return -1;
 }

@@ -265,6 +265,88 @@ void smm64_f32_mfma_kernel(DevAddr ad, long long batch)
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// smm64 fp64: the same work-group-per-item plan with v_mfma_f64_16x16x4_f64 (probed to be the k-ordered fma chain bit for bit,
+// tools/probe/mfma_f64_chain.hip). Wave (mq, nq) owns a 32x32 quadrant as 2x2 tiles of 16x16; step s feeds k = 4s + q
+// (q = lane >> 4). B is the first operand, so register r of lane (i, q) is C[n = q + 4r][m = i] of a tile: 128-byte rows.
+// LDS images (32 KiB each), both k-major so that the 16 lanes of a k read neighbouring words:
+//   A: word k*64 + (m ^ 16(k&1));  B (transposed while parking): word k*64 + (n ^ (k>>1) ^ 16(k&1)) -- reads (q, q+1 in one
+//   phase) and the transposing writes (32 different k of one column per phase) are conflict-free.
+// ---------------------------------------------------------------------------------------------------------------
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f64x2 ldd2(const double* p, bool al)
+{
+  if (al) return __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(p));
+  return f64x2{ __builtin_nontemporal_load(p), __builtin_nontemporal_load(p + 1) }; // operands that are only element-aligned
+}
+
+template<bool BETA0>
+__global__ __launch_bounds__(256, 2)
+void smm64_f64_mfma_kernel(DevAddr ad, long long batch)
+{
+  __shared__ __align__(16) double As[4096];
+  __shared__ __align__(16) double Bs[4096];
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63, i = lane & 15, q = lane >> 4;
+  const int mq = wave & 1, nq = wave >> 1;
+  const int m0 = 32 * mq + i, n0 = 32 * nq + i;
+  const int coff = (32 * nq + q) * 64 + m0; // lane's first C element
+  long long item = blockIdx.x;
+  if (item >= batch) return; // the whole work-group
+
+  f64x2 ra[8], rb[8];
+  double rc[16];
+  auto load_ab = [&](long long it) {
+    const double* const pa = addr_a<double>(ad, it);
+    const double* const pb = addr_b<double>(ad, it);
+    const bool ala = aligned16(pa), alb = aligned16(pb);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      ra[j] = ldd2(pa + 2 * (256 * j + t), ala);
+      rb[j] = ldd2(pb + 2 * (256 * j + t), alb);
+    }
+  };
+  auto load_c = [&](const double* pc) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) rc[e] = __builtin_nontemporal_load(pc + (16 * (e >> 3) + 4 * (e & 3)) * 64 + 16 * ((e >> 2) & 1));
+  };
+  load_ab(item);
+  if (!BETA0) load_c(addr_c<double>(ad, item) + coff);
+  for (; item < batch; item += gridDim.x) {
+    double* const pc = addr_c<double>(ad, item) + coff;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = 256 * j + t, row = c >> 5, q2 = c & 31; // row: k of A, n of B; the chunk holds elements 2 q2, 2 q2 + 1
+      *reinterpret_cast<f64x2*>(As + row * 64 + ((2 * q2) ^ ((row & 1) << 4))) = ra[j];
+      Bs[(2 * q2) * 64 + (row ^ q2)] = rb[j][0];
+      Bs[(2 * q2 + 1) * 64 + (row ^ q2 ^ 16)] = rb[j][1];
+    }
+    f64x4 acc[2][2]; // [tn][tm]
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e >> 3][(e >> 2) & 1][e & 3] = BETA0 ? 0.0 : rc[e];
+    const long long next = item + gridDim.x;
+    if (next < batch) {
+      load_ab(next);
+      if (!BETA0) load_c(addr_c<double>(ad, next) + coff);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const int k = 4 * s + q, sa = (q & 1) << 4, sb = (2 * s + (q >> 1)) ^ sa;
+      const double a0 = As[k * 64 + (m0 ^ sa)], a1 = As[k * 64 + ((m0 + 16) ^ sa)];
+      const double b0 = Bs[k * 64 + (n0 ^ sb)], b1 = Bs[k * 64 + ((n0 + 16) ^ sb)];
+      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, a0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, a1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a1, acc[1][1], 0, 0, 0);
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) __builtin_nontemporal_store(acc[e >> 3][(e >> 2) & 1][e & 3], pc + (16 * (e >> 3) + 4 * (e & 3)) * 64 + 16 * ((e >> 2) & 1));
+    __syncthreads(); // all reads of the images are done before the next item is parked
+  }
+}
+
 // c[i] = a[i] + b[i] + c[i] in whole 4 KiB items per wave with the same prefetch structure as the SMM kernels: the
 // traffic mix of a beta=1 SMM batch (3 reads : 1 write) without arithmetic or LDS -- the measured ceiling the SMM
 // kernels are compared against (bench.py "stream_ceiling").
@@ -309,9 +391,9 @@ bool is_smm32_f32(const SmmBatch& s)
       && 0 == (s.flags & LIBXSMM_GEMM_FLAG_TRANS_B) && SYNC_NONE == s.sync && 0 == s.general;
 }
 
-bool is_smm64_f32(const SmmBatch& s)
+bool is_smm64(const SmmBatch& s, int typesize)
 {
-  return 4 == s.typesize && 64 == s.m && 64 == s.n && 64 == s.k && 64 == s.lda && 64 == s.ldb && 64 == s.ldc
+  return typesize == s.typesize && 64 == s.m && 64 == s.n && 64 == s.k && 64 == s.lda && 64 == s.ldb && 64 == s.ldc
       && 0 == (s.flags & LIBXSMM_GEMM_FLAG_TRANS_B) && SYNC_NONE == s.sync && 0 == s.general && 0 != s.use_mfma;
 }
 
@@ -351,7 +433,19 @@ int launch_smm_special(const SmmBatch& s, void* stream, const char** name)
     if (1 == variant) return (0 != nt) ? launch_smm32<true, true>(s, st, (unsigned)blocks, name) : launch_smm32<false, true>(s, st, (unsigned)blocks, name);
     return (0 != nt) ? launch_smm32<true, false>(s, st, (unsigned)blocks, name) : launch_smm32<false, false>(s, st, (unsigned)blocks, name);
   }
-  if (is_smm64_f32(s) && 0 != env_int("XSMM_SMM64_MFMA", 1)) {
+  if (is_smm64(s, 8) && 0 != env_int("XSMM_SMM64_MFMA", 1)) {
+    const int bpc = env_int("XSMM_SMM64_BPC", 2);
+    long long blocks = s.batch;
+    const long long resident = 256LL * (bpc > 0 ? bpc : 2);
+    if (blocks > resident) blocks = resident;
+    if (blocks < 1) return -1;
+    const DevAddr ad = make_addr(s);
+    *name = "smm_f64_64x64x64_mfma";
+    if (0 != (s.flags & LIBXSMM_GEMM_FLAG_BETA_0)) hipLaunchKernelGGL((smm64_f64_mfma_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, st, ad, s.batch);
+    else hipLaunchKernelGGL((smm64_f64_mfma_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, st, ad, s.batch);
+    return (int)hipGetLastError();
+  }
+  if (is_smm64(s, 4) && 0 != env_int("XSMM_SMM64_MFMA", 1)) {
     const int bpc = env_int("XSMM_SMM64_BPC", 4);
     long long blocks = s.batch;
     const long long resident = 256LL * (bpc > 0 ? bpc : 3);

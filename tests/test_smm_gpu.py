@@ -107,41 +107,43 @@ def test_smm32_f32_special(xs, orc, torch_gpu, beta, mfma):
 
 @pytest.mark.parametrize("beta", [1.0, 0.0])
 @pytest.mark.parametrize("mode", ["strided", "index"])
-def test_smm64_f32_mfma(xs, orc, torch_gpu, beta, mode):
-    """fp32 64^3 (tight) on the matrix cores, one work-group per item: bit-identical to the oracle's k-ordered fma chain;
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_smm64_mfma(xs, orc, torch_gpu, dtype, beta, mode):
+    """64^3 (tight) on the matrix cores (v_mfma_f32_32x32x2_f32 / v_mfma_f64_16x16x4_f64), one work-group per item: bit-identical to the oracle's k-ordered fma chain;
     strided and index-array addressing (items at odd element offsets: operands only 4-byte aligned), batch not a multiple of the grid."""
     torch = torch_gpu
     m = n = k = 64
     batch = 1543
     rng = np.random.default_rng(64)
-    a, b, c, asz, bsz, csz = make_inputs(rng, np.float32, batch, m, n, k, m, k, m, False, False, orc)
+    a, b, c, asz, bsz, csz = make_inputs(rng, dtype, batch, m, n, k, m, k, m, False, False, orc)
     if beta == 0.0:
         c[:] = np.nan
     flags = xs.FLAG_BETA_0 if beta == 0.0 else 0
+    prec = xs.F64 if dtype == np.float64 else xs.F32
     old = xs.lib().libxsmm_amd_set_mfma(1)
     try:
         ref = c.copy()
         if mode == "strided":
             orc.gemm_batch_strided(orc.FMA, flags, m, n, k, m, k, m, a, b, ref, asz, bsz, csz, batch, 8)
             da, db, dc = (torch.from_numpy(x).cuda() for x in (a, b, c))
-            blob, desc = xs.descriptor(xs.F32, m, n, k, m, k, m, 1.0, beta)
+            blob, desc = xs.descriptor(prec, m, n, k, m, k, m, 1.0, beta)
             assert 0 == xs.lib().libxsmm_amd_gemm_batch_strided(desc, xs.dptr(da), xs.dptr(db), xs.dptr(dc), asz, bsz, csz, batch)
         else:
             # A and B shifted by one and three elements (operands only 4-byte aligned), walked out of order; distinct C blocks
-            a1 = np.concatenate([np.zeros(1, np.float32), a])
-            b1 = np.concatenate([np.zeros(3, np.float32), b])
+            a1 = np.concatenate([np.zeros(1, dtype), a])
+            b1 = np.concatenate([np.zeros(3, dtype), b])
             sa = (rng.permutation(batch) * asz + 1).astype(np.int32)
             sb = (rng.integers(0, batch, batch) * bsz + 3).astype(np.int32)
             sc = (np.arange(batch) * csz).astype(np.int32)
             assert 0 == orc.gemm_batch_idx(orc.FMA, flags, m, n, k, m, k, m, a1, b1, ref, 0, sa, sb, sc, batch)
             da, db, dc = (torch.from_numpy(x).cuda() for x in (a1, b1, c))
             # negative batch size: the caller's promise that C blocks are distinct (src/libxsmm_gemm.c:1338) -- no look at the order of C
-            xs.gemm_batch(xs.F32, "N", "N", m, n, k, 1.0, da, m, db, k, beta, dc, m, 0, 4, sa, sb, sc, -batch)
+            xs.gemm_batch(prec, "N", "N", m, n, k, 1.0, da, m, db, k, beta, dc, m, 0, 4, sa, sb, sc, -batch)
         torch.cuda.synchronize()
         out = dc.cpu().numpy()
     finally:
         xs.lib().libxsmm_amd_set_mfma(old)
-    assert xs.last_kernel() == "smm_f32_64x64x64_mfma", xs.last_kernel()
+    assert xs.last_kernel() == ("smm_f64_64x64x64_mfma" if dtype == np.float64 else "smm_f32_64x64x64_mfma"), xs.last_kernel()
     assert np.array_equal(out, ref)
 
 

@@ -347,6 +347,97 @@ void smm64_f64_mfma_kernel(DevAddr ad, long long batch)
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// smm_f32_mfma_wg: the same plan for any fp32 shape with 32 < max(M, N) <= 64 and K <= 64, any leading dimensions -- the
+// class the register-tiled work-group kernels serve at about half of the HBM peak. Operands travel as dwords (lanes along
+// a column: whole 128/256-byte rows of every column), both LDS images are k-major:
+//   A: word k*64 + (m ^ 32(k&1));  B (transposed while parking): word k*64 + (n ^ (k>>1) ^ 32(k&1))
+// (reads of the two k of a step and the transposing writes, 64 different k of one column per wave, are conflict-free).
+// K is padded to an even count with A = -0, B = +0: the extra product is -0 and x + (-0) = x for every x, signed zeros
+// included, so the chain stays the reference's. Rows m >= M and columns n >= N of the images hold the same padding; the
+// C elements they would produce are neither loaded nor stored.
+// ---------------------------------------------------------------------------------------------------------------
+// The operands of an item are the same for the whole work-group: with the base in scalar registers a load is "scalar base
+// + one 32-bit lane offset", and the 48 loads of an item share three offset registers instead of holding 48 addresses.
+template<typename T> __device__ __forceinline__ T* wave_uniform(T* p)
+{
+  const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
+}
+
+template<bool BETA0>
+__global__ __launch_bounds__(256, 4)
+void smm_f32_mfma_wg_kernel(DevAddr ad, int M, int N, int K, int lda, int ldb, int ldc, long long batch)
+{
+  __shared__ __align__(16) float As[4096];
+  __shared__ __align__(16) float Bs[4096];
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63, lo = lane & 31, hi = lane >> 5;
+  const int mq = wave & 1, nq = wave >> 1;
+  const int m = 32 * mq + lo, n = 32 * nq + lo;
+  const int ksteps = (K + 1) >> 1;
+  const bool active = (32 * mq < M) && (32 * nq < N); // the wave's quadrant holds part of C
+  long long item = blockIdx.x;
+  if (item >= batch) return; // the whole work-group
+
+  float ra[16], rb[16], rc[16];
+  const unsigned offa = (unsigned)(wave * lda + lane), offb = (unsigned)(wave * ldb + lane);
+  const unsigned offc = (unsigned)((32 * nq + 4 * hi) * ldc + m);
+  auto load_ab = [&](long long it) {
+    const float* const pa = wave_uniform(addr_a<float>(ad, it));
+    const float* const pb = wave_uniform(addr_b<float>(ad, it));
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { // element (row = lane, column = 4j + wave) of the 64x64 frame
+      const int col = 4 * j + wave;
+      ra[j] = (lane < M && col < K) ? ld1<true, true>(pa + (size_t)(4 * j) * lda + offa) : -0.f;
+      rb[j] = (lane < K && col < N) ? ld1<true, true>(pb + (size_t)(4 * j) * ldb + offb) : 0.f;
+    }
+  };
+  auto load_c = [&](const float* pc0) {
+    const float* const pc = wave_uniform(pc0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int nr = (r & 3) + 8 * (r >> 2);
+      rc[r] = (m < M && 32 * nq + 4 * hi + nr < N) ? ld1<true, true>(pc + (size_t)nr * ldc + offc) : 0.f;
+    }
+  };
+  load_ab(item);
+  if (!BETA0 && active) load_c(addr_c<float>(ad, item));
+  for (; item < batch; item += gridDim.x) {
+    float* const pc = wave_uniform(addr_c<float>(ad, item));
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int col = 4 * j + wave;
+      As[col * 64 + (lane ^ ((col & 1) << 5))] = ra[j];                         // A[m = lane][k = col]
+      Bs[lane * 64 + (col ^ (lane >> 1) ^ ((lane & 1) << 5))] = rb[j];          // B[k = lane][n = col]
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = BETA0 ? 0.f : rc[r];
+    const long long next = item + gridDim.x;
+    if (next < batch) {
+      load_ab(next);
+      if (!BETA0 && active) load_c(addr_c<float>(ad, next));
+    }
+    __syncthreads();
+    if (active) {
+#pragma unroll 4
+      for (int s = 0; s < ksteps; ++s) {
+        const int k = 2 * s + hi;
+        const float av = As[k * 64 + (m ^ (hi << 5))];       // A[m][k]
+        const float bv = Bs[k * 64 + (n ^ s ^ (hi << 5))];   // B[k][n]
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bv, av, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int nr = (r & 3) + 8 * (r >> 2);
+        if (m < M && 32 * nq + 4 * hi + nr < N) st1<true, true>(pc + (size_t)nr * ldc + offc, acc[r]);
+      }
+    }
+    __syncthreads(); // all reads of the images are done before the next item is parked
+  }
+}
+
 // c[i] = a[i] + b[i] + c[i] in whole 4 KiB items per wave with the same prefetch structure as the SMM kernels: the
 // traffic mix of a beta=1 SMM batch (3 reads : 1 write) without arithmetic or LDS -- the measured ceiling the SMM
 // kernels are compared against (bench.py "stream_ceiling").
@@ -455,6 +546,20 @@ int launch_smm_special(const SmmBatch& s, void* stream, const char** name)
     *name = "smm_f32_64x64x64_mfma";
     if (0 != (s.flags & LIBXSMM_GEMM_FLAG_BETA_0)) hipLaunchKernelGGL((smm64_f32_mfma_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, st, ad, s.batch);
     else hipLaunchKernelGGL((smm64_f32_mfma_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, st, ad, s.batch);
+    return (int)hipGetLastError();
+  }
+  if (4 == s.typesize && (32 < s.m || 32 < s.n) && s.m <= 64 && s.n <= 64 && 0 < s.k && s.k <= 64 && s.lda >= s.m && s.ldb >= s.k && s.ldc >= s.m
+    && 0 == (s.flags & LIBXSMM_GEMM_FLAG_TRANS_B) && SYNC_NONE == s.sync && 0 == s.general && 0 != s.use_mfma && 0 != env_int("XSMM_SMM64_MFMA", 1))
+  {
+    const int bpc = env_int("XSMM_SMM64_BPC", 4);
+    long long blocks = s.batch;
+    const long long resident = 256LL * (bpc > 0 ? bpc : 4);
+    if (blocks > resident) blocks = resident;
+    if (blocks < 1) return -1;
+    const DevAddr ad = make_addr(s);
+    *name = "smm_f32_mfma_wg";
+    if (0 != (s.flags & LIBXSMM_GEMM_FLAG_BETA_0)) hipLaunchKernelGGL((smm_f32_mfma_wg_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, st, ad, s.m, s.n, s.k, s.lda, s.ldb, s.ldc, s.batch);
+    else hipLaunchKernelGGL((smm_f32_mfma_wg_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, st, ad, s.m, s.n, s.k, s.lda, s.ldb, s.ldc, s.batch);
     return (int)hipGetLastError();
   }
   return -1;

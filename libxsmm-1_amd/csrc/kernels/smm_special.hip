@@ -12,12 +12,14 @@
 //   "mfma" variants: v_mfma_f32_32x32x2_f32, a k-ordered fmaf chain; the two k of instruction s are (2s, 2s+1), so the
 //                   chain per C element runs k = 0,1,2,...: bit-identical to the "fma" variant and the reference's chain.
 #include "smm_common.cuh"
+#include <mutex>
 
 namespace xsmm {
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ bool aligned16(const void* p) { return 0 == (reinterpret_cast<uintptr_t>(p) & 15); }
 
@@ -266,88 +268,6 @@ void smm64_f32_mfma_kernel(DevAddr ad, long long batch)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// smm64 fp64: the same work-group-per-item plan with v_mfma_f64_16x16x4_f64 (probed to be the k-ordered fma chain bit for bit,
-// tools/probe/mfma_f64_chain.hip). Wave (mq, nq) owns a 32x32 quadrant as 2x2 tiles of 16x16; step s feeds k = 4s + q
-// (q = lane >> 4). B is the first operand, so register r of lane (i, q) is C[n = q + 4r][m = i] of a tile: 128-byte rows.
-// LDS images (32 KiB each), both k-major so that the 16 lanes of a k read neighbouring words:
-//   A: word k*64 + (m ^ 16(k&1));  B (transposed while parking): word k*64 + (n ^ (k>>1) ^ 16(k&1)) -- reads (q, q+1 in one
-//   phase) and the transposing writes (32 different k of one column per phase) are conflict-free.
-// ---------------------------------------------------------------------------------------------------------------
-typedef double f64x2 __attribute__((ext_vector_type(2)));
-typedef double f64x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ f64x2 ldd2(const double* p, bool al)
-{
-  if (al) return __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(p));
-  return f64x2{ __builtin_nontemporal_load(p), __builtin_nontemporal_load(p + 1) }; // operands that are only element-aligned
-}
-
-template<bool BETA0>
-__global__ __launch_bounds__(256, 2)
-void smm64_f64_mfma_kernel(DevAddr ad, long long batch)
-{
-  __shared__ __align__(16) double As[4096];
-  __shared__ __align__(16) double Bs[4096];
-  const int t = threadIdx.x, wave = t >> 6, lane = t & 63, i = lane & 15, q = lane >> 4;
-  const int mq = wave & 1, nq = wave >> 1;
-  const int m0 = 32 * mq + i, n0 = 32 * nq + i;
-  const int coff = (32 * nq + q) * 64 + m0; // lane's first C element
-  long long item = blockIdx.x;
-  if (item >= batch) return; // the whole work-group
-
-  f64x2 ra[8], rb[8];
-  double rc[16];
-  auto load_ab = [&](long long it) {
-    const double* const pa = addr_a<double>(ad, it);
-    const double* const pb = addr_b<double>(ad, it);
-    const bool ala = aligned16(pa), alb = aligned16(pb);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      ra[j] = ldd2(pa + 2 * (256 * j + t), ala);
-      rb[j] = ldd2(pb + 2 * (256 * j + t), alb);
-    }
-  };
-  auto load_c = [&](const double* pc) {
-#pragma unroll
-    for (int e = 0; e < 16; ++e) rc[e] = __builtin_nontemporal_load(pc + (16 * (e >> 3) + 4 * (e & 3)) * 64 + 16 * ((e >> 2) & 1));
-  };
-  load_ab(item);
-  if (!BETA0) load_c(addr_c<double>(ad, item) + coff);
-  for (; item < batch; item += gridDim.x) {
-    double* const pc = addr_c<double>(ad, item) + coff;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int c = 256 * j + t, row = c >> 5, q2 = c & 31; // row: k of A, n of B; the chunk holds elements 2 q2, 2 q2 + 1
-      *reinterpret_cast<f64x2*>(As + row * 64 + ((2 * q2) ^ ((row & 1) << 4))) = ra[j];
-      Bs[(2 * q2) * 64 + (row ^ q2)] = rb[j][0];
-      Bs[(2 * q2 + 1) * 64 + (row ^ q2 ^ 16)] = rb[j][1];
-    }
-    f64x4 acc[2][2]; // [tn][tm]
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e >> 3][(e >> 2) & 1][e & 3] = BETA0 ? 0.0 : rc[e];
-    const long long next = item + gridDim.x;
-    if (next < batch) {
-      load_ab(next);
-      if (!BETA0) load_c(addr_c<double>(ad, next) + coff);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      const int k = 4 * s + q, sa = (q & 1) << 4, sb = (2 * s + (q >> 1)) ^ sa;
-      const double a0 = As[k * 64 + (m0 ^ sa)], a1 = As[k * 64 + ((m0 + 16) ^ sa)];
-      const double b0 = Bs[k * 64 + (n0 ^ sb)], b1 = Bs[k * 64 + ((n0 + 16) ^ sb)];
-      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, a0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, a1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a1, acc[1][1], 0, 0, 0);
-    }
-#pragma unroll
-    for (int e = 0; e < 16; ++e) __builtin_nontemporal_store(acc[e >> 3][(e >> 2) & 1][e & 3], pc + (16 * (e >> 3) + 4 * (e & 3)) * 64 + 16 * ((e >> 2) & 1));
-    __syncthreads(); // all reads of the images are done before the next item is parked
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
 // smm_f32_mfma_wg: the same plan for any fp32 shape with 32 < max(M, N) <= 64 and K <= 64, any leading dimensions -- the
 // class the register-tiled work-group kernels serve at about half of the HBM peak. Operands travel as dwords (lanes along
 // a column: whole 128/256-byte rows of every column), both LDS images are k-major:
@@ -421,7 +341,6 @@ void smm_f32_mfma_wg_kernel(DevAddr ad, int M, int N, int K, int lda, int ldb, i
     }
     __syncthreads();
     if (active) {
-#pragma unroll 4
       for (int s = 0; s < ksteps; ++s) {
         const int k = 2 * s + hi;
         const float av = As[k * 64 + (m ^ (hi << 5))];       // A[m][k]
@@ -432,6 +351,102 @@ void smm_f32_mfma_wg_kernel(DevAddr ad, int M, int N, int K, int lda, int ldb, i
       for (int r = 0; r < 16; ++r) {
         const int nr = (r & 3) + 8 * (r >> 2);
         if (m < M && 32 * nq + 4 * hi + nr < N) st1<true, true>(pc + (size_t)nr * ldc + offc, acc[r]);
+      }
+    }
+    __syncthreads(); // all reads of the images are done before the next item is parked
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// smm_f64_mfma_wg: the fp64 member: v_mfma_f64_16x16x4_f64 (probed to be the k-ordered fma chain bit for bit,
+// tools/probe/mfma_f64_chain.hip), 2x2 tiles of 16x16 per wave, step s feeds k = 4s + q (q = lane >> 4); B is the first
+// operand, so register r of lane (i, q) is C[n = q + 4r][m = i] of a tile: 128-byte rows. Images k-major, only the
+// 4*ceil(K/4) rows in use are allocated (dynamic LDS: 1 KiB per k), so shorter K leave room for a third work-group per CU:
+//   A: word k*64 + (m ^ 16(k&1));  B: word k*64 + (n ^ ((k>>1)&15) ^ 16(k&1))
+// K is padded to a multiple of four with A = -0, B = +0 (see above).
+// ---------------------------------------------------------------------------------------------------------------
+template<bool BETA0>
+__global__ __launch_bounds__(256, 3)
+void smm_f64_mfma_wg_kernel(DevAddr ad, int M, int N, int K, int lda, int ldb, int ldc, long long batch)
+{
+  extern __shared__ __align__(16) double lds64[];
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63, i = lane & 15, q = lane >> 4;
+  const int mq = wave & 1, nq = wave >> 1;
+  const int ksteps = (K + 3) >> 2, kp = 4 * ksteps;
+  double* const As = lds64;
+  double* const Bs = lds64 + kp * 64;
+  const int m0 = 32 * mq + i, n0 = 32 * nq + i;
+  const bool tm1 = (32 * mq + 16 < M), tn1 = (32 * nq + 16 < N);
+  const bool active = (32 * mq < M) && (32 * nq < N); // the wave's quadrant holds part of C
+  long long item = blockIdx.x;
+  if (item >= batch) return; // the whole work-group
+
+  double ra[16], rb[16], rc[16];
+  const unsigned offa = (unsigned)(wave * lda + lane), offb = (unsigned)(wave * ldb + lane);
+  const unsigned offc = (unsigned)((32 * nq + q) * ldc + m0);
+  typedef const __attribute__((address_space(1))) double* gcptr;
+  typedef __attribute__((address_space(1))) double* gptr;
+  auto load_ab = [&](long long it) {
+    const double* const pa = wave_uniform(addr_a<double>(ad, it));
+    const double* const pb = wave_uniform(addr_b<double>(ad, it));
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { // element (row = lane, column = 4j + wave) of the 64x64 frame
+      const int col = 4 * j + wave;
+      ra[j] = (lane < M && col < K) ? __builtin_nontemporal_load((gcptr)(pa + (size_t)(4 * j) * lda + offa)) : -0.0;
+      rb[j] = (lane < K && col < N) ? __builtin_nontemporal_load((gcptr)(pb + (size_t)(4 * j) * ldb + offb)) : 0.0;
+    }
+  };
+  // C element e = 8 tn + 4 tm + r: n = 32 nq + 16 tn + q + 4r, m = 32 mq + 16 tm + i
+  auto load_c = [&](const double* pc0) {
+    const double* const pc = wave_uniform(pc0);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int nr = 16 * (e >> 3) + 4 * (e & 3), mr = 16 * ((e >> 2) & 1);
+      rc[e] = (m0 + mr < M && 32 * nq + q + nr < N) ? __builtin_nontemporal_load((gcptr)(pc + (size_t)nr * ldc + mr + offc)) : 0.0;
+    }
+  };
+  load_ab(item);
+  if (!BETA0 && active) load_c(addr_c<double>(ad, item));
+  for (; item < batch; item += gridDim.x) {
+    double* const pc = wave_uniform(addr_c<double>(ad, item));
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int col = 4 * j + wave;
+      if (col < kp) As[col * 64 + (lane ^ ((col & 1) << 4))] = ra[j];                                      // A[m = lane][k = col]
+      if (lane < kp) Bs[lane * 64 + (col ^ ((lane >> 1) & 15) ^ ((lane & 1) << 4))] = rb[j];               // B[k = lane][n = col]
+    }
+    f64x4 acc[2][2]; // [tn][tm]
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e >> 3][(e >> 2) & 1][e & 3] = BETA0 ? 0.0 : rc[e];
+    const long long next = item + gridDim.x;
+    if (next < batch) {
+      load_ab(next);
+      if (!BETA0 && active) load_c(addr_c<double>(ad, next));
+    }
+    __syncthreads();
+    if (active) {
+      for (int s = 0; s < ksteps; ++s) {
+        const int k = 4 * s + q, sa = (q & 1) << 4, sb = ((2 * s + (q >> 1)) & 15) ^ sa;
+        const double a0 = As[k * 64 + (m0 ^ sa)], b0 = Bs[k * 64 + (n0 ^ sb)];
+        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, a0, acc[0][0], 0, 0, 0);
+        if (tm1) {
+          const double a1 = As[k * 64 + ((m0 + 16) ^ sa)];
+          acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, a1, acc[0][1], 0, 0, 0);
+          if (tn1) {
+            const double b1 = Bs[k * 64 + ((n0 + 16) ^ sb)];
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a1, acc[1][1], 0, 0, 0);
+          }
+        }
+        else if (tn1) {
+          const double b1 = Bs[k * 64 + ((n0 + 16) ^ sb)];
+          acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a0, acc[1][0], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int nr = 16 * (e >> 3) + 4 * (e & 3), mr = 16 * ((e >> 2) & 1);
+        if (m0 + mr < M && 32 * nq + q + nr < N) __builtin_nontemporal_store(acc[e >> 3][(e >> 2) & 1][e & 3], (gptr)(pc + (size_t)nr * ldc + mr + offc));
       }
     }
     __syncthreads(); // all reads of the images are done before the next item is parked
@@ -524,19 +539,7 @@ int launch_smm_special(const SmmBatch& s, void* stream, const char** name)
     if (1 == variant) return (0 != nt) ? launch_smm32<true, true>(s, st, (unsigned)blocks, name) : launch_smm32<false, true>(s, st, (unsigned)blocks, name);
     return (0 != nt) ? launch_smm32<true, false>(s, st, (unsigned)blocks, name) : launch_smm32<false, false>(s, st, (unsigned)blocks, name);
   }
-  if (is_smm64(s, 8) && 0 != env_int("XSMM_SMM64_MFMA", 1)) {
-    const int bpc = env_int("XSMM_SMM64_BPC", 2);
-    long long blocks = s.batch;
-    const long long resident = 256LL * (bpc > 0 ? bpc : 2);
-    if (blocks > resident) blocks = resident;
-    if (blocks < 1) return -1;
-    const DevAddr ad = make_addr(s);
-    *name = "smm_f64_64x64x64_mfma";
-    if (0 != (s.flags & LIBXSMM_GEMM_FLAG_BETA_0)) hipLaunchKernelGGL((smm64_f64_mfma_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, st, ad, s.batch);
-    else hipLaunchKernelGGL((smm64_f64_mfma_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, st, ad, s.batch);
-    return (int)hipGetLastError();
-  }
-  if (is_smm64(s, 4) && 0 != env_int("XSMM_SMM64_MFMA", 1)) {
+  if (is_smm64(s, 4) && 0 != env_int("XSMM_SMM64_MFMA", 1) && 0 != env_int("XSMM_SMM64_TIGHT", 1)) {
     const int bpc = env_int("XSMM_SMM64_BPC", 4);
     long long blocks = s.batch;
     const long long resident = 256LL * (bpc > 0 ? bpc : 3);
@@ -560,6 +563,31 @@ int launch_smm_special(const SmmBatch& s, void* stream, const char** name)
     *name = "smm_f32_mfma_wg";
     if (0 != (s.flags & LIBXSMM_GEMM_FLAG_BETA_0)) hipLaunchKernelGGL((smm_f32_mfma_wg_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, st, ad, s.m, s.n, s.k, s.lda, s.ldb, s.ldc, s.batch);
     else hipLaunchKernelGGL((smm_f32_mfma_wg_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, st, ad, s.m, s.n, s.k, s.lda, s.ldb, s.ldc, s.batch);
+    return (int)hipGetLastError();
+  }
+  if (8 == s.typesize && (32 < s.m || 32 < s.n) && s.m <= 64 && s.n <= 64 && 0 < s.k && s.k <= 64 && s.lda >= s.m && s.ldb >= s.k && s.ldc >= s.m
+    && 0 == (s.flags & LIBXSMM_GEMM_FLAG_TRANS_B) && SYNC_NONE == s.sync && 0 == s.general && 0 != s.use_mfma && 0 != env_int("XSMM_SMM64_MFMA", 1))
+  {
+    const size_t lds = (size_t)2 * (4 * ((s.k + 3) / 4)) * 64 * sizeof(double);
+    int fit = (int)((160u * 1024u) / lds);
+    if (fit > 3) fit = 3;
+    // long K leaves room for two work-groups per CU only: thin items are then better off on the register-tiled form
+    // (64x32x64: 48 % here, 53 % there; 64x64x64: 65 % here, 56 % there)
+    if (fit < 3 && s.m * s.n <= 3072 && 0 == env_int("XSMM_SMM64_ALWAYS", 0)) return -1;
+    const int bpc = env_int("XSMM_SMM64_BPC", fit);
+    long long blocks = s.batch;
+    const long long resident = 256LL * (bpc > 0 ? bpc : fit);
+    if (blocks > resident) blocks = resident;
+    if (blocks < 1) return -1;
+    const DevAddr ad = make_addr(s);
+    *name = "smm_f64_mfma_wg";
+    static std::once_flag once; // more than 64 KiB of dynamic LDS has to be asked for
+    std::call_once(once, []() {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&smm_f64_mfma_wg_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&smm_f64_mfma_wg_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    });
+    if (0 != (s.flags & LIBXSMM_GEMM_FLAG_BETA_0)) hipLaunchKernelGGL((smm_f64_mfma_wg_kernel<true>), dim3((unsigned)blocks), dim3(256), lds, st, ad, s.m, s.n, s.k, s.lda, s.ldb, s.ldc, s.batch);
+    else hipLaunchKernelGGL((smm_f64_mfma_wg_kernel<false>), dim3((unsigned)blocks), dim3(256), lds, st, ad, s.m, s.n, s.k, s.lda, s.ldb, s.ldc, s.batch);
     return (int)hipGetLastError();
   }
   return -1;

@@ -143,11 +143,11 @@ def test_smm64_mfma(xs, orc, torch_gpu, dtype, beta, mode):
         out = dc.cpu().numpy()
     finally:
         xs.lib().libxsmm_amd_set_mfma(old)
-    assert xs.last_kernel() == ("smm_f64_64x64x64_mfma" if dtype == np.float64 else "smm_f32_64x64x64_mfma"), xs.last_kernel()
+    assert xs.last_kernel() == ("smm_f64_mfma_wg" if dtype == np.float64 else "smm_f32_64x64x64_mfma"), xs.last_kernel()
     assert np.array_equal(out, ref)
 
 
-MFMA_WG_SHAPES = [  # fp32, 32 < max(M, N) <= 64, K <= 64: tight and with gaps, odd K (padded step), thin quadrants
+MFMA_WG_SHAPES = [  # 32 < max(M, N) <= 64, K <= 64: tight and with gaps, odd K (padded step), thin quadrants
     (64, 64, 64, 72, 64, 64), (48, 48, 48, 48, 48, 48), (40, 64, 17, 40, 17, 44), (64, 16, 32, 64, 32, 64),
     (16, 64, 64, 16, 64, 16), (33, 33, 33, 33, 33, 33), (64, 8, 24, 64, 24, 64), (57, 39, 1, 57, 1, 57), (43, 9, 27, 48, 32, 48),
 ]
@@ -155,14 +155,16 @@ MFMA_WG_SHAPES = [  # fp32, 32 < max(M, N) <= 64, K <= 64: tight and with gaps, 
 
 @pytest.mark.parametrize("shape", MFMA_WG_SHAPES)
 @pytest.mark.parametrize("beta", [1.0, 0.0])
-def test_smm_f32_mfma_wg(xs, orc, torch_gpu, shape, beta):
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_smm_mfma_wg(xs, orc, torch_gpu, monkeypatch, dtype, shape, beta):
     """The general matrix-core kernel (work-group per item) against the oracle's fma chain, bit for bit -- including the sign of
     zeros: a batch of all-zero A with C = -0 (the padded k step of an odd K must not turn -0 into +0)."""
     torch = torch_gpu
     m, n, k, lda, ldb, ldc = shape
     batch = 1100
+    monkeypatch.setenv("XSMM_SMM64_ALWAYS", "1")  # fp64: thin items with long K would otherwise go to the register-tiled form
     rng = np.random.default_rng(99 + m + 64 * n + k)
-    a, b, c, asz, bsz, csz = make_inputs(rng, np.float32, batch, m, n, k, lda, ldb, ldc, False, False, orc)
+    a, b, c, asz, bsz, csz = make_inputs(rng, dtype, batch, m, n, k, lda, ldb, ldc, False, False, orc)
     a[:3 * asz] = 0.0
     c[:2 * csz] = -0.0
     b[:bsz] = -np.abs(b[:bsz])
@@ -176,14 +178,15 @@ def test_smm_f32_mfma_wg(xs, orc, torch_gpu, shape, beta):
     old = xs.lib().libxsmm_amd_set_mfma(1)
     try:
         da, db, dc = (torch.from_numpy(x).cuda() for x in (a, b, c))
-        blob, desc = xs.descriptor(xs.F32, m, n, k, lda, ldb, ldc, 1.0, beta)
+        blob, desc = xs.descriptor(xs.F64 if dtype == np.float64 else xs.F32, m, n, k, lda, ldb, ldc, 1.0, beta)
         assert 0 == xs.lib().libxsmm_amd_gemm_batch_strided(desc, xs.dptr(da), xs.dptr(db), xs.dptr(dc), asz, bsz, csz, batch)
         torch.cuda.synchronize()
         out = dc.cpu().numpy()
     finally:
         xs.lib().libxsmm_amd_set_mfma(old)
-    assert xs.last_kernel() == "smm_f32_mfma_wg", xs.last_kernel()
-    assert np.array_equal(out.view(np.uint32), ref.view(np.uint32))
+    assert xs.last_kernel() == ("smm_f64_mfma_wg" if dtype == np.float64 else "smm_f32_mfma_wg"), xs.last_kernel()
+    bits = np.uint64 if dtype == np.float64 else np.uint32
+    assert np.array_equal(out.view(bits), ref.view(bits))
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])

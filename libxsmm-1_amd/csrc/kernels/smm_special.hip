@@ -288,7 +288,7 @@ template<typename T> __device__ __forceinline__ T* wave_uniform(T* p)
 
 template<bool BETA0>
 __global__ __launch_bounds__(256, 4)
-void smm_f32_mfma_wg_kernel(DevAddr ad, int M, int N, int K, int lda, int ldb, int ldc, long long batch)
+void smm_f32_mfma_wg_kernel(DevAddr ad, int M, int N, int K, int lda, int ldb, int ldc, long long batch, int runlen)
 {
   __shared__ __align__(16) float As[4096];
   __shared__ __align__(16) float Bs[4096];
@@ -297,8 +297,12 @@ void smm_f32_mfma_wg_kernel(DevAddr ad, int M, int N, int K, int lda, int ldb, i
   const int m = 32 * mq + lo, n = 32 * nq + lo;
   const int ksteps = (K + 1) >> 1;
   const bool active = (32 * mq < M) && (32 * nq < N); // the wave's quadrant holds part of C
-  long long item = blockIdx.x;
-  if (item >= batch) return; // the whole work-group
+  // A unit is a run of `runlen` consecutive items with one C block (blocked GEMM: the k blocks of a C block); C stays in the
+  // accumulators across the run. runlen = 1: independent items.
+  const long long nunits = batch / runlen;
+  long long unit = blockIdx.x;
+  int r0 = 0; // position inside the run
+  if (unit >= nunits) return; // the whole work-group
 
   float ra[16], rb[16], rc[16];
   const unsigned offa = (unsigned)(wave * lda + lane), offb = (unsigned)(wave * ldb + lane);
@@ -321,23 +325,27 @@ void smm_f32_mfma_wg_kernel(DevAddr ad, int M, int N, int K, int lda, int ldb, i
       rc[r] = (m < M && 32 * nq + 4 * hi + nr < N) ? ld1<true, true>(pc + (size_t)nr * ldc + offc) : 0.f;
     }
   };
-  load_ab(item);
-  if (!BETA0 && active) load_c(addr_c<float>(ad, item));
-  for (; item < batch; item += gridDim.x) {
-    float* const pc = wave_uniform(addr_c<float>(ad, item));
+  load_ab(unit * runlen);
+  if (!BETA0 && active) load_c(addr_c<float>(ad, unit * runlen));
+  f32x16 acc;
+  for (;;) {
+    const long long item = unit * runlen + r0;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       const int col = 4 * j + wave;
       As[col * 64 + (lane ^ ((col & 1) << 5))] = ra[j];                         // A[m = lane][k = col]
       Bs[lane * 64 + (col ^ (lane >> 1) ^ ((lane & 1) << 5))] = rb[j];          // B[k = lane][n = col]
     }
-    f32x16 acc;
+    if (0 == r0) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = BETA0 ? 0.f : rc[r];
-    const long long next = item + gridDim.x;
-    if (next < batch) {
-      load_ab(next);
-      if (!BETA0 && active) load_c(addr_c<float>(ad, next));
+      for (int r = 0; r < 16; ++r) acc[r] = BETA0 ? 0.f : rc[r];
+    }
+    int r1 = r0 + 1; long long unit1 = unit;
+    if (r1 == runlen) { r1 = 0; unit1 += gridDim.x; }
+    const bool more = unit1 < nunits;
+    if (more) {
+      load_ab(unit1 * runlen + r1);
+      if (!BETA0 && active && 0 == r1) load_c(addr_c<float>(ad, unit1 * runlen));
     }
     __syncthreads();
     if (active) {
@@ -347,13 +355,18 @@ void smm_f32_mfma_wg_kernel(DevAddr ad, int M, int N, int K, int lda, int ldb, i
         const float bv = Bs[k * 64 + (n ^ s ^ (hi << 5))];   // B[k][n]
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bv, av, acc, 0, 0, 0);
       }
+      if (r0 + 1 == runlen) {
+        float* const pc = wave_uniform(addr_c<float>(ad, item));
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int nr = (r & 3) + 8 * (r >> 2);
-        if (m < M && 32 * nq + 4 * hi + nr < N) st1<true, true>(pc + (size_t)nr * ldc + offc, acc[r]);
+        for (int r = 0; r < 16; ++r) {
+          const int nr = (r & 3) + 8 * (r >> 2);
+          if (m < M && 32 * nq + 4 * hi + nr < N) st1<true, true>(pc + (size_t)nr * ldc + offc, acc[r]);
+        }
       }
     }
     __syncthreads(); // all reads of the images are done before the next item is parked
+    if (!more) break;
+    unit = unit1; r0 = r1;
   }
 }
 
@@ -367,7 +380,7 @@ void smm_f32_mfma_wg_kernel(DevAddr ad, int M, int N, int K, int lda, int ldb, i
 // ---------------------------------------------------------------------------------------------------------------
 template<bool BETA0>
 __global__ __launch_bounds__(256, 3)
-void smm_f64_mfma_wg_kernel(DevAddr ad, int M, int N, int K, int lda, int ldb, int ldc, long long batch)
+void smm_f64_mfma_wg_kernel(DevAddr ad, int M, int N, int K, int lda, int ldb, int ldc, long long batch, int runlen)
 {
   extern __shared__ __align__(16) double lds64[];
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63, i = lane & 15, q = lane >> 4;
@@ -378,8 +391,12 @@ void smm_f64_mfma_wg_kernel(DevAddr ad, int M, int N, int K, int lda, int ldb, i
   const int m0 = 32 * mq + i, n0 = 32 * nq + i;
   const bool tm1 = (32 * mq + 16 < M), tn1 = (32 * nq + 16 < N);
   const bool active = (32 * mq < M) && (32 * nq < N); // the wave's quadrant holds part of C
-  long long item = blockIdx.x;
-  if (item >= batch) return; // the whole work-group
+  // A unit is a run of `runlen` consecutive items with one C block (blocked GEMM: the k blocks of a C block); C stays in the
+  // accumulators across the run. runlen = 1: independent items.
+  const long long nunits = batch / runlen;
+  long long unit = blockIdx.x;
+  int r0 = 0; // position inside the run
+  if (unit >= nunits) return; // the whole work-group
 
   double ra[16], rb[16], rc[16];
   const unsigned offa = (unsigned)(wave * lda + lane), offb = (unsigned)(wave * ldb + lane);
@@ -405,23 +422,27 @@ void smm_f64_mfma_wg_kernel(DevAddr ad, int M, int N, int K, int lda, int ldb, i
       rc[e] = (m0 + mr < M && 32 * nq + q + nr < N) ? __builtin_nontemporal_load((gcptr)(pc + (size_t)nr * ldc + mr + offc)) : 0.0;
     }
   };
-  load_ab(item);
-  if (!BETA0 && active) load_c(addr_c<double>(ad, item));
-  for (; item < batch; item += gridDim.x) {
-    double* const pc = wave_uniform(addr_c<double>(ad, item));
+  load_ab(unit * runlen);
+  if (!BETA0 && active) load_c(addr_c<double>(ad, unit * runlen));
+  f64x4 acc[2][2]; // [tn][tm]
+  for (;;) {
+    const long long item = unit * runlen + r0;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       const int col = 4 * j + wave;
       if (col < kp) As[col * 64 + (lane ^ ((col & 1) << 4))] = ra[j];                                      // A[m = lane][k = col]
       if (lane < kp) Bs[lane * 64 + (col ^ ((lane >> 1) & 15) ^ ((lane & 1) << 4))] = rb[j];               // B[k = lane][n = col]
     }
-    f64x4 acc[2][2]; // [tn][tm]
+    if (0 == r0) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e >> 3][(e >> 2) & 1][e & 3] = BETA0 ? 0.0 : rc[e];
-    const long long next = item + gridDim.x;
-    if (next < batch) {
-      load_ab(next);
-      if (!BETA0 && active) load_c(addr_c<double>(ad, next));
+      for (int e = 0; e < 16; ++e) acc[e >> 3][(e >> 2) & 1][e & 3] = BETA0 ? 0.0 : rc[e];
+    }
+    int r1 = r0 + 1; long long unit1 = unit;
+    if (r1 == runlen) { r1 = 0; unit1 += gridDim.x; }
+    const bool more = unit1 < nunits;
+    if (more) {
+      load_ab(unit1 * runlen + r1);
+      if (!BETA0 && active && 0 == r1) load_c(addr_c<double>(ad, unit1 * runlen));
     }
     __syncthreads();
     if (active) {
@@ -443,13 +464,18 @@ void smm_f64_mfma_wg_kernel(DevAddr ad, int M, int N, int K, int lda, int ldb, i
           acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a0, acc[1][0], 0, 0, 0);
         }
       }
+      if (r0 + 1 == runlen) {
+        double* const pc = wave_uniform(addr_c<double>(ad, item));
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int nr = 16 * (e >> 3) + 4 * (e & 3), mr = 16 * ((e >> 2) & 1);
-        if (m0 + mr < M && 32 * nq + q + nr < N) __builtin_nontemporal_store(acc[e >> 3][(e >> 2) & 1][e & 3], (gptr)(pc + (size_t)nr * ldc + mr + offc));
+        for (int e = 0; e < 16; ++e) {
+          const int nr = 16 * (e >> 3) + 4 * (e & 3), mr = 16 * ((e >> 2) & 1);
+          if (m0 + mr < M && 32 * nq + q + nr < N) __builtin_nontemporal_store(acc[e >> 3][(e >> 2) & 1][e & 3], (gptr)(pc + (size_t)nr * ldc + mr + offc));
+        }
       }
     }
     __syncthreads(); // all reads of the images are done before the next item is parked
+    if (!more) break;
+    unit = unit1; r0 = r1;
   }
 }
 
@@ -503,6 +529,16 @@ bool is_smm64(const SmmBatch& s, int typesize)
       && 0 == (s.flags & LIBXSMM_GEMM_FLAG_TRANS_B) && SYNC_NONE == s.sync && 0 == s.general && 0 != s.use_mfma;
 }
 
+// Work units of the matrix-core work-group kernels: independent items, or runs of a fixed length the caller vouches for
+// (blocked GEMM: the k blocks of a C block follow each other). 0: not for these kernels.
+long long mfma_wg_units(const SmmBatch& s)
+{
+  if (SYNC_NONE == s.sync) return s.batch;
+  if (SYNC_RUNS == s.sync && 0 < s.uniform_run && 0 == s.batch % s.uniform_run) return s.batch / s.uniform_run;
+  return 0;
+}
+int mfma_wg_runlen(const SmmBatch& s) { return SYNC_NONE == s.sync ? 1 : s.uniform_run; }
+
 template<bool NT, bool GLB>
 int launch_smm32(const SmmBatch& s, hipStream_t st, unsigned blocks, const char** name)
 {
@@ -552,21 +588,22 @@ int launch_smm_special(const SmmBatch& s, void* stream, const char** name)
     return (int)hipGetLastError();
   }
   if (4 == s.typesize && (32 < s.m || 32 < s.n) && s.m <= 64 && s.n <= 64 && 0 < s.k && s.k <= 64 && s.lda >= s.m && s.ldb >= s.k && s.ldc >= s.m
-    && 0 == (s.flags & LIBXSMM_GEMM_FLAG_TRANS_B) && SYNC_NONE == s.sync && 0 == s.general && 0 != s.use_mfma && 0 != env_int("XSMM_SMM64_MFMA", 1))
+    && 0 == (s.flags & LIBXSMM_GEMM_FLAG_TRANS_B) && mfma_wg_units(s) > 0 && 0 == s.general && 0 != s.use_mfma && 0 != env_int("XSMM_SMM64_MFMA", 1))
   {
     const int bpc = env_int("XSMM_SMM64_BPC", 4);
-    long long blocks = s.batch;
+    long long blocks = mfma_wg_units(s);
     const long long resident = 256LL * (bpc > 0 ? bpc : 4);
     if (blocks > resident) blocks = resident;
     if (blocks < 1) return -1;
     const DevAddr ad = make_addr(s);
-    *name = "smm_f32_mfma_wg";
-    if (0 != (s.flags & LIBXSMM_GEMM_FLAG_BETA_0)) hipLaunchKernelGGL((smm_f32_mfma_wg_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, st, ad, s.m, s.n, s.k, s.lda, s.ldb, s.ldc, s.batch);
-    else hipLaunchKernelGGL((smm_f32_mfma_wg_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, st, ad, s.m, s.n, s.k, s.lda, s.ldb, s.ldc, s.batch);
+    const int runlen = mfma_wg_runlen(s);
+    *name = (1 == runlen) ? "smm_f32_mfma_wg" : "smm_f32_mfma_wg_runs";
+    if (0 != (s.flags & LIBXSMM_GEMM_FLAG_BETA_0)) hipLaunchKernelGGL((smm_f32_mfma_wg_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, st, ad, s.m, s.n, s.k, s.lda, s.ldb, s.ldc, s.batch, runlen);
+    else hipLaunchKernelGGL((smm_f32_mfma_wg_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, st, ad, s.m, s.n, s.k, s.lda, s.ldb, s.ldc, s.batch, runlen);
     return (int)hipGetLastError();
   }
   if (8 == s.typesize && (32 < s.m || 32 < s.n) && s.m <= 64 && s.n <= 64 && 0 < s.k && s.k <= 64 && s.lda >= s.m && s.ldb >= s.k && s.ldc >= s.m
-    && 0 == (s.flags & LIBXSMM_GEMM_FLAG_TRANS_B) && SYNC_NONE == s.sync && 0 == s.general && 0 != s.use_mfma && 0 != env_int("XSMM_SMM64_MFMA", 1))
+    && 0 == (s.flags & LIBXSMM_GEMM_FLAG_TRANS_B) && mfma_wg_units(s) > 0 && 0 == s.general && 0 != s.use_mfma && 0 != env_int("XSMM_SMM64_MFMA", 1))
   {
     const size_t lds = (size_t)2 * (4 * ((s.k + 3) / 4)) * 64 * sizeof(double);
     int fit = (int)((160u * 1024u) / lds);
@@ -575,19 +612,20 @@ int launch_smm_special(const SmmBatch& s, void* stream, const char** name)
     // (64x32x64: 48 % here, 53 % there; 64x64x64: 65 % here, 56 % there)
     if (fit < 3 && s.m * s.n <= 3072 && 0 == env_int("XSMM_SMM64_ALWAYS", 0)) return -1;
     const int bpc = env_int("XSMM_SMM64_BPC", fit);
-    long long blocks = s.batch;
+    long long blocks = mfma_wg_units(s);
     const long long resident = 256LL * (bpc > 0 ? bpc : fit);
     if (blocks > resident) blocks = resident;
     if (blocks < 1) return -1;
     const DevAddr ad = make_addr(s);
-    *name = "smm_f64_mfma_wg";
+    const int runlen = mfma_wg_runlen(s);
+    *name = (1 == runlen) ? "smm_f64_mfma_wg" : "smm_f64_mfma_wg_runs";
     static std::once_flag once; // more than 64 KiB of dynamic LDS has to be asked for
     std::call_once(once, []() {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&smm_f64_mfma_wg_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&smm_f64_mfma_wg_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     });
-    if (0 != (s.flags & LIBXSMM_GEMM_FLAG_BETA_0)) hipLaunchKernelGGL((smm_f64_mfma_wg_kernel<true>), dim3((unsigned)blocks), dim3(256), lds, st, ad, s.m, s.n, s.k, s.lda, s.ldb, s.ldc, s.batch);
-    else hipLaunchKernelGGL((smm_f64_mfma_wg_kernel<false>), dim3((unsigned)blocks), dim3(256), lds, st, ad, s.m, s.n, s.k, s.lda, s.ldb, s.ldc, s.batch);
+    if (0 != (s.flags & LIBXSMM_GEMM_FLAG_BETA_0)) hipLaunchKernelGGL((smm_f64_mfma_wg_kernel<true>), dim3((unsigned)blocks), dim3(256), lds, st, ad, s.m, s.n, s.k, s.lda, s.ldb, s.ldc, s.batch, runlen);
+    else hipLaunchKernelGGL((smm_f64_mfma_wg_kernel<false>), dim3((unsigned)blocks), dim3(256), lds, st, ad, s.m, s.n, s.k, s.lda, s.ldb, s.ldc, s.batch, runlen);
     return (int)hipGetLastError();
   }
   return -1;

@@ -175,6 +175,7 @@ void bgemm_run(const libxsmm_blocked_gemm_handle* h, const void* a, const void* 
   s.mode = ADDR_INDEX; s.a = da; s.b = db; s.c = dc; s.ia = h->d_ia; s.ib = h->d_ib; s.ic = h->d_ic;
   s.index_base = 0; s.index_stride = (int)sizeof(int); s.batch = h->nitems; s.sync = SYNC_RUNS;
   s.use_mfma = libxsmm_amd_get_mfma(); s.alpha = 1; s.beta = 1;
+  s.uniform_run = h->kb; // every C block's k blocks follow each other in the work list
   const char* name = "";
   int e = launch_smm_special(s, device().stream, &name);
   if (e < 0) {

@@ -125,7 +125,8 @@ def test_blocked_permutations(xs, orc, torch_gpu, dtype, geom):
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("geom", [(256, 192, 320, 32, 32, 32), (256, 128, 384, 64, 64, 64), (192, 192, 192, 48, 24, 16), (128, 128, 4096, 32, 32, 32)])
-def test_blocked_gemm_on_the_specialised_run_kernels(xs, torch_gpu, dtype, geom):
+@pytest.mark.parametrize("mfma", [0, 1])
+def test_blocked_gemm_on_the_specialised_run_kernels(xs, torch_gpu, dtype, geom, mfma):
     """Large block GEMMs run on the hiprtc-specialised run kernels (wave / work-group per C block, segments for few long runs,
     the work-group-per-item form with uniform runs for blocks up to 64): forced here for small problems; compared with the
     plain GEMM the reference's sample checks against (samples/blocked_gemm/blocked_gemm.c:181). (128 x 128 x 4096: 16 C
@@ -139,7 +140,7 @@ def test_blocked_gemm_on_the_specialised_run_kernels(xs, torch_gpu, dtype, geom)
     L = xs.lib()
     old_env = os.environ.get("LIBXSMM_AMD_JIT_MINBATCH")
     os.environ["LIBXSMM_AMD_JIT_MINBATCH"] = "1"
-    old = L.libxsmm_amd_set_mfma(0)
+    old = L.libxsmm_amd_set_mfma(mfma)  # on: blocks beyond 32 go to the matrix-core work-group kernel, a run of k blocks per unit
     try:
         ibm, ibn, ibk, one, iorder = (C.c_int(v) for v in (bm, bn, bk, 1, 0))
         al = (C.c_double if ts == 8 else C.c_float)(1.0); be = (C.c_double if ts == 8 else C.c_float)(1.0)
@@ -154,7 +155,7 @@ def test_blocked_gemm_on_the_specialised_run_kernels(xs, torch_gpu, dtype, geom)
         assert 0 == L.libxsmm_blocked_gemm_copyin_c(h, xs.dptr(dc), C.byref(ldm), xs.dptr(bc))
         L.libxsmm_blocked_gemm_st(h, xs.dptr(ba), xs.dptr(bb), xs.dptr(bc), 0, 0)
         torch.cuda.synchronize()
-        assert "_jit_shape" in xs.last_kernel(), xs.last_kernel()
+        assert ("_mfma_wg_runs" if (mfma and max(bm, bn) > 32) else "_jit_shape") in xs.last_kernel(), xs.last_kernel()
         out = torch.empty_like(dc)
         assert 0 == L.libxsmm_blocked_gemm_copyout_c(h, xs.dptr(bc), C.byref(ldm), xs.dptr(out))
         torch.cuda.synchronize()

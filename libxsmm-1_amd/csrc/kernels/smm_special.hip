@@ -139,17 +139,18 @@ void smm32_f32_fma_kernel(DevAddr ad, long long batch)
 // dword per lane, two full 128-byte rows per wave instruction. (The transposed operand order, where C moves as four
 // 16-byte pieces per lane, was measured 15-40 % slower and has been removed.)
 // ---------------------------------------------------------------------------------------------------------------
-template<bool BETA0, bool NT, bool GLB>
+template<bool BETA0, bool NT, bool GLB, bool RUNS>
 __global__ __launch_bounds__(256, 4)
-void smm32_f32_mfma_kernel(DevAddr ad, long long batch)
-{
+void smm32_f32_mfma_kernel(DevAddr ad, long long batch, int runlen)
+{ // RUNS: a unit is a run of `runlen` consecutive items with one C block (blocked GEMM), C stays in the accumulators
   __shared__ __align__(16) float lds[4][2048];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int lo = lane & 31, hi = lane >> 5;
   float* const As = lds[wave];
   float* const Bs = lds[wave] + 1024;
   const long long w = (long long)blockIdx.x * 4 + wave, W = (long long)gridDim.x * 4;
-  if (w >= batch) return;
+  const long long nunits = RUNS ? batch / runlen : batch;
+  if (w >= nunits) return;
   const int coff = 4 * hi * 32 + lo; // lane's first C element
 
   f32x4 ra[4], rb[4];
@@ -158,20 +159,30 @@ void smm32_f32_mfma_kernel(DevAddr ad, long long batch)
 #pragma unroll
     for (int r = 0; r < 16; ++r) rc[r] = ld1<NT, GLB>(pc + ((r & 3) + 8 * (r >> 2)) * 32);
   };
-  load_mat32<NT, GLB>(addr_a<float>(ad, w), lane, ra);
-  load_mat32<NT, GLB>(addr_b<float>(ad, w), lane, rb);
-  if (!BETA0) load_c(addr_c<float>(ad, w) + coff);
-  for (long long item = w; item < batch; item += W) {
-    float* const pc = addr_c<float>(ad, item) + coff;
+  long long unit = w;
+  int r0 = 0; // position inside the run
+  {
+    const long long first = RUNS ? unit * runlen : unit;
+    load_mat32<NT, GLB>(addr_a<float>(ad, first), lane, ra);
+    load_mat32<NT, GLB>(addr_b<float>(ad, first), lane, rb);
+    if (!BETA0) load_c(addr_c<float>(ad, first) + coff);
+  }
+  f32x16 acc;
+  for (;;) {
+    const long long item = RUNS ? unit * runlen + r0 : unit;
     park_ab<1>(As, Bs, lane, ra, rb);
-    f32x16 acc;
+    if (!RUNS || 0 == r0) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = BETA0 ? 0.f : rc[r];
-    const long long next = item + W;
-    if (next < batch) {
+      for (int r = 0; r < 16; ++r) acc[r] = BETA0 ? 0.f : rc[r];
+    }
+    int r1 = RUNS ? r0 + 1 : 0; long long unit1 = unit;
+    if (!RUNS || r1 == runlen) { r1 = 0; unit1 += W; }
+    const bool more = unit1 < nunits;
+    if (more) {
+      const long long next = RUNS ? unit1 * runlen + r1 : unit1;
       load_mat32<NT, GLB>(addr_a<float>(ad, next), lane, ra);
       load_mat32<NT, GLB>(addr_b<float>(ad, next), lane, rb);
-      if (!BETA0) load_c(addr_c<float>(ad, next) + coff);
+      if (!BETA0 && (!RUNS || 0 == r1)) load_c(addr_c<float>(ad, next) + coff);
     }
     wave_lds_sync();
     // The instruction is a k-ordered fmaf chain (one rounding per product): with the two k of step s being 2s and 2s + 1 every
@@ -185,9 +196,14 @@ void smm32_f32_mfma_kernel(DevAddr ad, long long batch)
       const float bv = (0 != hi) ? bt[s >> 1][2 * (s & 1) + 1] : bt[s >> 1][2 * (s & 1)]; // B[k = 2s + hi][n = lo]
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bv, av, acc, 0, 0, 0);
     }
+    if (!RUNS || r0 + 1 == runlen) {
+      float* const pc = addr_c<float>(ad, item) + coff;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) st1<NT, GLB>(pc + ((r & 3) + 8 * (r >> 2)) * 32, acc[r]);
+      for (int r = 0; r < 16; ++r) st1<NT, GLB>(pc + ((r & 3) + 8 * (r >> 2)) * 32, acc[r]);
+    }
     wave_lds_sync();
+    if (!more) break;
+    unit = unit1; r0 = r1;
   }
 }
 
@@ -551,8 +567,8 @@ int launch_smm32(const SmmBatch& s, hipStream_t st, unsigned blocks, const char*
   }
   else {
     *name = "smm_f32_32x32x32_mfma";
-    if (beta0) hipLaunchKernelGGL((smm32_f32_mfma_kernel<true, NT, GLB>), dim3(blocks), dim3(256), 0, st, ad, s.batch);
-    else hipLaunchKernelGGL((smm32_f32_mfma_kernel<false, NT, GLB>), dim3(blocks), dim3(256), 0, st, ad, s.batch);
+    if (beta0) hipLaunchKernelGGL((smm32_f32_mfma_kernel<true, NT, GLB, false>), dim3(blocks), dim3(256), 0, st, ad, s.batch, 1);
+    else hipLaunchKernelGGL((smm32_f32_mfma_kernel<false, NT, GLB, false>), dim3(blocks), dim3(256), 0, st, ad, s.batch, 1);
   }
   return (int)hipGetLastError();
 }
@@ -574,6 +590,21 @@ int launch_smm_special(const SmmBatch& s, void* stream, const char** name)
     if (blocks > resident) blocks = resident;
     if (1 == variant) return (0 != nt) ? launch_smm32<true, true>(s, st, (unsigned)blocks, name) : launch_smm32<false, true>(s, st, (unsigned)blocks, name);
     return (0 != nt) ? launch_smm32<true, false>(s, st, (unsigned)blocks, name) : launch_smm32<false, false>(s, st, (unsigned)blocks, name);
+  }
+  if (4 == s.typesize && 32 == s.m && 32 == s.n && 32 == s.k && 32 == s.lda && 32 == s.ldb && 32 == s.ldc && 0 == (s.flags & LIBXSMM_GEMM_FLAG_TRANS_B)
+    && SYNC_RUNS == s.sync && 0 < s.uniform_run && 0 == s.batch % s.uniform_run && 0 == s.general && 0 != s.use_mfma && 0 != env_int("XSMM_SMM32_RUNS", 1))
+  { // blocked GEMM with 32^3 blocks: a wave per C block, the k blocks of the run through the matrix cores
+    const long long units = s.batch / s.uniform_run;
+    const int bpc = env_int("XSMM_SMM32_RUNS_BPC", 4);
+    long long blocks = (units + 3) / 4;
+    const long long resident = 256LL * (bpc > 0 ? bpc : 4);
+    if (blocks > resident) blocks = resident;
+    if (blocks < 1) return -1;
+    const DevAddr ad = make_addr(s);
+    *name = "smm_f32_32x32x32_mfma_runs";
+    if (0 != (s.flags & LIBXSMM_GEMM_FLAG_BETA_0)) hipLaunchKernelGGL((smm32_f32_mfma_kernel<true, false, true, true>), dim3((unsigned)blocks), dim3(256), 0, st, ad, s.batch, s.uniform_run);
+    else hipLaunchKernelGGL((smm32_f32_mfma_kernel<false, false, true, true>), dim3((unsigned)blocks), dim3(256), 0, st, ad, s.batch, s.uniform_run);
+    return (int)hipGetLastError();
   }
   if (is_smm64(s, 4) && 0 != env_int("XSMM_SMM64_MFMA", 1) && 0 != env_int("XSMM_SMM64_TIGHT", 1)) {
     const int bpc = env_int("XSMM_SMM64_BPC", 4);

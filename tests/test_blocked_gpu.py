@@ -155,7 +155,12 @@ def test_blocked_gemm_on_the_specialised_run_kernels(xs, torch_gpu, dtype, geom,
         assert 0 == L.libxsmm_blocked_gemm_copyin_c(h, xs.dptr(dc), C.byref(ldm), xs.dptr(bc))
         L.libxsmm_blocked_gemm_st(h, xs.dptr(ba), xs.dptr(bb), xs.dptr(bc), 0, 0)
         torch.cuda.synchronize()
-        assert ("_mfma_wg_runs" if (mfma and max(bm, bn) > 32) else "_jit_shape") in xs.last_kernel(), xs.last_kernel()
+        expect = "_jit_shape"
+        if mfma and max(bm, bn) > 32:
+            expect = "_mfma_wg_runs"
+        elif mfma and ts == 4 and (bm, bn, bk) == (32, 32, 32):
+            expect = "smm_f32_32x32x32_mfma_runs"
+        assert expect in xs.last_kernel(), xs.last_kernel()
         out = torch.empty_like(dc)
         assert 0 == L.libxsmm_blocked_gemm_copyout_c(h, xs.dptr(bc), C.byref(ldm), xs.dptr(out))
         torch.cuda.synchronize()

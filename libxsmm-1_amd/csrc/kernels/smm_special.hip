@@ -287,12 +287,19 @@ void smm64_f32_mfma_kernel(DevAddr ad, long long batch)
 // smm_f32_mfma_wg: the same plan for any fp32 shape with 32 < max(M, N) <= 64 and K <= 64, any leading dimensions -- the
 // class the register-tiled work-group kernels serve at about half of the HBM peak. Operands travel as dwords (lanes along
 // a column: whole 128/256-byte rows of every column), both LDS images are k-major:
-//   A: word k*64 + (m ^ 32(k&1));  B (transposed while parking): word k*64 + (n ^ (k>>1) ^ 32(k&1))
-// (reads of the two k of a step and the transposing writes, 64 different k of one column per wave, are conflict-free).
+//   A: word k*64 + (m ^ 32(k&1));  B (transposed while parking): word k*64 + (n ^ bkey32(k)), see below.
 // K is padded to an even count with A = -0, B = +0: the extra product is -0 and x + (-0) = x for every x, signed zeros
 // included, so the chain stays the reference's. Rows m >= M and columns n >= N of the images hold the same padding; the
 // C elements they would produce are neither loaded nor stored.
 // ---------------------------------------------------------------------------------------------------------------
+// Swizzle keys of the k-major B images: word k*64 + (n ^ key(k)). The transposing writes put 64 (fp32) resp. 64 (fp64)
+// different k of one column into one instruction, the reads the two (fp32) resp. four (fp64) k of an MFMA step with 32 resp.
+// 16 neighbouring n each. The LDS serves a dword instruction in passes of 32 lanes and a qword instruction in passes of 16
+// (measured: keys that were only distinct over the full wave showed SQ_LDS_BANK_CONFLICT), so the low bits of the key
+// follow k itself and one more bit separates the k of a step as well as the two halves of the wave.
+__device__ __forceinline__ int bkey32(int k) { return (k & 31) | ((((k >> 5) ^ k) & 1) << 5); }
+__device__ __forceinline__ int bkey64(int k) { return (k & 15) | ((((k >> 4) ^ k) & 1) << 4); }
+
 // The operands of an item are the same for the whole work-group: with the base in scalar registers a load is "scalar base
 // + one 32-bit lane offset", and the 48 loads of an item share three offset registers instead of holding 48 addresses.
 template<typename T> __device__ __forceinline__ T* wave_uniform(T* p)
@@ -350,7 +357,7 @@ void smm_f32_mfma_wg_kernel(DevAddr ad, int M, int N, int K, int lda, int ldb, i
     for (int j = 0; j < 16; ++j) {
       const int col = 4 * j + wave;
       As[col * 64 + (lane ^ ((col & 1) << 5))] = ra[j];                         // A[m = lane][k = col]
-      Bs[lane * 64 + (col ^ (lane >> 1) ^ ((lane & 1) << 5))] = rb[j];          // B[k = lane][n = col]
+      Bs[lane * 64 + (col ^ bkey32(lane))] = rb[j];                               // B[k = lane][n = col]
     }
     if (0 == r0) {
 #pragma unroll
@@ -368,7 +375,7 @@ void smm_f32_mfma_wg_kernel(DevAddr ad, int M, int N, int K, int lda, int ldb, i
       for (int s = 0; s < ksteps; ++s) {
         const int k = 2 * s + hi;
         const float av = As[k * 64 + (m ^ (hi << 5))];       // A[m][k]
-        const float bv = Bs[k * 64 + (n ^ s ^ (hi << 5))];   // B[k][n]
+        const float bv = Bs[k * 64 + (n ^ bkey32(k))];       // B[k][n]
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bv, av, acc, 0, 0, 0);
       }
       if (r0 + 1 == runlen) {
@@ -391,7 +398,7 @@ void smm_f32_mfma_wg_kernel(DevAddr ad, int M, int N, int K, int lda, int ldb, i
 // tools/probe/mfma_f64_chain.hip), 2x2 tiles of 16x16 per wave, step s feeds k = 4s + q (q = lane >> 4); B is the first
 // operand, so register r of lane (i, q) is C[n = q + 4r][m = i] of a tile: 128-byte rows. Images k-major, only the
 // 4*ceil(K/4) rows in use are allocated (dynamic LDS: 1 KiB per k), so shorter K leave room for a third work-group per CU:
-//   A: word k*64 + (m ^ 16(k&1));  B: word k*64 + (n ^ ((k>>1)&15) ^ 16(k&1))
+//   A: word k*64 + (m ^ 16(k&1));  B: word k*64 + (n ^ bkey64(k))
 // K is padded to a multiple of four with A = -0, B = +0 (see above).
 // ---------------------------------------------------------------------------------------------------------------
 template<bool BETA0>
@@ -447,7 +454,7 @@ void smm_f64_mfma_wg_kernel(DevAddr ad, int M, int N, int K, int lda, int ldb, i
     for (int j = 0; j < 16; ++j) {
       const int col = 4 * j + wave;
       if (col < kp) As[col * 64 + (lane ^ ((col & 1) << 4))] = ra[j];                                      // A[m = lane][k = col]
-      if (lane < kp) Bs[lane * 64 + (col ^ ((lane >> 1) & 15) ^ ((lane & 1) << 4))] = rb[j];               // B[k = lane][n = col]
+      if (lane < kp) Bs[lane * 64 + (col ^ bkey64(lane))] = rb[j];                                         // B[k = lane][n = col]
     }
     if (0 == r0) {
 #pragma unroll
@@ -463,7 +470,7 @@ void smm_f64_mfma_wg_kernel(DevAddr ad, int M, int N, int K, int lda, int ldb, i
     __syncthreads();
     if (active) {
       for (int s = 0; s < ksteps; ++s) {
-        const int k = 4 * s + q, sa = (q & 1) << 4, sb = ((2 * s + (q >> 1)) & 15) ^ sa;
+        const int k = 4 * s + q, sa = (q & 1) << 4, sb = bkey64(k);
         const double a0 = As[k * 64 + (m0 ^ sa)], b0 = Bs[k * 64 + (n0 ^ sb)];
         acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, a0, acc[0][0], 0, 0, 0);
         if (tm1) {

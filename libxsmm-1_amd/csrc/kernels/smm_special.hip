@@ -309,7 +309,7 @@ template<typename T> __device__ __forceinline__ T* wave_uniform(T* p)
   return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
 }
 
-template<bool BETA0>
+template<bool BETA0, bool TIGHT>
 __global__ __launch_bounds__(256, 4)
 void smm_f32_mfma_wg_kernel(DevAddr ad, int M, int N, int K, int lda, int ldb, int ldc, long long batch, int runlen)
 {
@@ -327,12 +327,28 @@ void smm_f32_mfma_wg_kernel(DevAddr ad, int M, int N, int K, int lda, int ldb, i
   int r0 = 0; // position inside the run
   if (unit >= nunits) return; // the whole work-group
 
+  // TIGHT (lda = M, ldb = K, M*K and K*N multiples of four): A and B of an item are contiguous arrays and travel as 16-byte
+  // chunks (chunk c = 256j + t holds elements 4c..4c+3) -- a few wide loads instead of one dword load per column; the
+  // elements are scattered into the images one by one. Rows k >= K of the images (odd K) are written once, up front.
   float ra[16], rb[16], rc[16];
+  const int mk = M * K, kn = K * N;
+  const float rcpm = 1.0f / (float)M, rcpk = 1.0f / (float)K;
+  if (TIGHT && 0 != (K & 1)) { As[K * 64 + (t & 63)] = -0.f; Bs[K * 64 + (t & 63)] = 0.f; }
   const unsigned offa = (unsigned)(wave * lda + lane), offb = (unsigned)(wave * ldb + lane);
   const unsigned offc = (unsigned)((32 * nq + 4 * hi) * ldc + m);
   auto load_ab = [&](long long it) {
     const float* const pa = wave_uniform(addr_a<float>(ad, it));
     const float* const pb = wave_uniform(addr_b<float>(ad, it));
+    if (TIGHT) {
+      const bool ala = aligned16(pa), alb = aligned16(pb);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int e = 4 * (256 * j + t);
+        if (e < mk) { const f32x4 v = ld4<true, true>(pa + e, ala); ra[4 * j] = v[0]; ra[4 * j + 1] = v[1]; ra[4 * j + 2] = v[2]; ra[4 * j + 3] = v[3]; }
+        if (e < kn) { const f32x4 v = ld4<true, true>(pb + e, alb); rb[4 * j] = v[0]; rb[4 * j + 1] = v[1]; rb[4 * j + 2] = v[2]; rb[4 * j + 3] = v[3]; }
+      }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < 16; ++j) { // element (row = lane, column = 4j + wave) of the 64x64 frame
       const int col = 4 * j + wave;
@@ -353,6 +369,18 @@ void smm_f32_mfma_wg_kernel(DevAddr ad, int M, int N, int K, int lda, int ldb, i
   f32x16 acc;
   for (;;) {
     const long long item = unit * runlen + r0;
+    if (TIGHT) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int e = 4 * (256 * j + t) + u;
+          if (e < mk) { const int col = (int)(((float)e + 0.5f) * rcpm), row = e - col * M; As[col * 64 + (row ^ ((col & 1) << 5))] = ra[4 * j + u]; } // A[m = row][k = col]
+          if (e < kn) { const int col = (int)(((float)e + 0.5f) * rcpk), row = e - col * K; Bs[row * 64 + (col ^ bkey32(row))] = rb[4 * j + u]; }       // B[k = row][n = col]
+        }
+      }
+    }
+    else
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       const int col = 4 * j + wave;
@@ -636,8 +664,16 @@ int launch_smm_special(const SmmBatch& s, void* stream, const char** name)
     const DevAddr ad = make_addr(s);
     const int runlen = mfma_wg_runlen(s);
     *name = (1 == runlen) ? "smm_f32_mfma_wg" : "smm_f32_mfma_wg_runs";
-    if (0 != (s.flags & LIBXSMM_GEMM_FLAG_BETA_0)) hipLaunchKernelGGL((smm_f32_mfma_wg_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, st, ad, s.m, s.n, s.k, s.lda, s.ldb, s.ldc, s.batch, runlen);
-    else hipLaunchKernelGGL((smm_f32_mfma_wg_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, st, ad, s.m, s.n, s.k, s.lda, s.ldb, s.ldc, s.batch, runlen);
+    const bool beta0 = 0 != (s.flags & LIBXSMM_GEMM_FLAG_BETA_0);
+    const bool tight = s.lda == s.m && s.ldb == s.k && 0 == ((s.m * s.k) & 3) && 0 == ((s.k * s.n) & 3) && 0 != env_int("XSMM_SMM64_WIDE", 1);
+    if (tight) {
+      if (beta0) hipLaunchKernelGGL((smm_f32_mfma_wg_kernel<true, true>), dim3((unsigned)blocks), dim3(256), 0, st, ad, s.m, s.n, s.k, s.lda, s.ldb, s.ldc, s.batch, runlen);
+      else hipLaunchKernelGGL((smm_f32_mfma_wg_kernel<false, true>), dim3((unsigned)blocks), dim3(256), 0, st, ad, s.m, s.n, s.k, s.lda, s.ldb, s.ldc, s.batch, runlen);
+    }
+    else {
+      if (beta0) hipLaunchKernelGGL((smm_f32_mfma_wg_kernel<true, false>), dim3((unsigned)blocks), dim3(256), 0, st, ad, s.m, s.n, s.k, s.lda, s.ldb, s.ldc, s.batch, runlen);
+      else hipLaunchKernelGGL((smm_f32_mfma_wg_kernel<false, false>), dim3((unsigned)blocks), dim3(256), 0, st, ad, s.m, s.n, s.k, s.lda, s.ldb, s.ldc, s.batch, runlen);
+    }
     return (int)hipGetLastError();
   }
   if (8 == s.typesize && (32 < s.m || 32 < s.n) && s.m <= 64 && s.n <= 64 && 0 < s.k && s.k <= 64 && s.lda >= s.m && s.ldb >= s.k && s.ldc >= s.m

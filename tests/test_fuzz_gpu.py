@@ -179,3 +179,47 @@ def test_fsspmdm_fuzz(xs, orc, torch_gpu, chunk):
             os.environ.pop("LIBXSMM_AMD_JIT", None)
         else:
             os.environ["LIBXSMM_AMD_JIT"] = old_jit
+
+
+@pytest.mark.parametrize("chunk", range(2))
+def test_matrix_core_work_group_kernels_fuzz(xs, orc, torch_gpu, monkeypatch, chunk):
+    """Random shapes of the class served by the matrix-core work-group kernels (32 < max(M, N) <= 64, K <= 64; tight or with
+    gaps in the leading dimensions; odd K; fp32 and fp64; beta 0/1): bit for bit the oracle's k-ordered fma chain, signs of
+    zeros included."""
+    torch = torch_gpu
+    from test_smm_gpu import make_inputs
+    monkeypatch.setenv("XSMM_SMM64_ALWAYS", "1")
+    rng = np.random.default_rng(6464 + chunk)
+    old = xs.lib().libxsmm_amd_set_mfma(1)
+    try:
+        for it in range(24):
+            dtype = np.float64 if rng.random() < 0.5 else np.float32
+            m, n = int(rng.integers(1, 65)), int(rng.integers(1, 65))
+            if max(m, n) <= 32:
+                m = int(rng.integers(33, 65))
+            k = int(rng.integers(1, 65))
+            gaps = rng.random() < 0.4
+            lda, ldb, ldc = (m + int(rng.integers(0, 9)), k + int(rng.integers(0, 9)), m + int(rng.integers(0, 9))) if gaps else (m, k, m)
+            beta = 0.0 if rng.random() < 0.3 else 1.0
+            batch = int(rng.integers(1, 3000))
+            a, b, c, asz, bsz, csz = make_inputs(rng, dtype, batch, m, n, k, lda, ldb, ldc, False, False, orc)
+            a[:asz] = 0.0
+            c[:csz] = -0.0
+            if beta == 0.0:
+                c[:] = np.nan
+                for i in range(batch):
+                    c[i * csz:(i + 1) * csz].reshape(n, ldc)[:, m:] = 0.5
+            flags = xs.FLAG_BETA_0 if beta == 0.0 else 0
+            ref = c.copy()
+            orc.gemm_batch_strided(orc.FMA, flags, m, n, k, lda, ldb, ldc, a, b, ref, asz, bsz, csz, batch, 8)
+            da, db, dc = (torch.from_numpy(x).cuda() for x in (a, b, c))
+            blob, desc = xs.descriptor(xs.F64 if dtype == np.float64 else xs.F32, m, n, k, lda, ldb, ldc, 1.0, beta)
+            assert 0 == xs.lib().libxsmm_amd_gemm_batch_strided(desc, xs.dptr(da), xs.dptr(db), xs.dptr(dc), asz, bsz, csz, batch)
+            torch.cuda.synchronize()
+            out = dc.cpu().numpy()
+            case = (dtype.__name__, m, n, k, lda, ldb, ldc, beta, batch, xs.last_kernel())
+            assert "mfma" in xs.last_kernel(), case
+            bits = np.uint64 if dtype == np.float64 else np.uint32
+            assert np.array_equal(out.view(bits), ref.view(bits)), case
+    finally:
+        xs.lib().libxsmm_amd_set_mfma(old)

@@ -530,6 +530,128 @@ void smm_f64_mfma_wg_kernel(DevAddr ad, int M, int N, int K, int lda, int ldb, i
   }
 }
 
+// Two-stage form for K > 32: the images hold 32 k at a time (32 KiB per work-group, so three work-groups fit a CU where the
+// one-stage form has room for two); the halves of A and B are parked and consumed one after the other, and the registers of a
+// half are refilled with the next item's as soon as they are parked. B is loaded k-fastest (32 consecutive k of a column per
+// half wave) so that a register belongs to one half.
+template<bool BETA0>
+__global__ __launch_bounds__(256, 3)
+void smm_f64_mfma_wg2_kernel(DevAddr ad, int M, int N, int K, int lda, int ldb, int ldc, long long batch, int runlen)
+{
+  extern __shared__ __align__(16) double lds64[];
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63, i = lane & 15, q = lane >> 4;
+  const int mq = wave & 1, nq = wave >> 1;
+  const int ksteps = (K + 3) >> 2, kp = 4 * ksteps;
+  double* const As = lds64;
+  double* const Bs = lds64 + 32 * 64;
+  const int m0 = 32 * mq + i, n0 = 32 * nq + i;
+  const bool tm1 = (32 * mq + 16 < M), tn1 = (32 * nq + 16 < N);
+  const bool active = (32 * mq < M) && (32 * nq < N); // the wave's quadrant holds part of C
+  // A unit is a run of `runlen` consecutive items with one C block (blocked GEMM: the k blocks of a C block); C stays in the
+  // accumulators across the run. runlen = 1: independent items.
+  const long long nunits = batch / runlen;
+  long long unit = blockIdx.x;
+  int r0 = 0; // position inside the run
+  if (unit >= nunits) return; // the whole work-group
+
+  double ra[16], rb[16], rc[16];
+  const int kk = t & 31, nb = t >> 5; // B: row within a half, first column
+  const unsigned offa = (unsigned)(wave * lda + lane), offb = (unsigned)(nb * ldb + kk);
+  const unsigned offc = (unsigned)((32 * nq + q) * ldc + m0);
+  typedef const __attribute__((address_space(1))) double* gcptr;
+  typedef __attribute__((address_space(1))) double* gptr;
+  auto load_half = [&](long long it, int h) {
+    const double* const pa = wave_uniform(addr_a<double>(ad, it));
+    const double* const pb = wave_uniform(addr_b<double>(ad, it));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int col = 32 * h + 4 * j + wave; // A[m = lane][k = col]
+      const double va = (lane < M && col < K) ? __builtin_nontemporal_load((gcptr)(pa + (size_t)(32 * h + 4 * j) * lda + offa)) : -0.0;
+      const int n = nb + 8 * j;              // B[k = 32h + kk][n]
+      const double vb = (32 * h + kk < K && n < N) ? __builtin_nontemporal_load((gcptr)(pb + (size_t)(8 * j) * ldb + 32 * h + offb)) : 0.0;
+      if (0 == h) { ra[j] = va; rb[j] = vb; } else { ra[8 + j] = va; rb[8 + j] = vb; }
+    }
+  };
+  auto park_half = [&](int h) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int col = 4 * j + wave, k = 32 * h + kk; // local row of A, global k of B
+      if (32 * h + col < kp) As[col * 64 + (lane ^ ((col & 1) << 4))] = (0 == h) ? ra[j] : ra[8 + j];
+      if (k < kp) Bs[kk * 64 + ((nb + 8 * j) ^ bkey64(k))] = (0 == h) ? rb[j] : rb[8 + j];
+    }
+  };
+  auto compute_half = [&](int h, f64x4 (&acc)[2][2]) {
+    const int s1 = (ksteps < 8 * h + 8) ? ksteps : 8 * h + 8;
+    for (int s = 8 * h; s < s1; ++s) {
+      const int k = 4 * s + q, kl = k - 32 * h, sa = (q & 1) << 4, sb = bkey64(k);
+      const double a0 = As[kl * 64 + (m0 ^ sa)], b0 = Bs[kl * 64 + (n0 ^ sb)];
+      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, a0, acc[0][0], 0, 0, 0);
+      if (tm1) {
+        const double a1 = As[kl * 64 + ((m0 + 16) ^ sa)];
+        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, a1, acc[0][1], 0, 0, 0);
+        if (tn1) {
+          const double b1 = Bs[kl * 64 + ((n0 + 16) ^ sb)];
+          acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a0, acc[1][0], 0, 0, 0);
+          acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a1, acc[1][1], 0, 0, 0);
+        }
+      }
+      else if (tn1) {
+        const double b1 = Bs[kl * 64 + ((n0 + 16) ^ sb)];
+        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a0, acc[1][0], 0, 0, 0);
+      }
+    }
+  };
+  // C element e = 8 tn + 4 tm + r: n = 32 nq + 16 tn + q + 4r, m = 32 mq + 16 tm + i
+  auto load_c = [&](const double* pc0) {
+    const double* const pc = wave_uniform(pc0);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int nr = 16 * (e >> 3) + 4 * (e & 3), mr = 16 * ((e >> 2) & 1);
+      rc[e] = (m0 + mr < M && 32 * nq + q + nr < N) ? __builtin_nontemporal_load((gcptr)(pc + (size_t)nr * ldc + mr + offc)) : 0.0;
+    }
+  };
+  load_half(unit * runlen, 0);
+  load_half(unit * runlen, 1);
+  if (!BETA0 && active) load_c(addr_c<double>(ad, unit * runlen));
+  f64x4 acc[2][2]; // [tn][tm]
+  for (;;) {
+    const long long item = unit * runlen + r0;
+    int r1 = r0 + 1; long long unit1 = unit;
+    if (r1 == runlen) { r1 = 0; unit1 += gridDim.x; }
+    const bool more = unit1 < nunits;
+    const long long next = unit1 * runlen + r1;
+    park_half(0);
+    if (0 == r0) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e >> 3][(e >> 2) & 1][e & 3] = BETA0 ? 0.0 : rc[e];
+    }
+    if (more) load_half(next, 0);
+    __syncthreads();
+    if (active) compute_half(0, acc);
+    __syncthreads(); // the first half has been read
+    park_half(1);
+    if (more) {
+      load_half(next, 1);
+      if (!BETA0 && active && 0 == r1) load_c(addr_c<double>(ad, unit1 * runlen));
+    }
+    __syncthreads();
+    if (active) {
+      compute_half(1, acc);
+      if (r0 + 1 == runlen) {
+        double* const pc = wave_uniform(addr_c<double>(ad, item));
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int nr = 16 * (e >> 3) + 4 * (e & 3), mr = 16 * ((e >> 2) & 1);
+          if (m0 + mr < M && 32 * nq + q + nr < N) __builtin_nontemporal_store(acc[e >> 3][(e >> 2) & 1][e & 3], (gptr)(pc + (size_t)nr * ldc + mr + offc));
+        }
+      }
+    }
+    __syncthreads(); // all reads of the images are done before the next item is parked
+    if (!more) break;
+    unit = unit1; r0 = r1;
+  }
+}
+
 // c[i] = a[i] + b[i] + c[i] in whole 4 KiB items per wave with the same prefetch structure as the SMM kernels: the
 // traffic mix of a beta=1 SMM batch (3 reads : 1 write) without arithmetic or LDS -- the measured ceiling the SMM
 // kernels are compared against (bench.py "stream_ceiling").
@@ -679,12 +801,10 @@ int launch_smm_special(const SmmBatch& s, void* stream, const char** name)
   if (8 == s.typesize && (32 < s.m || 32 < s.n) && s.m <= 64 && s.n <= 64 && 0 < s.k && s.k <= 64 && s.lda >= s.m && s.ldb >= s.k && s.ldc >= s.m
     && 0 == (s.flags & LIBXSMM_GEMM_FLAG_TRANS_B) && mfma_wg_units(s) > 0 && 0 == s.general && 0 != s.use_mfma && 0 != env_int("XSMM_SMM64_MFMA", 1))
   {
-    const size_t lds = (size_t)2 * (4 * ((s.k + 3) / 4)) * 64 * sizeof(double);
+    const bool two = s.k > 32 && 0 != env_int("XSMM_SMM64_TWOSTAGE", 1);
+    const size_t lds = two ? (size_t)2 * 32 * 64 * sizeof(double) : (size_t)2 * (4 * ((s.k + 3) / 4)) * 64 * sizeof(double);
     int fit = (int)((160u * 1024u) / lds);
     if (fit > 3) fit = 3;
-    // long K leaves room for two work-groups per CU only: thin items are then better off on the register-tiled form
-    // (64x32x64: 48 % here, 53 % there; 64x64x64: 65 % here, 56 % there)
-    if (fit < 3 && s.m * s.n <= 3072 && 0 == env_int("XSMM_SMM64_ALWAYS", 0)) return -1;
     const int bpc = env_int("XSMM_SMM64_BPC", fit);
     long long blocks = mfma_wg_units(s);
     const long long resident = 256LL * (bpc > 0 ? bpc : fit);
@@ -698,6 +818,11 @@ int launch_smm_special(const SmmBatch& s, void* stream, const char** name)
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&smm_f64_mfma_wg_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&smm_f64_mfma_wg_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     });
+    if (two) {
+      if (0 != (s.flags & LIBXSMM_GEMM_FLAG_BETA_0)) hipLaunchKernelGGL((smm_f64_mfma_wg2_kernel<true>), dim3((unsigned)blocks), dim3(256), lds, st, ad, s.m, s.n, s.k, s.lda, s.ldb, s.ldc, s.batch, runlen);
+      else hipLaunchKernelGGL((smm_f64_mfma_wg2_kernel<false>), dim3((unsigned)blocks), dim3(256), lds, st, ad, s.m, s.n, s.k, s.lda, s.ldb, s.ldc, s.batch, runlen);
+      return (int)hipGetLastError();
+    }
     if (0 != (s.flags & LIBXSMM_GEMM_FLAG_BETA_0)) hipLaunchKernelGGL((smm_f64_mfma_wg_kernel<true>), dim3((unsigned)blocks), dim3(256), lds, st, ad, s.m, s.n, s.k, s.lda, s.ldb, s.ldc, s.batch, runlen);
     else hipLaunchKernelGGL((smm_f64_mfma_wg_kernel<false>), dim3((unsigned)blocks), dim3(256), lds, st, ad, s.m, s.n, s.k, s.lda, s.ldb, s.ldc, s.batch, runlen);
     return (int)hipGetLastError();

@@ -182,13 +182,12 @@ def test_fsspmdm_fuzz(xs, orc, torch_gpu, chunk):
 
 
 @pytest.mark.parametrize("chunk", range(2))
-def test_matrix_core_work_group_kernels_fuzz(xs, orc, torch_gpu, monkeypatch, chunk):
+def test_matrix_core_work_group_kernels_fuzz(xs, orc, torch_gpu, chunk):
     """Random shapes of the class served by the matrix-core work-group kernels (32 < max(M, N) <= 64, K <= 64; tight or with
     gaps in the leading dimensions; odd K; fp32 and fp64; beta 0/1): bit for bit the oracle's k-ordered fma chain, signs of
     zeros included."""
     torch = torch_gpu
     from test_smm_gpu import make_inputs
-    monkeypatch.setenv("XSMM_SMM64_ALWAYS", "1")
     rng = np.random.default_rng(6464 + chunk)
     old = xs.lib().libxsmm_amd_set_mfma(1)
     try:

@@ -156,13 +156,12 @@ MFMA_WG_SHAPES = [  # 32 < max(M, N) <= 64, K <= 64: tight and with gaps, odd K 
 @pytest.mark.parametrize("shape", MFMA_WG_SHAPES)
 @pytest.mark.parametrize("beta", [1.0, 0.0])
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
-def test_smm_mfma_wg(xs, orc, torch_gpu, monkeypatch, dtype, shape, beta):
+def test_smm_mfma_wg(xs, orc, torch_gpu, dtype, shape, beta):
     """The general matrix-core kernel (work-group per item) against the oracle's fma chain, bit for bit -- including the sign of
     zeros: a batch of all-zero A with C = -0 (the padded k step of an odd K must not turn -0 into +0)."""
     torch = torch_gpu
     m, n, k, lda, ldb, ldc = shape
     batch = 1100
-    monkeypatch.setenv("XSMM_SMM64_ALWAYS", "1")  # fp64: thin items with long K would otherwise go to the register-tiled form
     rng = np.random.default_rng(99 + m + 64 * n + k)
     a, b, c, asz, bsz, csz = make_inputs(rng, dtype, batch, m, n, k, lda, ldb, ldc, False, False, orc)
     a[:3 * asz] = 0.0

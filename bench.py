@@ -10,7 +10,7 @@ libxsmm_gemm_batch with device index arrays).
 Output: ONE JSON line (rank 0) with the driver's contract fields plus
   roofline     -- dominant kernel's algorithmic bytes per launch / HIP-event launch time vs 8 TB/s HBM peak
   cpu_baseline -- the CPU oracle (a port of the reference arithmetic, NOT the product) timed on host cores, N=1 only
-  secondary    -- spmdm CSR compute phase (BASELINE config 4 shape) and fsspmdm (config 3) rates on this GPU.
+  secondary    -- spmdm CSR compute phase (BASELINE config 4 shape), fsspmdm (config 3), CP2K stacks (config 5) and 64^3 batches on this GPU.
 Multi-GPU: one process per GPU (torch.distributed over RCCL); the batch axis shards with no data-path collective
 ("weak" scaling: fixed per-GPU batch). value = work of all ranks / max-over-ranks time.
 """
@@ -277,6 +277,24 @@ def secondary(torch, xs, L):
     _, to = time_steps(torch, stacks_omp, 5, 2, None)
     mo = sum(to) / len(to) * 1e-3
     res["cp2k_stacks_f64_27shapes"]["omp_entry"] = {"ms": round(mo * 1e3, 4), "hbm_gbs": round(byt / mo / 1e9, 1), "frac": round(byt / mo / 1e9 / HBM_PEAK_GBS, 4)}
+    # the upper end of the (M,N,K) <= 64 family: strided batches of 64^3 on the matrix-core work-group kernels
+    L.libxsmm_amd_set_mfma(1)
+    for (name, dt, prec, ts) in (("smm_f32_64x64x64", torch.float32, xs.F32, 4), ("smm_f64_64x64x64", torch.float64, xs.F64, 8)):
+        m = n = k = 64
+        B64 = 65536 if ts == 4 else 32768
+        a = torch.rand(B64 * m * k, device="cuda", dtype=dt, generator=g) - 0.5
+        b = torch.rand(B64 * k * n, device="cuda", dtype=dt, generator=g) - 0.5
+        c = torch.zeros(B64 * m * n, device="cuda", dtype=dt)
+        blob, desc = xs.descriptor(prec, m, n, k, m, k, m, 1.0, 1.0)
+
+        def dense64():
+            assert 0 == L.libxsmm_amd_gemm_batch_strided(desc, xs.dptr(a), xs.dptr(b), xs.dptr(c), m * k, k * n, m * n, B64)
+        _, td = time_steps(torch, dense64, 5, 2, None)
+        md = sum(td) / len(td) * 1e-3
+        byt64 = B64 * float(ts) * (m * k + k * n + 2 * m * n)
+        res[name] = {"batch": B64, "kernel": xs.last_kernel(), "ms": round(md * 1e3, 4), "hbm_gbs": round(byt64 / md / 1e9, 1),
+                     "frac": round(byt64 / md / 1e9 / HBM_PEAK_GBS, 4), "gflops": round(2.0 * m * n * k * B64 / md / 1e9, 1)}
+        del a, b, c
     L.libxsmm_amd_set_mfma(old_mfma)
     return res
 

@@ -177,7 +177,7 @@ int flag_slot_set(int* slot, int equal_pairs, int decreasing_pairs)
 
 // Index arrays of a batch call that live in host memory (an unchanged caller's stride arrays): staged through a per-thread ring
 // of pinned buffers and copied with the copy engine, asynchronously -- the call does not wait for the GPU. A ring entry is
-// reused 8 calls later; by then the launch that read it (event recorded by index_upload_commit) is normally long done.
+// reused INDEX_RING calls later; by then the launch that read it (event recorded by index_upload_commit) is normally long done.
 namespace {
 struct IndexStage { void* host = nullptr; void* dev = nullptr; size_t size = 0; hipEvent_t done = nullptr; void* stream = nullptr; int state = 0; /* 1: filled, 2: committed */ };
 constexpr int INDEX_RING = 24;

@@ -75,6 +75,22 @@ LIBXSMM_API int libxsmm_amd_spmdm_batch_compute(libxsmm_amd_spmdm_batch* sb, cha
 LIBXSMM_API int libxsmm_amd_spmdm_batch_get_slice(const libxsmm_amd_spmdm_batch* sb, long long item,
   uint16_t* rowidx, uint16_t* colidx, float* values, int capacity);
 
+/** The reference spmdm interface in one call per phase: what the caller's loop over block ids does
+ *  (samples/spmdm/spmdm.c:74-112: libxsmm_spmdm_createSparseSlice_fp32_thread for every id below
+ *  libxsmm_spmdm_get_num_createSparseSlice_blocks, then libxsmm_spmdm_compute_fp32_thread for every id below
+ *  libxsmm_spmdm_get_num_compute_blocks), as one launch over the whole problem. The *_thread functions keep the reference's
+ *  contract -- a call touches the slice resp. the C tile of its block id and nothing else -- and cost one launch per block;
+ *  these are for callers that own the whole loop. Same operands and semantics (alpha ignored, beta == 0 never reads C);
+ *  device or host operands. Returns EXIT_SUCCESS/EXIT_FAILURE. */
+LIBXSMM_API int libxsmm_amd_spmdm_createSparseSlice_all(const libxsmm_spmdm_handle* handle, char transa, const float* a,
+  libxsmm_CSR_sparseslice* libxsmm_output_csr_a);
+LIBXSMM_API int libxsmm_amd_spmdm_compute_all(const libxsmm_spmdm_handle* handle, char transa, char transb, const float* alpha,
+  libxsmm_CSR_sparseslice* a_sparse, const float* b, char transc, const float* beta, float* c);
+LIBXSMM_API int libxsmm_amd_spmdm_createSparseSlice_bfloat16_all(const libxsmm_spmdm_handle* handle, char transa, const libxsmm_bfloat16* a,
+  libxsmm_CSR_sparseslice* libxsmm_output_csr_a);
+LIBXSMM_API int libxsmm_amd_spmdm_compute_bfloat16_all(const libxsmm_spmdm_handle* handle, char transa, char transb, const libxsmm_bfloat16* alpha,
+  libxsmm_CSR_sparseslice* a_sparse, const libxsmm_bfloat16* b, char transc, const libxsmm_bfloat16* beta, float* c);
+
 /** Batched fsspmdm: the operator of `handle` applied to `batch` column panels of width handle->N that sit
  *  side by side in B (K x ldb) / C (M x ldc): panel i = columns [i*N, (i+1)*N). Equivalent to calling
  *  libxsmm_?fsspmdm_execute(handle, B + i*N, C + i*N) for every i (samples/pyfr/pyfr_driver_asp_reg.c:295-309). */

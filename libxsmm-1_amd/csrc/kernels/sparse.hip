@@ -118,6 +118,70 @@ void spmdm_create_kernel(long long nslices, int nrows_full, int ncols_full, int 
   }
 }
 
+// Block form of one large matrix (the reference API, slices of bm <= 512 rows x bk <= 64 columns): a work-group of eight
+// waves per slice. Wave w owns a contiguous share of the slice's rows; a first pass counts its entries (__ballot +
+// popcount per row), the eight counts are exchanged through LDS, a second pass (the rows come out of L2 this time)
+// writes rowidx / colidx / values at the positions the sequential scan of the reference gives them.
+constexpr int SPB_WAVES = 8;
+__global__ __launch_bounds__(64 * SPB_WAVES)
+void spmdm_create_block_kernel(int first_slice, int transa, const float* __restrict__ a, int mb_count, int bm, int bk, int M, int K,
+                               uint16_t* __restrict__ rowidx, uint16_t* __restrict__ colidx, float* __restrict__ values,
+                               long long rowidx_stride, long long cap)
+{
+  __shared__ unsigned wave_count[SPB_WAVES];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int s = first_slice + blockIdx.x;
+  const int kb = s / mb_count, mb = s % mb_count; // reference: kb = id / mb, mb = id % mb
+  const int nrows = ((mb + 1) * bm > M) ? (M - mb * bm) : bm;
+  const int ncols = ((kb + 1) * bk > K) ? (K - kb * bk) : bk; // <= 64 (host check)
+  const int ld = transa ? M : K;
+  const float* const in = transa ? (a + (size_t)mb * bm + (size_t)kb * bk * M) : (a + (size_t)kb * bk + (size_t)mb * bm * K);
+  uint16_t* const ri = rowidx + s * rowidx_stride;
+  uint16_t* const ci = colidx + s * cap;
+  float* const va = values + s * cap;
+  const int share = (nrows + SPB_WAVES - 1) / SPB_WAVES;
+  const int r0 = wave * share, r1 = (r0 + share < nrows) ? (r0 + share) : nrows;
+  const bool in_range = (lane < ncols);
+  unsigned cnt = 0;
+  for (int rb = r0; rb < r1; rb += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int r = rb + u;
+      v[u] = (in_range && r < r1) ? (transa ? in[(size_t)lane * ld + r] : in[(size_t)r * ld + lane]) : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) cnt += __popcll(__ballot(!(0.f == v[u]))); // LIBXSMM_FEQ(0, v) ? 0 : 1  (-0 is zero, NaN is kept)
+  }
+  if (0 == lane) wave_count[wave] = cnt;
+  __syncthreads();
+  cnt = 0;
+  for (int w = 0; w < wave; ++w) cnt += wave_count[w];
+  for (int rb = r0; rb < r1; rb += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int r = rb + u;
+      v[u] = (in_range && r < r1) ? (transa ? in[(size_t)lane * ld + r] : in[(size_t)r * ld + lane]) : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int r = rb + u;
+      if (r < r1) {
+        if (0 == lane) ri[r] = (uint16_t)cnt;
+        const bool keep = !(0.f == v[u]);
+        const unsigned long long mask = __ballot(keep);
+        if (keep) {
+          const unsigned pos = cnt + __popcll(mask & ((1ULL << lane) - 1ULL));
+          ci[pos] = (uint16_t)lane; va[pos] = v[u];
+        }
+        cnt += __popcll(mask);
+      }
+    }
+  }
+  if (r0 < nrows && r1 == nrows && 0 == lane) ri[nrows] = (uint16_t)cnt; // the wave that owns the last row closes the slice
+}
+
 // Batch form for slices of at most 64 columns whose slots are 16-byte aligned (cap % 8 == 0): the compacted entries are
 // collected in wave-private LDS and leave as 16-byte vector stores, 1 KiB per wave instruction, instead of the per-row
 // 2- and 4-byte scatter of the kernel above (partial lines). Same scan order, same output.
@@ -721,6 +785,253 @@ void spmdm_compute_mfma_kernel(long long batch, int M_arg, int K_arg, float beta
   }
 }
 
+// ---- spmdm compute: one large problem (the reference API), tiled ----------------------------------------------------------
+// A work-group of eight waves owns a 64 x 256 tile of C for the whole sum over k: per slice column block (bk = 64 columns of
+// A = 64 rows of B) the B panel [64][256] and the CSR entries of the tile's 64 rows are staged in LDS (loads of the next
+// block in flight in registers meanwhile), C stays in registers. All 64 lanes of a wave work on ONE row at a time, a lane
+// owning four adjacent columns: the row's entries (at most 64) are fetched with a single ds_read_b64 -- one entry per lane
+// -- and handed round with v_readlane, so that the LDS pipe only carries the gathered B rows (one conflict-free
+// ds_read_b128 per entry and wave). Row r = 8 i + w of the tile belongs to wave w, round i. Per C element:
+// acc = beta * C; acc = fma(val_p, B[col_p][n], acc) over the column blocks in order and the row's entries in order --
+// the chain of the reference (compute tpl :321-371); beta == 0 never reads C.
+constexpr int SPT_BK = 64, SPT_TN = 256, SPT_TM = 64, SPT_CAP = 1536, SPT_THREADS = 512;
+constexpr size_t SPT_LDS = (size_t)SPT_BK * SPT_TN * 4 + (size_t)SPT_CAP * 8 + 160;
+
+template<int U>
+__device__ __forceinline__ void spt_fold(const sp_f32x2 ent, int j0, const float* __restrict__ brow, sp_f32x4& acc)
+{
+  sp_f32x4 bv[U]; float av[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int off = __builtin_amdgcn_readlane(__float_as_int(ent[0]), j0 + u);
+    av[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ent[1]), j0 + u));
+    bv[u] = *reinterpret_cast<const sp_f32x4*>(brow + off);
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    acc[0] = xfma(av[u], bv[u][0], acc[0]); acc[1] = xfma(av[u], bv[u][1], acc[1]);
+    acc[2] = xfma(av[u], bv[u][2], acc[2]); acc[3] = xfma(av[u], bv[u][3], acc[3]);
+  }
+}
+
+// VEC: N % 4 == 0 (K % 4 == 0 for a transposed B) and 16-byte aligned B and C: 16-byte global accesses
+template<bool VEC, bool TRANSB>
+__global__ __launch_bounds__(SPT_THREADS, 4)
+void spmdm_tiled_kernel(int M, int N, int K, int bm, int mb_count, int kb_count, int transc, float beta,
+                        const uint16_t* __restrict__ rowidx, const uint16_t* __restrict__ colidx, const float* __restrict__ values,
+                        long long rstride, long long cap, const float* __restrict__ b, float* __restrict__ c,
+                        int mb_begin, int mb_n, int n_begin, int n_end)
+{
+  extern __shared__ __align__(16) unsigned char spt_raw[];
+  float* const Bs = reinterpret_cast<float*>(spt_raw);                               // [64][256]
+  float2* const meta = reinterpret_cast<float2*>(Bs + SPT_BK * SPT_TN);              // [SPT_CAP] {bitcast(float offset of the B row), value}
+  unsigned short* const ris = reinterpret_cast<unsigned short*>(meta + SPT_CAP);     // [65]
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  // ---- which tile: consecutive tiles of one column panel go to one XCD (its L2 then holds that panel of B)
+  const int tiles_per_mb = (bm + SPT_TM - 1) / SPT_TM;
+  const int tiles_m = mb_n * tiles_per_mb, tiles_n = (n_end - n_begin + SPT_TN - 1) / SPT_TN;
+  const int total = tiles_m * tiles_n, per_xcd = (total + 7) / 8;
+  const int linear = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= per_xcd || linear >= total) return;
+  const int tn = linear / tiles_m, tmi = linear - tn * tiles_m;
+  const int mbi = mb_begin + tmi / tiles_per_mb, ml0 = (tmi % tiles_per_mb) * SPT_TM;
+  const int nrows_mb = ((mbi + 1) * bm > M) ? (M - mbi * bm) : bm;
+  if (ml0 >= nrows_mb) return;
+  const int rows = (nrows_mb - ml0 < SPT_TM) ? (nrows_mb - ml0) : SPT_TM;
+  const int n0 = n_begin + tn * SPT_TN;
+  const int ncols = (n_end - n0 < SPT_TN) ? (n_end - n0) : SPT_TN;
+  const int m0 = mbi * bm + ml0;           // first row of the tile in C
+  const int nl = 4 * lane;                 // this lane's columns: n0 + nl .. + 3
+  const int nvalid = ncols - nl;           // > 0: the lane has columns (>= 4: all four)
+
+  // ---- register stages: B panel (8 x 16 bytes), row starts, CSR entries of the next column block.
+  // Piece j of a thread: (wave-uniform base of the column block and of j) + (one per-thread offset): nothing per piece
+  // stays in vector registers between the blocks.
+  //   B[k][n]: piece = 4 columns c4 of row kr = (t >> 6) + 8 j        TRANSB, B[n][k]: 4 k's kq = 4 ((t >> 8) + 2 j) of column cc = t & 255
+  //   (lanes along n also when B is transposed: parked without bank conflicts; the global side is served by L1/L2)
+  const int pr = TRANSB ? (t >> 8) : (t >> 6), pc = TRANSB ? (t & 255) : ((t & 63) << 2);
+  const int voff = TRANSB ? (pc * K + 4 * pr) : (pr * N + pc);
+  const bool pc_ok = (pc < ncols);
+  sp_f32x4 rb[8]; unsigned short rix = 0; unsigned cols[2]; sp_f32x2 vals[2];
+  auto fetch = [&](int kb, int base, int pend) {
+    const int k0 = kb * SPT_BK, kc = (K - k0 < SPT_BK) ? (K - k0) : SPT_BK;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      sp_f32x4 v = sp_f32x4{ 0.f, 0.f, 0.f, 0.f };
+      if (!TRANSB) {
+        const float* const sbase = b + (size_t)(k0 + 8 * j) * N + n0; // wave-uniform
+        if (pr + 8 * j < kc && pc_ok) {
+          if (VEC) v = *reinterpret_cast<const sp_f32x4*>(sbase + voff);
+          else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (pc + q < ncols) v[q] = sbase[voff + q];
+          }
+        }
+      }
+      else {
+        const float* const sbase = b + (size_t)n0 * K + k0 + 8 * j;
+        if (4 * pr + 8 * j < kc && pc_ok) {
+          if (VEC) v = *reinterpret_cast<const sp_f32x4*>(sbase + voff);
+          else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (4 * pr + 8 * j + q < kc) v[q] = sbase[voff + q];
+          }
+        }
+      }
+      rb[j] = v;
+    }
+    const long long s = (long long)kb * mb_count + mbi;
+    if (t <= rows) rix = rowidx[s * rstride + ml0 + t];
+    if (pend - base <= SPT_CAP) { // one window (the common case): the entries travel through registers as well
+      const uint16_t* const ci = colidx + s * cap + base;
+      const float* const va = values + s * cap + base;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int e = 2 * (t + SPT_THREADS * j);
+        if (e < pend - base) { // (an odd count fetches one entry too many: inside the slice's capacity, never used)
+          cols[j] = *reinterpret_cast<const unsigned*>(ci + e);
+          vals[j] = *reinterpret_cast<const sp_f32x2*>(va + e);
+        }
+      }
+    }
+  };
+  // entry range [base, pend) of the tile's rows inside slice (kb, mbi); base is rounded down to an even entry (aligned pairs)
+  auto entry_range = [&](int kb, int& base, int& pend) {
+    if (kb < kb_count) {
+      const uint16_t* const ri = rowidx + ((long long)kb * mb_count + mbi) * rstride + ml0;
+      base = __builtin_amdgcn_readfirstlane((int)ri[0] & ~1); pend = __builtin_amdgcn_readfirstlane((int)ri[rows]);
+    }
+    else { base = 0; pend = 0; }
+  };
+
+  // ---- C tile: acc[i] = row 8 i + wave
+  sp_f32x4 acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    acc[i] = sp_f32x4{ 0.f, 0.f, 0.f, 0.f };
+    const int r = 8 * i + wave;
+    if (0.f != beta && r < rows && 0 < nvalid) {
+      sp_f32x4 cv = sp_f32x4{ 0.f, 0.f, 0.f, 0.f };
+      if (0 == transc) {
+        const float* const src = c + (size_t)(m0 + r) * N + n0;
+        if (VEC) cv = *reinterpret_cast<const sp_f32x4*>(src + nl);
+        else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) if (q < nvalid) cv[q] = src[nl + q];
+        }
+      }
+      else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) if (q < nvalid) cv[q] = c[(size_t)(n0 + nl + q) * M + m0 + r];
+      }
+      acc[i] = (1.f == beta) ? cv : beta * cv;
+    }
+  }
+
+  int base, pend, base1, pend1;
+  entry_range(0, base, pend);
+  entry_range(1, base1, pend1);
+  fetch(0, base, pend);
+  const float* const brow = Bs + nl;
+  for (int kb = 0; kb < kb_count; ++kb) {
+    const bool one_window = (pend - base <= SPT_CAP);
+    // ---- park this column block's registers in LDS
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (!TRANSB) *reinterpret_cast<sp_f32x4*>(Bs + (pr + 8 * j) * SPT_TN + pc) = rb[j];
+      else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Bs[(4 * pr + 8 * j + q) * SPT_TN + pc] = rb[j][q];
+      }
+    }
+    if (t <= rows) ris[t] = rix;
+    if (one_window) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int e = 2 * (t + SPT_THREADS * j);
+        if (e < pend - base) {
+          const int o0 = (int)(cols[j] & 0xFFFFu) * SPT_TN, o1 = (int)(cols[j] >> 16) * SPT_TN;
+          *reinterpret_cast<sp_f32x4*>(meta + e) = sp_f32x4{ __int_as_float(o0), vals[j][0], __int_as_float(o1), vals[j][1] };
+        }
+      }
+    }
+    // ---- the next column block's loads go out now
+    int base2, pend2;
+    entry_range(kb + 2, base2, pend2);
+    if (kb + 1 < kb_count) fetch(kb + 1, base1, pend1);
+    spw_lds_barrier();
+    // ---- rounds of eight rows; a window holds the entries of as many consecutive rounds as fit the buffer
+    int round0 = 0;
+    const int nrounds = (rows + 7) >> 3;
+    while (round0 < nrounds) {
+      int round1 = nrounds, wbase = base;
+      if (!one_window) {
+        const uint16_t* const ci = colidx + ((long long)kb * mb_count + mbi) * cap;
+        const float* const va = values + ((long long)kb * mb_count + mbi) * cap;
+        wbase = __builtin_amdgcn_readfirstlane((int)ris[8 * round0]);
+        round1 = round0 + 1; // (a round holds at most 8 x 64 entries: always fits)
+        while (round1 < nrounds) {
+          const int rend = (8 * (round1 + 1) < rows) ? 8 * (round1 + 1) : rows;
+          if ((int)ris[rend] - wbase > SPT_CAP) break;
+          ++round1;
+        }
+        round1 = __builtin_amdgcn_readfirstlane(round1);
+        const int wend = (int)ris[(8 * round1 < rows) ? 8 * round1 : rows];
+        for (int e = t; e < wend - wbase; e += SPT_THREADS) meta[e] = float2{ __int_as_float((int)ci[wbase + e] * SPT_TN), va[wbase + e] };
+        spw_lds_barrier();
+      }
+      // entry ranges of this wave's eight rows, one row per lane (rows outside the window or the tile: empty)
+      int vp0 = 0, vcnt = 0;
+      if (lane < 8) {
+        const int r = 8 * lane + wave;
+        if (lane >= round0 && lane < round1 && r < rows) { vp0 = (int)ris[r] - wbase; vcnt = (int)ris[r + 1] - wbase - vp0; }
+      }
+      // a row's entries: one per lane (a single ds_read_b64), fetched one row ahead of the arithmetic
+      auto row_entries = [&](int i, int& cnt) -> sp_f32x2 {
+        const int p0 = __builtin_amdgcn_readlane(vp0, i);
+        cnt = __builtin_amdgcn_readlane(vcnt, i);
+        sp_f32x2 ent = sp_f32x2{ 0.f, 0.f };
+        if (lane < cnt) { const float2 e2 = meta[p0 + lane]; ent = sp_f32x2{ e2.x, e2.y }; }
+        return ent;
+      };
+      int cnt_next = 0;
+      sp_f32x2 ent_next = row_entries(0, cnt_next);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const sp_f32x2 ent = ent_next; const int cnt = cnt_next;
+        if (i + 1 < 8) ent_next = row_entries(i + 1, cnt_next);
+        int j = 0;
+        for (; j + 4 <= cnt; j += 4) spt_fold<4>(ent, j, brow, acc[i]);
+        if (cnt & 2) { spt_fold<2>(ent, j, brow, acc[i]); j += 2; }
+        if (cnt & 1) spt_fold<1>(ent, j, brow, acc[i]);
+      }
+      spw_lds_barrier(); // the buffers are overwritten next
+      round0 = round1;
+    }
+    base = base1; pend = pend1; base1 = base2; pend1 = pend2;
+  }
+
+  // ---- C leaves
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int r = 8 * i + wave;
+    if (r < rows && 0 < nvalid) {
+      if (0 == transc) {
+        float* const dst = c + (size_t)(m0 + r) * N + n0;
+        if (VEC) *reinterpret_cast<sp_f32x4*>(dst + nl) = acc[i];
+        else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) if (q < nvalid) dst[nl + q] = acc[i][q];
+        }
+      }
+      else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) if (q < nvalid) c[(size_t)(n0 + nl + q) * M + m0 + r] = acc[i][q];
+      }
+    }
+  }
+}
+
 unsigned grid_for(long long work, int per_block)
 {
   long long blocks = (work + per_block - 1) / per_block;
@@ -770,17 +1081,17 @@ int launch_spmdm_create(const SpmdmGeom& g, int transa, const float* a, uint16_t
 
 int launch_spmdm_create_blocks(int M, int K, int bm, int bk, int mb, int first_slice, int nslices, int transa, const float* a,
                                uint16_t* rowidx, uint16_t* colidx, float* values, void* stream, const char** name)
-{ // single matrix decomposed into (kb,mb) slices; slices [first_slice, first_slice+nslices)
+{ // one matrix decomposed into (kb, mb) slices; slices [first_slice, first_slice + nslices): a work-group per slice
   hipStream_t st = (hipStream_t)stream;
-  *name = "spmdm_create_slices_wave";
   const long long cap = (long long)bm * bk, rstride = (long long)bm + 1;
-  if (0 == first_slice && 1 < nslices) { // all slices of the matrix: one launch, a wavefront per slice (kb = id / mb, mb = id % mb)
-    hipLaunchKernelGGL(spmdm_create_kernel, dim3(grid_for(nslices, 4)), dim3(256), 0, st,
-      (long long)nslices, 0, 0, transa, a, 0LL, transa ? M : K, mb, bm, bk, M, K, rowidx, colidx, values, rstride, cap);
+  if (0 >= nslices) { *name = "spmdm_create_noop"; return 0; }
+  if (bk <= 64) {
+    *name = "spmdm_create_slice_wg";
+    hipLaunchKernelGGL(spmdm_create_block_kernel, dim3((unsigned)nslices), dim3(64 * SPB_WAVES), 0, st,
+      first_slice, transa, a, mb, bm, bk, M, K, rowidx, colidx, values, rstride, cap);
     return (int)hipGetLastError();
   }
-  // the kernel numbers slices from 0: offset the outputs and let it skip the leading ids via the pointer arithmetic
-  // (slice id is needed for kb/mb, so pass a shifted count and shift inside through a wrapper loop)
+  *name = "spmdm_create_slices_wave"; // wider slices (not produced by libxsmm_spmdm_init): a wavefront per slice
   for (int s = first_slice; s < first_slice + nslices; ++s) {
     const int kb = s / mb, imb = s % mb;
     const int nrows = ((imb + 1) * bm > M) ? (M - imb * bm) : bm;
@@ -790,6 +1101,36 @@ int launch_spmdm_create_blocks(int M, int K, int bm, int bk, int mb, int first_s
       1LL, nrows, ncols, transa, in, 0LL, transa ? M : K, 0, bm, bk, M, K,
       rowidx + s * rstride, colidx + s * cap, values + s * cap, rstride, cap);
   }
+  return (int)hipGetLastError();
+}
+
+// C tile rows of the row blocks [mb_begin, mb_begin + mb_n), columns [n_begin, n_end) of one problem whose slices are
+// bm x bk (bk == SPT_BK). -1: the geometry is not served by the tiled kernel.
+int launch_spmdm_compute_tiled(int M, int N, int K, int bm, int bk, int mb, int kb, int transb, int transc, float beta,
+                               const uint16_t* rowidx, const uint16_t* colidx, const float* values, long long rowidx_stride, long long cap,
+                               const float* b, float* c, int mb_begin, int mb_n, int n_begin, int n_end, void* stream, const char** name)
+{
+  if (SPT_BK != bk || 0 != (cap & 1) || bm > 65535 / SPT_BK) return -1;
+  if (0 >= mb_n || n_end <= n_begin) { *name = "spmdm_compute_noop"; return 0; }
+  static const bool attr = []() {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spmdm_tiled_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SPT_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spmdm_tiled_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SPT_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spmdm_tiled_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SPT_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spmdm_tiled_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SPT_LDS);
+    return true;
+  }();
+  (void)attr;
+  const int tiles_per_mb = (bm + SPT_TM - 1) / SPT_TM;
+  const long long total = (long long)mb_n * tiles_per_mb * ((n_end - n_begin + SPT_TN - 1) / SPT_TN);
+  const unsigned grid = (unsigned)(8 * ((total + 7) / 8));
+  const uintptr_t bits = reinterpret_cast<uintptr_t>(b) | (0 == transc ? reinterpret_cast<uintptr_t>(c) : 0); // (a transposed C moves element by element anyway)
+  const bool vec = (0 == (bits & 15)) && 0 == (N & 3) && 0 == (n_begin & 3) && (0 == transb || 0 == (K & 3));
+  *name = "spmdm_compute_tiled";
+#define XSMM_SPT(V, TB) hipLaunchKernelGGL((spmdm_tiled_kernel<V, TB>), dim3(grid), dim3(SPT_THREADS), SPT_LDS, (hipStream_t)stream, \
+      M, N, K, bm, mb, kb, transc, beta, rowidx, colidx, values, rowidx_stride, cap, b, c, mb_begin, mb_n, n_begin, n_end)
+  if (vec) { if (0 == transb) XSMM_SPT(true, false); else XSMM_SPT(true, true); }
+  else { if (0 == transb) XSMM_SPT(false, false); else XSMM_SPT(false, true); }
+#undef XSMM_SPT
   return (int)hipGetLastError();
 }
 

@@ -3,10 +3,10 @@
 // Reference: src/libxsmm_fsspmdm.c:48-329 and src/libxsmm_spmdm.c:103-627 with the fp32 templates.
 #include "xsmm_internal.hpp"
 
+#include <hip/hip_runtime_api.h>
+
 #include <cassert>
 #include <cstring>
-#include <mutex>
-#include <unordered_map>
 #include <vector>
 
 namespace xsmm {
@@ -184,9 +184,20 @@ LIBXSMM_API int libxsmm_amd_sfsspmdm_execute_batch(const libxsmm_sfsspmdm* handl
 // The handle and slice structs are caller-visible (include/libxsmm_spmdm.h:42-72); the slice arrays
 // (rowidx/colidx/values) are allocated in HBM, the slice descriptors in host memory.
 // Block geometry: bm/bn/bk only partition the work (results do not depend on them); the reference derives them
-// from the CPU ISA and thread count (src/libxsmm_spmdm.c:555-608). Here: bk = 128 and bm = 512|256 as in the
-// reference (both bound the uint16 slice-local indexes), bn = 96.
+// from the CPU ISA and thread count (src/libxsmm_spmdm.c:555-608: bm 256|512 shrunk for load balance, bn 96|48|6,
+// bk 128). Here they are sized for the GPU: a block call is one launch, so blocks are as large as the uint16 slice-local
+// indexes and counters allow -- bm = 512 rows, bk = 64 columns (a slice holds at most 32 768 entries; 64 is also the
+// width of a wavefront: a row of a slice is one load per wave and at most one entry per lane), bn = 2048.
+// Contract kept from the reference (compute tpl :38-39, 509-558): a compute call writes the C tile of its block and
+// nothing else, whatever the other calls did; a create call writes its slice and nothing else. Calls are asynchronous
+// for device operands. The whole problem in one launch is an explicit extension: libxsmm_amd_spmdm_*_all.
 // ---------------------------------------------------------------------------------------------------------------
+namespace xsmm {
+int launch_spmdm_compute_tiled(int M, int N, int K, int bm, int bk, int mb, int kb, int transb, int transc, float beta,
+                               const uint16_t* rowidx, const uint16_t* colidx, const float* values, long long rowidx_stride, long long cap,
+                               const float* b, float* c, int mb_begin, int mb_n, int n_begin, int n_end, void* stream, const char** name);
+}
+
 LIBXSMM_API void libxsmm_spmdm_init(int M, int N, int K, int max_threads,
   libxsmm_spmdm_handle* handle, libxsmm_CSR_sparseslice** libxsmm_output_csr)
 {
@@ -196,9 +207,9 @@ LIBXSMM_API void libxsmm_spmdm_init(int M, int N, int K, int max_threads,
   memset(handle, 0, sizeof(*handle));
   *libxsmm_output_csr = nullptr;
   handle->m = M; handle->n = N; handle->k = K;
-  handle->bm = (M >= 4096 || M <= 1024) ? 512 : 256;
+  handle->bm = 512;
   if (handle->bm > M && 0 < M) handle->bm = M; // no point in a block taller than the matrix (keeps scratch small)
-  handle->bn = 96; handle->bk = 128;
+  handle->bn = 2048; handle->bk = 64;
   handle->mb = (M + handle->bm - 1) / handle->bm;
   handle->nb = (N + handle->bn - 1) / handle->bn;
   handle->kb = (K + handle->bk - 1) / handle->bk;
@@ -206,7 +217,7 @@ LIBXSMM_API void libxsmm_spmdm_init(int M, int N, int K, int max_threads,
   if (!device_ready()) { fail_no_device("libxsmm_spmdm_init"); return; }
   const size_t nslices = (size_t)handle->mb * handle->kb;
   const size_t cap = (size_t)handle->bm * handle->bk, rstride = (size_t)handle->bm + 1;
-  // one device block: [rowidx | colidx | values] for all slices (capacity per slice as in the reference :109-112)
+  // one device block: [values | colidx | rowidx] for all slices (capacity per slice as in the reference :109-112)
   const size_t bytes = nslices * (rstride * sizeof(uint16_t) + cap * sizeof(uint16_t) + cap * sizeof(float)) + 256;
   char* const block = static_cast<char*>(dev_alloc(bytes));
   libxsmm_CSR_sparseslice* const slices = static_cast<libxsmm_CSR_sparseslice*>(calloc(nslices ? nslices : 1, sizeof(libxsmm_CSR_sparseslice)));
@@ -226,13 +237,10 @@ LIBXSMM_API void libxsmm_spmdm_init(int M, int N, int K, int max_threads,
   *libxsmm_output_csr = slices;
 }
 
-namespace { void spmdm_forget(const void* device_block); }
-
 LIBXSMM_API void libxsmm_spmdm_destroy(libxsmm_spmdm_handle* handle)
 {
   if (nullptr == handle) return;
   if (device_ready()) (void)stream_sync();
-  spmdm_forget(handle->base_ptr_scratch_A);
   dev_free(handle->base_ptr_scratch_A); handle->base_ptr_scratch_A = nullptr;
   free(handle->base_ptr_scratch_B_scratch_C); handle->base_ptr_scratch_B_scratch_C = nullptr;
 }
@@ -241,17 +249,20 @@ LIBXSMM_API int libxsmm_spmdm_get_num_createSparseSlice_blocks(const libxsmm_spm
 LIBXSMM_API int libxsmm_spmdm_get_num_compute_blocks(const libxsmm_spmdm_handle* handle) { return handle->mb * handle->nb; }
 
 namespace {
-// dense operands of the single-problem API may be host memory (unchanged caller): mirror them on the device once per call
-const float* mirror_in(const float* p, size_t elems, int slot, bool* ok)
+// Dense operands of the single-problem API may be host memory (an unchanged caller). They are mirrored in device scratch
+// buffers that have the shape of the whole matrix, but only the part a block call needs travels: rows [r0, r0 + nr) x
+// columns [c0, c0 + nc) of a row-major matrix with leading dimension ld (one strided copy).
+int copy_window(float* dev, float* host, int ld, int r0, int nr, int c0, int nc, bool to_device)
 {
-  if (is_device_ptr(p)) return p;
-  void* d = scratch(slot, elems * sizeof(float));
-  if (nullptr == d || 0 != h2d(d, p, elems * sizeof(float))) { *ok = false; return nullptr; }
-  return static_cast<const float*>(d);
-}
+  if (0 >= nr || 0 >= nc) return 0;
+  float* const d = dev + (size_t)r0 * ld + c0; float* const h = host + (size_t)r0 * ld + c0;
+  const size_t pitch = (size_t)ld * sizeof(float), width = (size_t)nc * sizeof(float);
+  hipStream_t st = (hipStream_t)device().stream;
+  const hipError_t e = to_device ? hipMemcpy2DAsync(d, pitch, h, pitch, width, (size_t)nr, hipMemcpyHostToDevice, st)
+                                 : hipMemcpy2DAsync(h, pitch, d, pitch, width, (size_t)nr, hipMemcpyDeviceToHost, st);
+  return (int)e;
 }
 
-namespace {
 // bfloat16 operands (reference: libxsmm_bfloat16 = the upper half of an IEEE float, src/libxsmm_spmdm_begin.h:69-75) are
 // widened to float in a device scratch buffer; from there on the fp32 kernels run unchanged -- exactly what the reference
 // templates do element by element (EXPAND_BFLOAT16 before the compare / the copy into scratch_B).
@@ -269,110 +280,125 @@ const float* widen_bf16(const libxsmm_bfloat16* p, size_t elems, int slot_raw, i
   return wide;
 }
 
-// ---- sweeps over the blocks of one problem -----------------------------------------------------------------------------
-// The reference's interface hands out one block per call (a thread's share of an OpenMP loop, samples/spmdm/spmdm.c:74-112).
-// One block is a few work-groups: launched call by call on one stream, a 2048^3 problem took 26 ms to slice and 17 ms to
-// multiply. A caller that walks the blocks from one thread (nthreads == 1) with device-resident operands gets the WHOLE
-// problem launched when it asks for the first block of a sweep; the remaining block calls of that sweep (same operands, a
-// block not yet asked for) find their work done and return. Asking for a block a second time, or with other operands,
-// starts a new sweep. (Blocks nobody asks for are computed as well: their tiles of C hold the product, too.)
-struct SpmdmSweep {
-  bool active = false; const void* p0 = nullptr; const void* p1 = nullptr; int t0 = 0, t1 = 0; float beta = 0.f;
-  std::vector<char> done;
-  // true: block_id belongs to the running sweep (nothing to do); false: the caller must launch the whole problem now
-  bool covered(const void* q0, const void* q1, int u0, int u1, float be, int block_id, int nblocks)
-  {
-    if (active && q0 == p0 && q1 == p1 && u0 == t0 && u1 == t1 && be == beta && block_id < (int)done.size() && 0 == done[block_id]) {
-      done[block_id] = 1;
-      bool all = true; for (char d : done) all = all && (0 != d);
-      if (all) active = false;
-      return true;
-    }
-    p0 = q0; p1 = q1; t0 = u0; t1 = u1; beta = be;
-    done.assign((size_t)(0 < nblocks ? nblocks : 1), 0);
-    if (0 <= block_id && block_id < nblocks) done[block_id] = 1;
-    active = (1 < nblocks);
-    return false;
-  }
-};
-struct SpmdmSweeps { SpmdmSweep create, compute; };
-std::mutex g_sweep_lock;
-std::unordered_map<const void*, SpmdmSweeps> g_sweeps; // keyed by the handle's device block
-
-void spmdm_forget(const void* device_block) { std::lock_guard<std::mutex> guard(g_sweep_lock); g_sweeps.erase(device_block); }
-
-void spmdm_create_block(const libxsmm_spmdm_handle* handle, int ta, const float* da, int block_id, bool sweep = false)
-{ // da: device-resident M x K (or K x M) fp32 matrix
-  const size_t nslices = (size_t)handle->mb * handle->kb, cap = (size_t)handle->bm * handle->bk;
-  float* const values = reinterpret_cast<float*>(handle->base_ptr_scratch_A);
-  uint16_t* const colidx = reinterpret_cast<uint16_t*>(handle->base_ptr_scratch_A + nslices * cap * sizeof(float));
-  uint16_t* const rowidx = colidx + nslices * cap;
-  const char* name = "";
-  int first = block_id, count = 1;
-  if (sweep) {
-    std::lock_guard<std::mutex> guard(g_sweep_lock);
-    SpmdmSweeps& w = g_sweeps[handle->base_ptr_scratch_A];
-    if (w.create.covered(da, nullptr, ta, 0, 0.f, block_id, (int)nslices)) return;
-    w.compute.active = false; // the slices change: whatever was multiplied belongs to the past
-    first = 0; count = (int)nslices;
-  }
-  const int e = launch_spmdm_create_blocks(handle->m, handle->k, handle->bm, handle->bk, handle->mb, first, count, ta, da,
-    rowidx, colidx, values, device().stream, &name);
-  note_launch(name);
-  if (0 != e) fprintf(stderr, "LIBXSMM-AMD ERROR: kernel launch failed (%s, hip error %d)\n", name, e);
+struct SliceArrays { float* values; uint16_t* colidx; uint16_t* rowidx; size_t cap, rstride; };
+SliceArrays slice_arrays(const libxsmm_spmdm_handle* handle)
+{
+  SliceArrays s;
+  const size_t nslices = (size_t)handle->mb * handle->kb;
+  s.cap = (size_t)handle->bm * handle->bk; s.rstride = (size_t)handle->bm + 1;
+  s.values = reinterpret_cast<float*>(handle->base_ptr_scratch_A);
+  s.colidx = reinterpret_cast<uint16_t*>(handle->base_ptr_scratch_A + nslices * s.cap * sizeof(float));
+  s.rowidx = s.colidx + nslices * s.cap;
+  return s;
 }
 
-void spmdm_compute_block(const libxsmm_spmdm_handle* handle, int tb, int tc, float beta, libxsmm_CSR_sparseslice* a_sparse,
-                         const float* db, float* c, int block_id, bool sync_inputs, bool sweep = false)
-{ // db: device-resident fp32 B; c: device or host
-  const int mb = block_id / handle->nb, nb = block_id % handle->nb; // compute tpl :38-39
-  int m0 = mb * handle->bm, n0 = nb * handle->bn;
-  int m1 = LIBXSMM_MIN(m0 + handle->bm, handle->m), n1 = LIBXSMM_MIN(n0 + handle->bn, handle->n);
-  float* dc = c; const bool c_host = !is_device_ptr(c);
-  if (sweep && !c_host && !sync_inputs) {
-    std::lock_guard<std::mutex> guard(g_sweep_lock);
-    SpmdmSweeps& w = g_sweeps[handle->base_ptr_scratch_A];
-    if (w.compute.covered(db, c, tb, tc, beta, block_id, handle->mb * handle->nb)) return;
-    m0 = 0; n0 = 0; m1 = handle->m; n1 = handle->n; // the whole product
-  }
-  const size_t celems = (size_t)handle->m * handle->n;
-  if (c_host) {
-    dc = static_cast<float*>(scratch(5, celems * sizeof(float)));
-    if (nullptr == dc || 0 != h2d(dc, c, celems * sizeof(float))) return;
-  }
-  const size_t cap = (size_t)handle->bm * handle->bk;
+// slices [first, first + count) of the device-resident M x K (or K x M) fp32 matrix da
+int spmdm_create_slices(const libxsmm_spmdm_handle* handle, int ta, const float* da, int first, int count)
+{
+  const SliceArrays s = slice_arrays(handle);
   const char* name = "";
-  // the slice arrays are one block: slice 0's pointers are the bases
-  const int e = launch_spmdm_compute_generic(1, handle->m, handle->n, handle->k, handle->bm, handle->bk, handle->mb, handle->kb,
-    tb, tc, beta, a_sparse[0].rowidx, a_sparse[0].colidx, a_sparse[0].values, (long long)handle->bm + 1, (long long)cap,
-    db, dc, 0, 0, m0, m1, n0, n1, device().stream, &name);
+  const int e = launch_spmdm_create_blocks(handle->m, handle->k, handle->bm, handle->bk, handle->mb, first, count, ta, da,
+    s.rowidx, s.colidx, s.values, device().stream, &name);
   note_launch(name);
-  if (0 != e) { fprintf(stderr, "LIBXSMM-AMD ERROR: kernel launch failed (%s, hip error %d)\n", name, e); return; }
-  if (c_host) { // copy back only this block's tile rows/columns: whole-matrix copy would clobber tiles of concurrent blocks
-    std::vector<float> tmp(celems);
-    if (0 != d2h(tmp.data(), dc, celems * sizeof(float))) return;
-    for (int m = m0; m < m1; ++m) for (int n = n0; n < n1; ++n) {
-      const size_t idx = tc ? ((size_t)n * handle->m + m) : ((size_t)m * handle->n + n);
-      c[idx] = tmp[idx];
+  if (0 != e) fprintf(stderr, "LIBXSMM-AMD ERROR: kernel launch failed (%s, hip error %d)\n", name, e);
+  return e;
+}
+
+// C tiles of the row blocks [mb0, mb0 + mbn) x columns [n0, n1): device-resident B and C
+int spmdm_compute_tiles(const libxsmm_spmdm_handle* handle, int tb, int tc, float beta, const float* db, float* dc, int mb0, int mbn, int n0, int n1)
+{
+  const SliceArrays s = slice_arrays(handle);
+  const char* name = "";
+  int e = launch_spmdm_compute_tiled(handle->m, handle->n, handle->k, handle->bm, handle->bk, handle->mb, handle->kb, tb, tc, beta,
+    s.rowidx, s.colidx, s.values, (long long)s.rstride, (long long)s.cap, db, dc, mb0, mbn, n0, n1, device().stream, &name);
+  if (e < 0) { // a geometry the tiled kernel does not take (handles not made by libxsmm_spmdm_init): a thread per C element
+    const int m0 = mb0 * handle->bm, m1 = LIBXSMM_MIN(m0 + mbn * handle->bm, handle->m);
+    e = launch_spmdm_compute_generic(1, handle->m, handle->n, handle->k, handle->bm, handle->bk, handle->mb, handle->kb, tb, tc, beta,
+      s.rowidx, s.colidx, s.values, (long long)s.rstride, (long long)s.cap, db, dc, 0, 0, m0, m1, n0, n1, device().stream, &name);
+  }
+  note_launch(name);
+  if (0 != e) fprintf(stderr, "LIBXSMM-AMD ERROR: kernel launch failed (%s, hip error %d)\n", name, e);
+  return e;
+}
+
+bool is_trans(char t) { return 'T' == t || 't' == t; }
+
+// one create call: `count` slices starting at `first`; a: float (widened already) or the caller's matrix
+void spmdm_create(const libxsmm_spmdm_handle* handle, char transa, const float* a, int first, int count, bool staged_input)
+{
+  const int ta = is_trans(transa) ? 1 : 0;
+  const float* da = a;
+  if (!staged_input && !is_device_ptr(a)) { // host matrix: only the rows/columns of these slices travel
+    float* const d = static_cast<float*>(scratch(3, (size_t)handle->m * handle->k * sizeof(float)));
+    if (nullptr == d) return;
+    if (0 == first && count == handle->mb * handle->kb) { // all slices: the whole matrix in one piece
+      if (0 != h2d(d, a, (size_t)handle->m * handle->k * sizeof(float))) return;
+    }
+    else for (int sl = first; sl < first + count; ++sl) {
+      const int kb = sl / handle->mb, mb = sl % handle->mb;
+      const int r0 = mb * handle->bm, nr = LIBXSMM_MIN(handle->bm, handle->m - r0), c0 = kb * handle->bk, nc = LIBXSMM_MIN(handle->bk, handle->k - c0);
+      const int e = ta ? copy_window(d, const_cast<float*>(a), handle->m, c0, nc, r0, nr, true) : copy_window(d, const_cast<float*>(a), handle->k, r0, nr, c0, nc, true);
+      if (0 != e) return;
+    }
+    da = d; staged_input = true;
+  }
+  if (0 != spmdm_create_slices(handle, ta, da, first, count)) return;
+  if (staged_input) (void)stream_sync(); // the staging buffer is reused by the next call
+  else settle(a);
+}
+
+// one compute call: row blocks [mb0, mb0 + mbn) x columns [n0, n1) of C
+void spmdm_compute(const libxsmm_spmdm_handle* handle, char transb, const float* b, bool staged_b, char transc, float beta, float* c,
+                   int mb0, int mbn, int n0, int n1)
+{
+  const int tb = is_trans(transb) ? 1 : 0, tc = is_trans(transc) ? 1 : 0;
+  const float* db = b;
+  if (!staged_b && !is_device_ptr(b)) {
+    float* const d = static_cast<float*>(scratch(4, (size_t)handle->k * handle->n * sizeof(float)));
+    if (nullptr == d) return;
+    // columns [n0, n1) of B (all k): B[k][n] resp. rows [n0, n1) of B[n][k]
+    const int e = tb ? copy_window(d, const_cast<float*>(b), handle->k, n0, n1 - n0, 0, handle->k, true) : copy_window(d, const_cast<float*>(b), handle->n, 0, handle->k, n0, n1 - n0, true);
+    if (0 != e) return;
+    db = d; staged_b = true;
+  }
+  const int m0 = mb0 * handle->bm, m1 = LIBXSMM_MIN(m0 + mbn * handle->bm, handle->m);
+  float* dc = c;
+  const bool c_host = !is_device_ptr(c);
+  if (c_host) { // the tile travels in (beta != 0) and out; nothing else of C is touched
+    dc = static_cast<float*>(scratch(5, (size_t)handle->m * handle->n * sizeof(float)));
+    if (nullptr == dc) return;
+    if (0.f != beta) {
+      const int e = tc ? copy_window(dc, c, handle->m, n0, n1 - n0, m0, m1 - m0, true) : copy_window(dc, c, handle->n, m0, m1 - m0, n0, n1 - n0, true);
+      if (0 != e) return;
     }
   }
-  else if (sync_inputs) (void)stream_sync(); // staged inputs are reused by the next call
-  else settle(db, c);
+  if (0 != spmdm_compute_tiles(handle, tb, tc, beta, db, dc, mb0, mbn, n0, n1)) return;
+  if (c_host) {
+    (void)(tc ? copy_window(dc, c, handle->m, n0, n1 - n0, m0, m1 - m0, false) : copy_window(dc, c, handle->n, m0, m1 - m0, n0, n1 - n0, false));
+    (void)stream_sync();
+  }
+  else if (staged_b) (void)stream_sync(); // staged inputs are reused by the next call
+  else settle(b, c);
+}
+
+bool spmdm_block_ok(const libxsmm_spmdm_handle* handle, int block_id, int nblocks, const char* what)
+{
+  if (0 <= block_id && block_id < nblocks) return true;
+  static int error_once = 0;
+  if (0 != libxsmm_verbosity && once(&error_once)) fprintf(stderr, "LIBXSMM ERROR: %s: block id %d out of range (handle has %d blocks)!\n", what, block_id, nblocks);
+  (void)handle;
+  return false;
 }
 }
 
 LIBXSMM_API void libxsmm_spmdm_createSparseSlice_fp32_thread(const libxsmm_spmdm_handle* handle, char transa,
   const float* a, libxsmm_CSR_sparseslice* libxsmm_output_csr_a, int block_id, int tid, int nthreads)
 {
-  (void)tid;
+  (void)tid; (void)nthreads;
   if (nullptr == handle || nullptr == a || nullptr == libxsmm_output_csr_a || nullptr == handle->base_ptr_scratch_A) return;
   if (!device_ready()) { fail_no_device("libxsmm_spmdm_createSparseSlice_fp32_thread"); return; }
-  bool ok = true;
-  const float* const da = mirror_in(a, (size_t)handle->m * handle->k, 3, &ok);
-  if (!ok) return;
-  spmdm_create_block(handle, ('T' == transa || 't' == transa), da, block_id, 1 == nthreads && da == a && !is_host_visible(a));
-  if (da != a) (void)stream_sync(); // the staging buffer is reused by the next call
-  else settle(a);
+  if (!spmdm_block_ok(handle, block_id, handle->mb * handle->kb, "libxsmm_spmdm_createSparseSlice_fp32_thread")) return;
+  spmdm_create(handle, transa, a, block_id, 1, false);
 }
 
 LIBXSMM_API void libxsmm_spmdm_createSparseSlice_bfloat16_thread(const libxsmm_spmdm_handle* handle, char transa,
@@ -381,25 +407,23 @@ LIBXSMM_API void libxsmm_spmdm_createSparseSlice_bfloat16_thread(const libxsmm_s
   (void)tid; (void)nthreads;
   if (nullptr == handle || nullptr == a || nullptr == libxsmm_output_csr_a || nullptr == handle->base_ptr_scratch_A) return;
   if (!device_ready()) { fail_no_device("libxsmm_spmdm_createSparseSlice_bfloat16_thread"); return; }
+  if (!spmdm_block_ok(handle, block_id, handle->mb * handle->kb, "libxsmm_spmdm_createSparseSlice_bfloat16_thread")) return;
   bool ok = true;
   const float* const da = widen_bf16(a, (size_t)handle->m * handle->k, 6, 3, &ok);
   if (!ok) return;
-  spmdm_create_block(handle, ('T' == transa || 't' == transa), da, block_id);
-  (void)stream_sync(); // the widened copy lives in a reused scratch buffer
+  spmdm_create(handle, transa, da, block_id, 1, true);
 }
 
 LIBXSMM_API void libxsmm_spmdm_compute_fp32_thread(const libxsmm_spmdm_handle* handle, char transa, char transb,
   const float* alpha, libxsmm_CSR_sparseslice* a_sparse, const float* b, char transc, const float* beta, float* c,
   int block_id, int tid, int nthreads)
 {
-  (void)transa; (void)alpha; (void)tid; // alpha is ignored by the reference (include/libxsmm_spmdm.h:104)
+  (void)transa; (void)alpha; (void)tid; (void)nthreads; // alpha is ignored by the reference (include/libxsmm_spmdm.h:104)
   if (nullptr == handle || nullptr == a_sparse || nullptr == b || nullptr == c || nullptr == beta) return;
   if (!device_ready()) { fail_no_device("libxsmm_spmdm_compute_fp32_thread"); return; }
-  bool ok = true;
-  const float* const db = mirror_in(b, (size_t)handle->k * handle->n, 4, &ok);
-  if (!ok) return;
-  spmdm_compute_block(handle, ('T' == transb || 't' == transb), ('T' == transc || 't' == transc), *beta, a_sparse, db, c, block_id, db != b,
-    1 == nthreads && db == b && !is_host_visible(b) && !is_host_visible(c));
+  if (!spmdm_block_ok(handle, block_id, handle->mb * handle->nb, "libxsmm_spmdm_compute_fp32_thread")) return;
+  const int mb = block_id / handle->nb, nb = block_id % handle->nb; // compute tpl :38-39
+  spmdm_compute(handle, transb, b, false, transc, *beta, c, mb, 1, nb * handle->bn, LIBXSMM_MIN((nb + 1) * handle->bn, handle->n));
 }
 
 LIBXSMM_API void libxsmm_spmdm_compute_bfloat16_thread(const libxsmm_spmdm_handle* handle, char transa, char transb,
@@ -411,10 +435,59 @@ LIBXSMM_API void libxsmm_spmdm_compute_bfloat16_thread(const libxsmm_spmdm_handl
   (void)transa; (void)alpha; (void)tid; (void)nthreads;
   if (nullptr == handle || nullptr == a_sparse || nullptr == b || nullptr == c || nullptr == beta) return;
   if (!device_ready()) { fail_no_device("libxsmm_spmdm_compute_bfloat16_thread"); return; }
+  if (!spmdm_block_ok(handle, block_id, handle->mb * handle->nb, "libxsmm_spmdm_compute_bfloat16_thread")) return;
   bool ok = true;
   const float* const db = widen_bf16(b, (size_t)handle->k * handle->n, 6, 4, &ok);
   if (!ok) return;
-  spmdm_compute_block(handle, ('T' == transb || 't' == transb), ('T' == transc || 't' == transc), (float)(*beta), a_sparse, db, c, block_id, true);
+  const int mb = block_id / handle->nb, nb = block_id % handle->nb;
+  spmdm_compute(handle, transb, db, true, transc, (float)(*beta), c, mb, 1, nb * handle->bn, LIBXSMM_MIN((nb + 1) * handle->bn, handle->n));
+}
+
+// ---- the whole problem in one call (extension) -------------------------------------------------------------------------
+// Equivalent to calling the *_thread function for every block id, as one launch that fills the chip: what a caller that
+// owns the whole loop (samples/spmdm/spmdm.c:74-112) uses instead of the loop.
+LIBXSMM_API int libxsmm_amd_spmdm_createSparseSlice_all(const libxsmm_spmdm_handle* handle, char transa, const float* a,
+  libxsmm_CSR_sparseslice* libxsmm_output_csr_a)
+{
+  if (nullptr == handle || nullptr == a || nullptr == libxsmm_output_csr_a || nullptr == handle->base_ptr_scratch_A) return EXIT_FAILURE;
+  if (!device_ready()) { fail_no_device("libxsmm_amd_spmdm_createSparseSlice_all"); return EXIT_FAILURE; }
+  spmdm_create(handle, transa, a, 0, handle->mb * handle->kb, false);
+  return EXIT_SUCCESS;
+}
+
+LIBXSMM_API int libxsmm_amd_spmdm_compute_all(const libxsmm_spmdm_handle* handle, char transa, char transb, const float* alpha,
+  libxsmm_CSR_sparseslice* a_sparse, const float* b, char transc, const float* beta, float* c)
+{
+  (void)transa; (void)alpha;
+  if (nullptr == handle || nullptr == a_sparse || nullptr == b || nullptr == c || nullptr == beta) return EXIT_FAILURE;
+  if (!device_ready()) { fail_no_device("libxsmm_amd_spmdm_compute_all"); return EXIT_FAILURE; }
+  spmdm_compute(handle, transb, b, false, transc, *beta, c, 0, handle->mb, 0, handle->n);
+  return EXIT_SUCCESS;
+}
+
+LIBXSMM_API int libxsmm_amd_spmdm_createSparseSlice_bfloat16_all(const libxsmm_spmdm_handle* handle, char transa, const libxsmm_bfloat16* a,
+  libxsmm_CSR_sparseslice* libxsmm_output_csr_a)
+{
+  if (nullptr == handle || nullptr == a || nullptr == libxsmm_output_csr_a || nullptr == handle->base_ptr_scratch_A) return EXIT_FAILURE;
+  if (!device_ready()) { fail_no_device("libxsmm_amd_spmdm_createSparseSlice_bfloat16_all"); return EXIT_FAILURE; }
+  bool ok = true;
+  const float* const da = widen_bf16(a, (size_t)handle->m * handle->k, 6, 3, &ok);
+  if (!ok) return EXIT_FAILURE;
+  spmdm_create(handle, transa, da, 0, handle->mb * handle->kb, true);
+  return EXIT_SUCCESS;
+}
+
+LIBXSMM_API int libxsmm_amd_spmdm_compute_bfloat16_all(const libxsmm_spmdm_handle* handle, char transa, char transb, const libxsmm_bfloat16* alpha,
+  libxsmm_CSR_sparseslice* a_sparse, const libxsmm_bfloat16* b, char transc, const libxsmm_bfloat16* beta, float* c)
+{
+  (void)transa; (void)alpha;
+  if (nullptr == handle || nullptr == a_sparse || nullptr == b || nullptr == c || nullptr == beta) return EXIT_FAILURE;
+  if (!device_ready()) { fail_no_device("libxsmm_amd_spmdm_compute_bfloat16_all"); return EXIT_FAILURE; }
+  bool ok = true;
+  const float* const db = widen_bf16(b, (size_t)handle->k * handle->n, 6, 4, &ok);
+  if (!ok) return EXIT_FAILURE;
+  spmdm_compute(handle, transb, db, true, transc, (float)(*beta), c, 0, handle->mb, 0, handle->n);
+  return EXIT_SUCCESS;
 }
 
 // ---------------------------------------------------------------------------------------------------------------

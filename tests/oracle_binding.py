@@ -201,13 +201,22 @@ def spmdm_exec_batch(arith, M, N, K, bn_isa, transa, transb, transc, beta, a, b,
                               C.c_char(transc.encode()), C.c_float(beta), p(a), p(b), p(c), C.c_longlong(batch), nthreads)
 
 
-def spmdm_slices(M, N, K, bn_isa, transa, a, max_threads=1):
-    """createSparseSlice on every block; returns (handle, [(rowidx, colidx, values)] indexed kb*mb_count+mb)"""
-    h = spmdm_init(M, N, K, max_threads, bn_isa)
+def spmdm_geometry(M, N, K, bm, bn, bk):
+    """a handle with a given block geometry (results do not depend on it; slices do)"""
+    h = SpmdmHandle()
+    h.m, h.n, h.k, h.bm, h.bn, h.bk = M, N, K, bm, bn, bk
+    h.mb, h.nb, h.kb = (M + bm - 1) // bm, (N + bn - 1) // bn, (K + bk - 1) // bk
+    return h
 
-    class Slice(C.Structure):
-        _fields_ = [("rowidx", C.POINTER(C.c_uint16)), ("colidx", C.POINTER(C.c_uint16)), ("values", C.POINTER(C.c_float))]
-    lib().xo_spmdm_alloc_slices.restype = C.POINTER(Slice)
+
+class _Slice(C.Structure):
+    _fields_ = [("rowidx", C.POINTER(C.c_uint16)), ("colidx", C.POINTER(C.c_uint16)), ("values", C.POINTER(C.c_float))]
+
+
+def spmdm_slices(M, N, K, bn_isa, transa, a, max_threads=1, handle=None):
+    """createSparseSlice on every block; returns (handle, [(rowidx, colidx, values)] indexed kb*mb_count+mb)"""
+    h = handle if handle is not None else spmdm_init(M, N, K, max_threads, bn_isa)
+    lib().xo_spmdm_alloc_slices.restype = C.POINTER(_Slice)
     s = lib().xo_spmdm_alloc_slices(C.byref(h))
     out = []
     for blk in range(h.mb * h.kb):
@@ -222,6 +231,19 @@ def spmdm_slices(M, N, K, bn_isa, transa, a, max_threads=1):
         out.append((ri, ci, va))
     lib().xo_spmdm_free_slices(C.byref(h), s)
     return h, out
+
+
+def spmdm_compute_blocks(arith, h, transa, transb, transc, beta, a, b, c, blocks):
+    """slices of `a` under geometry `h`, then xo_spmdm_compute for the listed compute block ids only (in place on c)"""
+    lib().xo_spmdm_alloc_slices.restype = C.POINTER(_Slice)
+    s = lib().xo_spmdm_alloc_slices(C.byref(h))
+    for blk in range(h.mb * h.kb):
+        lib().xo_spmdm_create_slice(C.byref(h), C.c_char(transa.encode()), p(a), s, blk)
+    alpha, be = C.c_float(1.0), C.c_float(beta)
+    for blk in blocks:
+        lib().xo_spmdm_compute(arith, C.byref(h), C.c_char(transa.encode()), C.c_char(transb.encode()), C.byref(alpha), s, p(b),
+                               C.c_char(transc.encode()), C.byref(be), p(c), blk)
+    lib().xo_spmdm_free_slices(C.byref(h), s)
 
 
 class Bgemm(C.Structure):

@@ -280,65 +280,214 @@ def test_spmdm_batch_config4(xs, orc, torch_gpu, keep, variant):
     L.libxsmm_amd_spmdm_batch_destroy(sb)
 
 
-def test_spmdm_block_sweeps(xs, orc, torch_gpu):
-    """The per-block interface walked from one thread: the whole problem is launched with the first block of a sweep and the
-    other block calls of that sweep return at once (csrc/xsmm_sparse.cpp). Checked here: a second sweep over the same
-    pointers after B changed recomputes; beta = 1 sweeps accumulate once per sweep; asking for a block twice starts a new
-    sweep; blocks in reverse order; new slices after A changed; several tasks (nthreads > 1) keep the per-block path."""
+def _device_slices(xs, h, slices):
+    """the handle's CSR slices copied from HBM: [(rowidx, colidx, values)] indexed kb*mb_count+mb"""
+    L = xs.lib()
+    out = []
+    for blk in range(h.mb * h.kb):
+        nrows = min(h.bm, h.m - (blk % h.mb) * h.bm)
+        ri = np.zeros(nrows + 1, dtype=np.uint16)
+        assert 0 == L.libxsmm_amd_memcpy_d2h(xs.dptr(ri), slices[blk].rowidx, ri.nbytes)
+        nnz = int(ri[nrows])
+        ci = np.zeros(max(nnz, 1), dtype=np.uint16); va = np.zeros(max(nnz, 1), dtype=np.float32)
+        if nnz:
+            assert 0 == L.libxsmm_amd_memcpy_d2h(xs.dptr(ci), slices[blk].colidx, 2 * nnz)
+            assert 0 == L.libxsmm_amd_memcpy_d2h(xs.dptr(va), slices[blk].values, 4 * nnz)
+        out.append((ri, ci[:nnz], va[:nnz]))
+    return out
+
+
+@pytest.mark.parametrize("transa", ["N", "T"])
+def test_spmdm_reference_slices_bitexact(xs, orc, torch_gpu, transa):
+    """createSparseSlice on one large matrix: every (kb, mb) slice -- row starts, uint16 column indexes, values -- equals the
+    oracle's slice of the same block geometry (createSparseSlice tpl :47-141), block by block and through the one-call
+    extension; -0 is dropped, NaN is kept; ragged last blocks in both directions."""
     torch = torch_gpu
-    M, N, K = 301, 131, 263
-    a, b, c = spmdm_inputs(M, N, K, 0.85, 2, orc)
+    M, K, N = 1100, 203, 40
+    rng = np.random.default_rng(5)
+    a = rng.uniform(-1, 1, M * K).astype(np.float32)
+    a[rng.random(M * K) < 0.8] = 0.0
+    a[7] = -0.0; a[11] = np.nan
+    a2d = a.reshape(K, M) if transa == "T" else a.reshape(M, K)
+    if transa == "T":
+        a2d[:, 600:664] = 1.25; a2d[:, 5] = 0.0   # 64 dense rows (a full tile of entries), an empty row
+    else:
+        a2d[600:664, :] = 1.25; a2d[5, :] = 0.0
+    L = xs.lib()
+    h = xs.SpmdmHandle(); slices = C.POINTER(xs.CSRSlice)()
+    L.libxsmm_spmdm_init(M, N, K, 1, C.byref(h), C.byref(slices))
+    assert h.mb > 1 and h.kb > 1 and h.bm * h.bk <= 65535
+    oh, osl = orc.spmdm_slices(M, N, K, 48, transa, a, handle=orc.spmdm_geometry(M, N, K, h.bm, h.bn, h.bk))
+    da = torch.from_numpy(a).cuda()
+    nblk = L.libxsmm_spmdm_get_num_createSparseSlice_blocks(C.byref(h))
+    assert nblk == h.mb * h.kb == len(osl)
+    for how in ("blocks", "all", "host"):
+        if how == "blocks":
+            for blk in reversed(range(nblk)):
+                L.libxsmm_spmdm_createSparseSlice_fp32_thread(C.byref(h), transa.encode(), xs.dptr(da), slices, blk, 0, 1)
+            assert xs.last_kernel() == "spmdm_create_slice_wg"
+        elif how == "all":
+            assert 0 == L.libxsmm_amd_spmdm_createSparseSlice_all(C.byref(h), transa.encode(), xs.dptr(da), slices)
+        else:  # pageable host matrix, block by block
+            for blk in range(nblk):
+                L.libxsmm_spmdm_createSparseSlice_fp32_thread(C.byref(h), transa.encode(), xs.dptr(a), slices, blk, 0, 1)
+        torch.cuda.synchronize()
+        got = _device_slices(xs, h, slices)
+        for blk, ((ri, ci, va), (oi, oc, ov)) in enumerate(zip(got, osl)):
+            assert np.array_equal(ri, oi), (how, blk)
+            assert np.array_equal(ci, oc), (how, blk)
+            assert np.array_equal(va.view(np.uint32), ov.view(np.uint32)), (how, blk)
+        # clear the slices between the rounds: the next round must rewrite everything it claims
+        nsl = h.mb * h.kb
+        assert 0 == L.libxsmm_amd_memcpy_h2d(slices[0].values, xs.dptr(np.zeros(nsl * h.bm * h.bk, dtype=np.float32)), 4 * nsl * h.bm * h.bk)
+    L.libxsmm_spmdm_destroy(C.byref(h))
+
+
+def test_spmdm_block_contract(xs, orc, torch_gpu):
+    """The per-block interface keeps the reference's contract (compute tpl :38-39, 509-558; createSparseSlice tpl :47-141): a
+    call touches the C tile resp. the slice of its block id and nothing else, with the operands of THAT call.
+    (i) every compute block with its own B and beta = 1; (ii) a subset of the blocks: the other tiles keep their NaN
+    canaries bit for bit; (iii) B changed in place between two block calls; (iv) a subset of the create blocks after A
+    changed: only those slices change."""
+    torch = torch_gpu
+    M, N, K = 1100, 2300, 150   # mb = 3, nb = 2, kb = 3 with the engine's geometry
+    a, b, c = spmdm_inputs(M, N, K, 0.85, 3, orc)
     L = xs.lib()
     h = xs.SpmdmHandle(); slices = C.POINTER(xs.CSRSlice)()
     L.libxsmm_spmdm_init(M, N, K, 1, C.byref(h), C.byref(slices))
     ncreate, ncomp = L.libxsmm_spmdm_get_num_createSparseSlice_blocks(C.byref(h)), L.libxsmm_spmdm_get_num_compute_blocks(C.byref(h))
-    assert ncreate > 1 and ncomp > 1
+    assert ncreate >= 4 and ncomp >= 4 and h.nb >= 2 and h.mb >= 2
+    geom = lambda: orc.spmdm_geometry(M, N, K, h.bm, h.bn, h.bk)
     da, db, dc = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), torch.from_numpy(c).cuda()
     alpha = C.c_float(1.0)
 
-    def create(order=None, nthreads=1):
-        for blk in (order if order is not None else range(ncreate)):
-            L.libxsmm_spmdm_createSparseSlice_fp32_thread(C.byref(h), b"N", xs.dptr(da), slices, blk, blk % nthreads, nthreads)
+    def create(blocks, src=None):
+        for blk in blocks:
+            L.libxsmm_spmdm_createSparseSlice_fp32_thread(C.byref(h), b"N", xs.dptr(da if src is None else src), slices, blk, 0, 1)
 
-    def compute(beta, order=None, nthreads=1):
+    def compute(blk, beta, bdev):
         be = C.c_float(beta)
-        for blk in (order if order is not None else range(ncomp)):
-            L.libxsmm_spmdm_compute_fp32_thread(C.byref(h), b"N", b"N", C.byref(alpha), slices, xs.dptr(db), b"N", C.byref(be), xs.dptr(dc), blk, blk % nthreads, nthreads)
-        torch.cuda.synchronize()
-        return dc.cpu().numpy()
+        L.libxsmm_spmdm_compute_fp32_thread(C.byref(h), b"N", b"N", C.byref(alpha), slices, xs.dptr(bdev), b"N", C.byref(be), xs.dptr(dc), blk, 0, 1)
 
-    def gold(a_, b_, c_, beta):
-        r = c_.copy(); orc.spmdm_exec(orc.FMA, M, N, K, 48, "N", "N", "N", beta, a_, b_, r); return r
-
-    create()
+    create(range(ncreate))
+    # (i) block i multiplies with its own B_i, beta = 1: one launch per call, each adds its own product to its own tile
+    bs = [(b * (1.0 + 0.25 * i) + 0.125 * i).astype(np.float32) for i in range(ncomp)]
+    dbs = [torch.from_numpy(x).cuda() for x in bs]
     launches = L.libxsmm_amd_launch_count()
-    out = compute(0.0)
-    assert L.libxsmm_amd_launch_count() == launches + 1  # one launch for the whole sweep
-    assert np.array_equal(out, gold(a, b, c, 0.0))
-    # B changes in place, same pointers: the next sweep (block 0 asked for again) recomputes
-    b2 = (b * 0.5 + 0.25).astype(np.float32); db.copy_(torch.from_numpy(b2))
-    out = compute(0.0, order=list(reversed(range(ncomp))))
-    assert np.array_equal(out, gold(a, b2, c, 0.0))
-    # beta = 1: one accumulation per sweep
-    c1 = gold(a, b2, c, 0.0)
-    out = compute(1.0)
-    assert np.array_equal(out, gold(a, b2, c1, 1.0))
-    out = compute(1.0)
-    assert np.array_equal(out, gold(a, b2, gold(a, b2, c1, 1.0), 1.0))
-    # a sweep that is abandoned half way, then a full one
-    out = compute(0.0, order=[0, 1])
-    out = compute(0.0)
-    assert np.array_equal(out, gold(a, b2, c, 0.0))
-    # A changes: new slices, then the product must use them (a compute sweep may not survive new slices)
-    a2 = a.copy(); a2[::7] = 0.0; a2[3::11] *= 2.0; da.copy_(torch.from_numpy(a2))
-    out_before = compute(0.0)  # still the old slices
-    assert np.array_equal(out_before, gold(a, b2, c, 0.0))
-    create(order=list(reversed(range(ncreate))))
-    out = compute(0.0)
-    assert np.array_equal(out, gold(a2, b2, c, 0.0))
-    # several tasks: block by block
-    launches = L.libxsmm_amd_launch_count()
-    out = compute(0.0, nthreads=3)
+    for i in range(ncomp):
+        compute(i, 1.0, dbs[i])
     assert L.libxsmm_amd_launch_count() == launches + ncomp
-    assert np.array_equal(out, gold(a2, b2, c, 0.0))
+    assert xs.last_kernel() == "spmdm_compute_tiled"
+    torch.cuda.synchronize()
+    ref = c.copy()
+    for i in range(ncomp):
+        orc.spmdm_compute_blocks(orc.FMA, geom(), "N", "N", "N", 1.0, a, bs[i], ref, [i])
+    assert np.array_equal(dc.cpu().numpy(), ref)
+    # (ii) a subset of the blocks, beta = 0 then beta = 1: every other tile keeps its canary
+    for beta in (0.0, 1.0):
+        canary = np.full(M * N, np.nan, dtype=np.float32)
+        canary.view(np.uint32)[:] = 0x7FC00000 + (np.arange(M * N, dtype=np.uint32) & 0xFFFF)  # NaNs with distinct payloads
+        subset = [1, ncomp - 1]
+        start = canary.copy()
+        if beta != 0.0:  # the tiles that are computed hold numbers
+            tmp = c.copy(); mask = np.zeros(M * N, dtype=bool)
+            for blk in subset:
+                mb, nb = blk // h.nb, blk % h.nb
+                m2 = np.zeros((M, N), dtype=bool); m2[mb * h.bm:(mb + 1) * h.bm, nb * h.bn:(nb + 1) * h.bn] = True
+                mask |= m2.reshape(-1)
+            start[mask] = tmp[mask]
+        dc.copy_(torch.from_numpy(start))
+        for blk in subset:
+            compute(blk, beta, db)
+        torch.cuda.synchronize()
+        ref = start.copy()
+        orc.spmdm_compute_blocks(orc.FMA, geom(), "N", "N", "N", beta, a, b, ref, subset)
+        out = dc.cpu().numpy()
+        assert np.array_equal(out.view(np.uint32), ref.view(np.uint32)), beta
+        assert np.isnan(out).sum() == np.isnan(ref).sum() > 0
+    # (iii) B modified in place between two block calls: the second call sees the new B
+    dc.copy_(torch.from_numpy(c)); dbm = torch.from_numpy(b).cuda()
+    compute(0, 0.0, dbm)
+    b2 = (b * 0.5 + 0.25).astype(np.float32); dbm.copy_(torch.from_numpy(b2))
+    compute(1, 0.0, dbm)
+    torch.cuda.synchronize()
+    ref = c.copy()
+    orc.spmdm_compute_blocks(orc.FMA, geom(), "N", "N", "N", 0.0, a, b, ref, [0])
+    orc.spmdm_compute_blocks(orc.FMA, geom(), "N", "N", "N", 0.0, a, b2, ref, [1])
+    assert np.array_equal(dc.cpu().numpy(), ref)
+    # (iv) A changes, only two create blocks are called: exactly those slices change
+    before = _device_slices(xs, h, slices)
+    a2 = a.copy(); a2[::7] = 0.0; a2[3::11] *= 2.0; a2[a2 == 0.0] = 0.0
+    da2 = torch.from_numpy(a2).cuda()
+    redo = [0, ncreate - 1]
+    create(redo, da2)
+    torch.cuda.synchronize()
+    after = _device_slices(xs, h, slices)
+    _, o2 = orc.spmdm_slices(M, N, K, 48, "N", a2, handle=geom())
+    for blk in range(ncreate):
+        want = o2[blk] if blk in redo else before[blk]
+        for x, y in zip(after[blk], want):
+            assert np.array_equal(x.view(np.uint16 if x.dtype == np.uint16 else np.uint32), y.view(np.uint16 if y.dtype == np.uint16 else np.uint32)), blk
     L.libxsmm_spmdm_destroy(C.byref(h))
+
+
+@pytest.mark.parametrize("case", [
+    # M, N, K, keep-threshold, (ta, tb, tc), beta
+    (700, 515, 330, 0.85, ("N", "N", "N"), 1.0),     # N % 4 != 0: element-wide global accesses
+    (700, 516, 328, 0.85, ("N", "N", "N"), 0.5),     # 16-byte accesses, ragged tiles in every direction
+    (130, 2304, 200, 0.0, ("N", "N", "N"), 0.0),     # fully dense A: 4096 entries per tile and column block (several windows)
+    (520, 260, 132, 0.5, ("T", "T", "T"), 1.0),
+    (520, 260, 132, 0.5, ("N", "T", "N"), 0.0),
+    (520, 258, 131, 0.5, ("T", "N", "T"), 0.5),
+    (64, 48, 64, 0.5, ("N", "N", "N"), 0.0),         # the config-4 problem as a single call
+    (1, 1, 1, 0.0, ("N", "N", "N"), 1.0),
+])
+def test_spmdm_whole_problem_calls(xs, orc, torch_gpu, case):
+    """libxsmm_amd_spmdm_createSparseSlice_all / _compute_all: the caller's two loops over block ids as one launch each;
+    equal to the oracle bit for bit. Device operands and pageable host operands."""
+    torch = torch_gpu
+    M, N, K, keep, (ta, tb, tc), beta = case
+    a, b, c = spmdm_inputs(M, N, K, keep, 4, orc) if M * K < 200000 else (None, None, None)
+    if a is None:
+        rng = np.random.default_rng(9)
+        a = rng.uniform(0, 1, M * K).astype(np.float32); a[rng.random(M * K) < keep] = 0.0
+        b = rng.uniform(0, 1, K * N).astype(np.float32); c = rng.uniform(0, 1, M * N).astype(np.float32)
+    if beta == 0.0:
+        c[:] = np.nan
+    ref = c.copy()
+    orc.spmdm_exec(orc.FMA, M, N, K, 48, ta, tb, tc, beta, a, b, ref)
+    L = xs.lib()
+    alpha, be = C.c_float(1.0), C.c_float(beta)
+    for on_device in (True, False):
+        h = xs.SpmdmHandle(); slices = C.POINTER(xs.CSRSlice)()
+        L.libxsmm_spmdm_init(M, N, K, 1, C.byref(h), C.byref(slices))
+        xa, xb, xc = (torch.from_numpy(x).cuda() for x in (a, b, c)) if on_device else (a, b, c.copy())
+        launches = L.libxsmm_amd_launch_count()
+        assert 0 == L.libxsmm_amd_spmdm_createSparseSlice_all(C.byref(h), ta.encode(), xs.dptr(xa), slices)
+        assert 0 == L.libxsmm_amd_spmdm_compute_all(C.byref(h), ta.encode(), tb.encode(), C.byref(alpha), slices, xs.dptr(xb), tc.encode(), C.byref(be), xs.dptr(xc))
+        assert L.libxsmm_amd_launch_count() == launches + 2
+        assert xs.last_kernel() == "spmdm_compute_tiled"
+        torch.cuda.synchronize()
+        out = xc.cpu().numpy() if on_device else xc
+        L.libxsmm_spmdm_destroy(C.byref(h))
+        assert np.array_equal(out.view(np.uint32), ref.view(np.uint32)), on_device
+
+
+def test_spmdm_whole_problem_bfloat16(xs, orc, torch_gpu):
+    """bfloat16 twins of the one-call extension (same widening and `*beta` reading as the *_thread functions)."""
+    torch = torch_gpu
+    M, N, K = 600, 136, 200
+    a32, b32, c = spmdm_inputs(M, N, K, 0.7, 1, orc)
+    a = (a32.view(np.uint32) >> 16).astype(np.uint16); b = (b32.view(np.uint32) >> 16).astype(np.uint16)
+    ref = c.copy()
+    orc.spmdm_exec_bf16(orc.FMA, M, N, K, 48, "N", "N", "N", 1, a, b, ref)
+    L = xs.lib()
+    h = xs.SpmdmHandle(); slices = C.POINTER(xs.CSRSlice)()
+    L.libxsmm_spmdm_init(M, N, K, 1, C.byref(h), C.byref(slices))
+    xa, xb, xc = torch.from_numpy(a.view(np.int16)).cuda(), torch.from_numpy(b.view(np.int16)).cuda(), torch.from_numpy(c).cuda()
+    alpha, be = C.c_ushort(0x3F80), C.c_ushort(1)
+    assert 0 == L.libxsmm_amd_spmdm_createSparseSlice_bfloat16_all(C.byref(h), b"N", xs.dptr(xa), slices)
+    assert 0 == L.libxsmm_amd_spmdm_compute_bfloat16_all(C.byref(h), b"N", b"N", C.byref(alpha), slices, xs.dptr(xb), b"N", C.byref(be), xs.dptr(xc))
+    torch.cuda.synchronize()
+    L.libxsmm_spmdm_destroy(C.byref(h))
+    assert np.array_equal(xc.cpu().numpy(), ref)

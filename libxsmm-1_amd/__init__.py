@@ -167,6 +167,8 @@ def _declare(L):
     sig("libxsmm_spmdm_createSparseSlice_bfloat16_thread", None, C.POINTER(SpmdmHandle), C.c_char, vp, C.POINTER(CSRSlice), i, i, i)
     sig("libxsmm_spmdm_compute_bfloat16_thread", None, C.POINTER(SpmdmHandle), C.c_char, C.c_char, vp, C.POINTER(CSRSlice), vp,
         C.c_char, vp, vp, i, i, i)
+    sig("libxsmm_amd_memcpy_h2d", i, vp, vp, C.c_size_t)
+    sig("libxsmm_amd_memcpy_d2h", i, vp, vp, C.c_size_t)
     sig("libxsmm_amd_spmdm_createSparseSlice_all", i, C.POINTER(SpmdmHandle), C.c_char, vp, C.POINTER(CSRSlice))
     sig("libxsmm_amd_spmdm_compute_all", i, C.POINTER(SpmdmHandle), C.c_char, C.c_char, vp, C.POINTER(CSRSlice), vp, C.c_char, vp, vp)
     sig("libxsmm_amd_spmdm_createSparseSlice_bfloat16_all", i, C.POINTER(SpmdmHandle), C.c_char, vp, C.POINTER(CSRSlice))

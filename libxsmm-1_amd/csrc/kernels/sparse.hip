@@ -118,11 +118,12 @@ void spmdm_create_kernel(long long nslices, int nrows_full, int ncols_full, int 
   }
 }
 
-// Block form of one large matrix (the reference API, slices of bm <= 512 rows x bk <= 64 columns): a work-group of eight
-// waves per slice. Wave w owns a contiguous share of the slice's rows; a first pass counts its entries (__ballot +
-// popcount per row), the eight counts are exchanged through LDS, a second pass (the rows come out of L2 this time)
-// writes rowidx / colidx / values at the positions the sequential scan of the reference gives them.
-constexpr int SPB_WAVES = 8;
+// Block form of one large matrix (the reference API, slices of bm <= 512 rows x bk <= 64 columns): a work-group of sixteen
+// waves per slice. Wave w owns a contiguous share of at most 32 of the slice's rows and fetches them all at once (a row is
+// one load per wave, a lane per column): one memory round trip per slice. The entry counts of the shares (__ballot +
+// popcount per row) are exchanged through LDS; then every wave writes rowidx / colidx / values from its registers at the
+// positions the sequential scan of the reference gives them.
+constexpr int SPB_WAVES = 16, SPB_ROWS = 32;
 __global__ __launch_bounds__(64 * SPB_WAVES)
 void spmdm_create_block_kernel(int first_slice, int transa, const float* __restrict__ a, int mb_count, int bm, int bk, int M, int K,
                                uint16_t* __restrict__ rowidx, uint16_t* __restrict__ colidx, float* __restrict__ values,
@@ -132,8 +133,8 @@ void spmdm_create_block_kernel(int first_slice, int transa, const float* __restr
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int s = first_slice + blockIdx.x;
   const int kb = s / mb_count, mb = s % mb_count; // reference: kb = id / mb, mb = id % mb
-  const int nrows = ((mb + 1) * bm > M) ? (M - mb * bm) : bm;
-  const int ncols = ((kb + 1) * bk > K) ? (K - kb * bk) : bk; // <= 64 (host check)
+  const int nrows = ((mb + 1) * bm > M) ? (M - mb * bm) : bm;  // <= SPB_WAVES * SPB_ROWS (host check)
+  const int ncols = ((kb + 1) * bk > K) ? (K - kb * bk) : bk;  // <= 64 (host check)
   const int ld = transa ? M : K;
   const float* const in = transa ? (a + (size_t)mb * bm + (size_t)kb * bk * M) : (a + (size_t)kb * bk + (size_t)mb * bm * K);
   uint16_t* const ri = rowidx + s * rowidx_stride;
@@ -142,41 +143,31 @@ void spmdm_create_block_kernel(int first_slice, int transa, const float* __restr
   const int share = (nrows + SPB_WAVES - 1) / SPB_WAVES;
   const int r0 = wave * share, r1 = (r0 + share < nrows) ? (r0 + share) : nrows;
   const bool in_range = (lane < ncols);
-  unsigned cnt = 0;
-  for (int rb = r0; rb < r1; rb += 8) {
-    float v[8];
+  float v[SPB_ROWS];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int r = rb + u;
-      v[u] = (in_range && r < r1) ? (transa ? in[(size_t)lane * ld + r] : in[(size_t)r * ld + lane]) : 0.f;
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) cnt += __popcll(__ballot(!(0.f == v[u]))); // LIBXSMM_FEQ(0, v) ? 0 : 1  (-0 is zero, NaN is kept)
+  for (int u = 0; u < SPB_ROWS; ++u) {
+    const int r = r0 + u;
+    v[u] = (in_range && r < r1) ? (transa ? in[(size_t)lane * ld + r] : in[(size_t)r * ld + lane]) : 0.f;
   }
+  unsigned cnt = 0;
+#pragma unroll
+  for (int u = 0; u < SPB_ROWS; ++u) cnt += __popcll(__ballot(!(0.f == v[u]))); // LIBXSMM_FEQ(0, v) ? 0 : 1  (-0 is zero, NaN is kept)
   if (0 == lane) wave_count[wave] = cnt;
   __syncthreads();
   cnt = 0;
   for (int w = 0; w < wave; ++w) cnt += wave_count[w];
-  for (int rb = r0; rb < r1; rb += 8) {
-    float v[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int r = rb + u;
-      v[u] = (in_range && r < r1) ? (transa ? in[(size_t)lane * ld + r] : in[(size_t)r * ld + lane]) : 0.f;
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int r = rb + u;
-      if (r < r1) {
-        if (0 == lane) ri[r] = (uint16_t)cnt;
-        const bool keep = !(0.f == v[u]);
-        const unsigned long long mask = __ballot(keep);
-        if (keep) {
-          const unsigned pos = cnt + __popcll(mask & ((1ULL << lane) - 1ULL));
-          ci[pos] = (uint16_t)lane; va[pos] = v[u];
-        }
-        cnt += __popcll(mask);
+  for (int u = 0; u < SPB_ROWS; ++u) {
+    const int r = r0 + u;
+    if (r < r1) {
+      if (0 == lane) ri[r] = (uint16_t)cnt;
+      const bool keep = !(0.f == v[u]);
+      const unsigned long long mask = __ballot(keep);
+      if (keep) {
+        const unsigned pos = cnt + __popcll(mask & ((1ULL << lane) - 1ULL));
+        ci[pos] = (uint16_t)lane; va[pos] = v[u];
       }
+      cnt += __popcll(mask);
     }
   }
   if (r0 < nrows && r1 == nrows && 0 == lane) ri[nrows] = (uint16_t)cnt; // the wave that owns the last row closes the slice
@@ -786,16 +777,19 @@ void spmdm_compute_mfma_kernel(long long batch, int M_arg, int K_arg, float beta
 }
 
 // ---- spmdm compute: one large problem (the reference API), tiled ----------------------------------------------------------
-// A work-group of eight waves owns a 64 x 256 tile of C for the whole sum over k: per slice column block (bk = 64 columns of
-// A = 64 rows of B) the B panel [64][256] and the CSR entries of the tile's 64 rows are staged in LDS (loads of the next
+// A work-group of sixteen waves owns a 64 x 256 tile of C for the whole sum over k: per slice column block (bk = 64 columns
+// of A = 64 rows of B) the B panel [64][256] and the CSR entries of the tile's 64 rows are staged in LDS (loads of the next
 // block in flight in registers meanwhile), C stays in registers. All 64 lanes of a wave work on ONE row at a time, a lane
 // owning four adjacent columns: the row's entries (at most 64) are fetched with a single ds_read_b64 -- one entry per lane
 // -- and handed round with v_readlane, so that the LDS pipe only carries the gathered B rows (one conflict-free
-// ds_read_b128 per entry and wave). Row r = 8 i + w of the tile belongs to wave w, round i. Per C element:
+// ds_read_b128 per entry and wave). Row r = 16 i + w of the tile belongs to wave w, round i. Per C element:
 // acc = beta * C; acc = fma(val_p, B[col_p][n], acc) over the column blocks in order and the row's entries in order --
 // the chain of the reference (compute tpl :321-371); beta == 0 never reads C.
-constexpr int SPT_BK = 64, SPT_TN = 256, SPT_TM = 64, SPT_CAP = 1536, SPT_THREADS = 512;
+constexpr int SPT_BK = 64, SPT_TN = 256, SPT_TM = 64, SPT_CAP = 1536, SPT_WAVES = 16, SPT_THREADS = 64 * SPT_WAVES;
+constexpr int SPT_RW = SPT_TM / SPT_WAVES;                        // rows per wave
+constexpr int SPT_NB = SPT_BK * SPT_TN / 4 / SPT_THREADS;         // 16-byte pieces of the B panel per thread
 constexpr size_t SPT_LDS = (size_t)SPT_BK * SPT_TN * 4 + (size_t)SPT_CAP * 8 + 160;
+static_assert(2 * SPT_THREADS >= SPT_CAP, "one pair of entries per thread covers a window");
 
 template<int U>
 __device__ __forceinline__ void spt_fold(const sp_f32x2 ent, int j0, const float* __restrict__ brow, sp_f32x4& acc)
@@ -816,7 +810,7 @@ __device__ __forceinline__ void spt_fold(const sp_f32x2 ent, int j0, const float
 
 // VEC: N % 4 == 0 (K % 4 == 0 for a transposed B) and 16-byte aligned B and C: 16-byte global accesses
 template<bool VEC, bool TRANSB>
-__global__ __launch_bounds__(SPT_THREADS, 4)
+__global__ __launch_bounds__(SPT_THREADS)
 void spmdm_tiled_kernel(int M, int N, int K, int bm, int mb_count, int kb_count, int transc, float beta,
                         const uint16_t* __restrict__ rowidx, const uint16_t* __restrict__ colidx, const float* __restrict__ values,
                         long long rstride, long long cap, const float* __restrict__ b, float* __restrict__ c,
@@ -844,23 +838,24 @@ void spmdm_tiled_kernel(int M, int N, int K, int bm, int mb_count, int kb_count,
   const int nl = 4 * lane;                 // this lane's columns: n0 + nl .. + 3
   const int nvalid = ncols - nl;           // > 0: the lane has columns (>= 4: all four)
 
-  // ---- register stages: B panel (8 x 16 bytes), row starts, CSR entries of the next column block.
+  // ---- register stages: B panel (SPT_NB x 16 bytes), row starts, CSR entries of the next column block.
   // Piece j of a thread: (wave-uniform base of the column block and of j) + (one per-thread offset): nothing per piece
   // stays in vector registers between the blocks.
-  //   B[k][n]: piece = 4 columns c4 of row kr = (t >> 6) + 8 j        TRANSB, B[n][k]: 4 k's kq = 4 ((t >> 8) + 2 j) of column cc = t & 255
+  //   B[k][n]: piece = 4 columns pc of row pr + PRS j               TRANSB, B[n][k]: 4 k's 4 (pr + PRS j) .. + 3 of column pc
   //   (lanes along n also when B is transposed: parked without bank conflicts; the global side is served by L1/L2)
+  constexpr int PRS = TRANSB ? (SPT_THREADS / 256) : (SPT_THREADS / 64); // rows resp. groups of four k's the threads cover per piece
   const int pr = TRANSB ? (t >> 8) : (t >> 6), pc = TRANSB ? (t & 255) : ((t & 63) << 2);
   const int voff = TRANSB ? (pc * K + 4 * pr) : (pr * N + pc);
   const bool pc_ok = (pc < ncols);
-  sp_f32x4 rb[8]; unsigned short rix = 0; unsigned cols[2]; sp_f32x2 vals[2];
+  sp_f32x4 rb[SPT_NB]; unsigned short rix = 0; unsigned cols = 0; sp_f32x2 vals = sp_f32x2{ 0.f, 0.f };
   auto fetch = [&](int kb, int base, int pend) {
     const int k0 = kb * SPT_BK, kc = (K - k0 < SPT_BK) ? (K - k0) : SPT_BK;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < SPT_NB; ++j) {
       sp_f32x4 v = sp_f32x4{ 0.f, 0.f, 0.f, 0.f };
       if (!TRANSB) {
-        const float* const sbase = b + (size_t)(k0 + 8 * j) * N + n0; // wave-uniform
-        if (pr + 8 * j < kc && pc_ok) {
+        const float* const sbase = b + (size_t)(k0 + PRS * j) * N + n0; // wave-uniform
+        if (pr + PRS * j < kc && pc_ok) {
           if (VEC) v = *reinterpret_cast<const sp_f32x4*>(sbase + voff);
           else {
 #pragma unroll
@@ -869,12 +864,12 @@ void spmdm_tiled_kernel(int M, int N, int K, int bm, int mb_count, int kb_count,
         }
       }
       else {
-        const float* const sbase = b + (size_t)n0 * K + k0 + 8 * j;
-        if (4 * pr + 8 * j < kc && pc_ok) {
+        const float* const sbase = b + (size_t)n0 * K + k0 + 4 * PRS * j;
+        if (4 * (pr + PRS * j) < kc && pc_ok) {
           if (VEC) v = *reinterpret_cast<const sp_f32x4*>(sbase + voff);
           else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) if (4 * pr + 8 * j + q < kc) v[q] = sbase[voff + q];
+            for (int q = 0; q < 4; ++q) if (4 * (pr + PRS * j) + q < kc) v[q] = sbase[voff + q];
           }
         }
       }
@@ -883,33 +878,35 @@ void spmdm_tiled_kernel(int M, int N, int K, int bm, int mb_count, int kb_count,
     const long long s = (long long)kb * mb_count + mbi;
     if (t <= rows) rix = rowidx[s * rstride + ml0 + t];
     if (pend - base <= SPT_CAP) { // one window (the common case): the entries travel through registers as well
-      const uint16_t* const ci = colidx + s * cap + base;
-      const float* const va = values + s * cap + base;
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int e = 2 * (t + SPT_THREADS * j);
-        if (e < pend - base) { // (an odd count fetches one entry too many: inside the slice's capacity, never used)
-          cols[j] = *reinterpret_cast<const unsigned*>(ci + e);
-          vals[j] = *reinterpret_cast<const sp_f32x2*>(va + e);
-        }
+      const int e = 2 * t;
+      if (e < pend - base) { // (an odd count fetches one entry too many: inside the slice's capacity, never used)
+        cols = *reinterpret_cast<const unsigned*>(colidx + s * cap + base + e);
+        vals = *reinterpret_cast<const sp_f32x2*>(values + s * cap + base + e);
       }
     }
   };
-  // entry range [base, pend) of the tile's rows inside slice (kb, mbi); base is rounded down to an even entry (aligned pairs)
+  // entry range [base, pend) of the tile's rows inside slice (kb, mbi); base is rounded down to an even entry (aligned pairs).
+  // The ranges of 64 column blocks are fetched at a time, one block per lane, and picked with v_readlane: no memory round
+  // trip on the path of a step.
+  int vbase = 0, vpend = 0;
   auto entry_range = [&](int kb, int& base, int& pend) {
-    if (kb < kb_count) {
-      const uint16_t* const ri = rowidx + ((long long)kb * mb_count + mbi) * rstride + ml0;
-      base = __builtin_amdgcn_readfirstlane((int)ri[0] & ~1); pend = __builtin_amdgcn_readfirstlane((int)ri[rows]);
+    if (0 == (kb & 63) && kb < kb_count) {
+      const int kq = kb + lane;
+      if (kq < kb_count) {
+        const uint16_t* const ri = rowidx + ((long long)kq * mb_count + mbi) * rstride + ml0;
+        vbase = (int)ri[0] & ~1; vpend = (int)ri[rows];
+      }
     }
+    if (kb < kb_count) { base = __builtin_amdgcn_readlane(vbase, kb & 63); pend = __builtin_amdgcn_readlane(vpend, kb & 63); }
     else { base = 0; pend = 0; }
   };
 
-  // ---- C tile: acc[i] = row 8 i + wave
-  sp_f32x4 acc[8];
+  // ---- C tile: acc[i] = row 16 i + wave
+  sp_f32x4 acc[SPT_RW];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < SPT_RW; ++i) {
     acc[i] = sp_f32x4{ 0.f, 0.f, 0.f, 0.f };
-    const int r = 8 * i + wave;
+    const int r = SPT_WAVES * i + wave;
     if (0.f != beta && r < rows && 0 < nvalid) {
       sp_f32x4 cv = sp_f32x4{ 0.f, 0.f, 0.f, 0.f };
       if (0 == transc) {
@@ -937,22 +934,19 @@ void spmdm_tiled_kernel(int M, int N, int K, int bm, int mb_count, int kb_count,
     const bool one_window = (pend - base <= SPT_CAP);
     // ---- park this column block's registers in LDS
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      if (!TRANSB) *reinterpret_cast<sp_f32x4*>(Bs + (pr + 8 * j) * SPT_TN + pc) = rb[j];
+    for (int j = 0; j < SPT_NB; ++j) {
+      if (!TRANSB) *reinterpret_cast<sp_f32x4*>(Bs + (pr + PRS * j) * SPT_TN + pc) = rb[j];
       else {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) Bs[(4 * pr + 8 * j + q) * SPT_TN + pc] = rb[j][q];
+        for (int q = 0; q < 4; ++q) Bs[(4 * (pr + PRS * j) + q) * SPT_TN + pc] = rb[j][q];
       }
     }
     if (t <= rows) ris[t] = rix;
     if (one_window) {
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int e = 2 * (t + SPT_THREADS * j);
-        if (e < pend - base) {
-          const int o0 = (int)(cols[j] & 0xFFFFu) * SPT_TN, o1 = (int)(cols[j] >> 16) * SPT_TN;
-          *reinterpret_cast<sp_f32x4*>(meta + e) = sp_f32x4{ __int_as_float(o0), vals[j][0], __int_as_float(o1), vals[j][1] };
-        }
+      const int e = 2 * t;
+      if (e < pend - base) {
+        const int o0 = (int)(cols & 0xFFFFu) * SPT_TN, o1 = (int)(cols >> 16) * SPT_TN;
+        *reinterpret_cast<sp_f32x4*>(meta + e) = sp_f32x4{ __int_as_float(o0), vals[0], __int_as_float(o1), vals[1] };
       }
     }
     // ---- the next column block's loads go out now
@@ -960,30 +954,30 @@ void spmdm_tiled_kernel(int M, int N, int K, int bm, int mb_count, int kb_count,
     entry_range(kb + 2, base2, pend2);
     if (kb + 1 < kb_count) fetch(kb + 1, base1, pend1);
     spw_lds_barrier();
-    // ---- rounds of eight rows; a window holds the entries of as many consecutive rounds as fit the buffer
+    // ---- rounds of sixteen rows; a window holds the entries of as many consecutive rounds as fit the buffer
     int round0 = 0;
-    const int nrounds = (rows + 7) >> 3;
+    const int nrounds = (rows + SPT_WAVES - 1) / SPT_WAVES;
     while (round0 < nrounds) {
       int round1 = nrounds, wbase = base;
       if (!one_window) {
         const uint16_t* const ci = colidx + ((long long)kb * mb_count + mbi) * cap;
         const float* const va = values + ((long long)kb * mb_count + mbi) * cap;
-        wbase = __builtin_amdgcn_readfirstlane((int)ris[8 * round0]);
-        round1 = round0 + 1; // (a round holds at most 8 x 64 entries: always fits)
+        wbase = __builtin_amdgcn_readfirstlane((int)ris[SPT_WAVES * round0]);
+        round1 = round0 + 1; // (a round holds at most 16 x 64 entries: always fits)
         while (round1 < nrounds) {
-          const int rend = (8 * (round1 + 1) < rows) ? 8 * (round1 + 1) : rows;
+          const int rend = (SPT_WAVES * (round1 + 1) < rows) ? SPT_WAVES * (round1 + 1) : rows;
           if ((int)ris[rend] - wbase > SPT_CAP) break;
           ++round1;
         }
         round1 = __builtin_amdgcn_readfirstlane(round1);
-        const int wend = (int)ris[(8 * round1 < rows) ? 8 * round1 : rows];
+        const int wend = (int)ris[(SPT_WAVES * round1 < rows) ? SPT_WAVES * round1 : rows];
         for (int e = t; e < wend - wbase; e += SPT_THREADS) meta[e] = float2{ __int_as_float((int)ci[wbase + e] * SPT_TN), va[wbase + e] };
         spw_lds_barrier();
       }
-      // entry ranges of this wave's eight rows, one row per lane (rows outside the window or the tile: empty)
+      // entry ranges of this wave's rows, one row per lane (rows outside the window or the tile: empty)
       int vp0 = 0, vcnt = 0;
-      if (lane < 8) {
-        const int r = 8 * lane + wave;
+      if (lane < SPT_RW) {
+        const int r = SPT_WAVES * lane + wave;
         if (lane >= round0 && lane < round1 && r < rows) { vp0 = (int)ris[r] - wbase; vcnt = (int)ris[r + 1] - wbase - vp0; }
       }
       // a row's entries: one per lane (a single ds_read_b64), fetched one row ahead of the arithmetic
@@ -997,11 +991,12 @@ void spmdm_tiled_kernel(int M, int N, int K, int bm, int mb_count, int kb_count,
       int cnt_next = 0;
       sp_f32x2 ent_next = row_entries(0, cnt_next);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
+      for (int i = 0; i < SPT_RW; ++i) {
         const sp_f32x2 ent = ent_next; const int cnt = cnt_next;
-        if (i + 1 < 8) ent_next = row_entries(i + 1, cnt_next);
+        if (i + 1 < SPT_RW) ent_next = row_entries(i + 1, cnt_next);
         int j = 0;
-        for (; j + 4 <= cnt; j += 4) spt_fold<4>(ent, j, brow, acc[i]);
+        for (; j + 8 <= cnt; j += 8) spt_fold<8>(ent, j, brow, acc[i]);
+        if (cnt & 4) { spt_fold<4>(ent, j, brow, acc[i]); j += 4; }
         if (cnt & 2) { spt_fold<2>(ent, j, brow, acc[i]); j += 2; }
         if (cnt & 1) spt_fold<1>(ent, j, brow, acc[i]);
       }
@@ -1013,8 +1008,8 @@ void spmdm_tiled_kernel(int M, int N, int K, int bm, int mb_count, int kb_count,
 
   // ---- C leaves
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int r = 8 * i + wave;
+  for (int i = 0; i < SPT_RW; ++i) {
+    const int r = SPT_WAVES * i + wave;
     if (r < rows && 0 < nvalid) {
       if (0 == transc) {
         float* const dst = c + (size_t)(m0 + r) * N + n0;
@@ -1085,7 +1080,7 @@ int launch_spmdm_create_blocks(int M, int K, int bm, int bk, int mb, int first_s
   hipStream_t st = (hipStream_t)stream;
   const long long cap = (long long)bm * bk, rstride = (long long)bm + 1;
   if (0 >= nslices) { *name = "spmdm_create_noop"; return 0; }
-  if (bk <= 64) {
+  if (bk <= 64 && bm <= SPB_WAVES * SPB_ROWS) {
     *name = "spmdm_create_slice_wg";
     hipLaunchKernelGGL(spmdm_create_block_kernel, dim3((unsigned)nslices), dim3(64 * SPB_WAVES), 0, st,
       first_slice, transa, a, mb, bm, bk, M, K, rowidx, colidx, values, rstride, cap);

@@ -15,6 +15,20 @@
 namespace xsmm {
 namespace {
 
+// *p += v by compare-and-swap at system scope (integer atomics travel over PCIe; hardware floating-point adds do not)
+__device__ __forceinline__ void cas_add(float* p, float v)
+{
+  unsigned* const u = reinterpret_cast<unsigned*>(p);
+  unsigned seen = __hip_atomic_load(u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  while (!__hip_atomic_compare_exchange_strong(u, &seen, __float_as_uint(__uint_as_float(seen) + v), __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) {}
+}
+__device__ __forceinline__ void cas_add(double* p, double v)
+{
+  unsigned long long* const u = reinterpret_cast<unsigned long long*>(p);
+  unsigned long long seen = __hip_atomic_load(u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  while (!__hip_atomic_compare_exchange_strong(u, &seen, (unsigned long long)__double_as_longlong(__longlong_as_double((long long)seen) + v), __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) {}
+}
+
 template<int G> __device__ __forceinline__ void unit_sync()
 {
   if constexpr (G == 64) wave_lds_sync(); else __syncthreads();
@@ -24,7 +38,7 @@ template<int G> __device__ __forceinline__ void unit_sync()
 template<typename T, int TM, int TN, int TGM, int TGN, bool GENERAL>
 __global__ __launch_bounds__(256)
 void smm_generic_kernel(DevAddr ad, int M, int N, int K, int lda, int ldb, int ldc, int flags, int sync_arg,
-                        long long batch_arg, int KC, int kshift, T alpha, T beta, int tiles_m, int tiles_n)
+                        long long batch_arg, int KC, int kshift, T alpha, T beta, int tiles_m, int tiles_n, int hw_atomics)
 {
   // tiles_m * tiles_n > 1 (independent C only): a unit is one MP x NP tile of one item -- a single large product
   // (libxsmm_?gemm, a relinked BLAS caller) spreads over the chip instead of running on one work-group
@@ -75,17 +89,26 @@ void smm_generic_kernel(DevAddr ad, int M, int N, int K, int lda, int ldb, int l
     for (int m0 = m_first; m0 < M && m0 < m_last; m0 += MP) {
       for (int n0 = n_first; n0 < N && n0 < n_last; n0 += NP) {
         T acc[TM][TN];
+        T cv[GENERAL ? TM : 1][GENERAL ? TN : 1]; // general form: the value of C as the items of a run update it one after the other
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
           for (int j = 0; j < TN; ++j) {
             const int m = m0 + tx * TM + i, n = n0 + ty * TN + j;
             acc[i][j] = (!GENERAL && !beta0 && SYNC_ATOMIC != sync && m < M && n < N) ? pc[(size_t)n * ldc + m] : T(0);
+            if constexpr (GENERAL) cv[i][j] = (T(0) != beta && m < M && n < N) ? pc[(size_t)n * ldc + m] : T(0);
           }
         }
         for (long long r = 0; r < count; ++r) {
           const T* const pa = addr_a<T>(ad, item + r);
           const T* const pb = addr_b<T>(ad, item + r);
+          if constexpr (GENERAL) { // C = alpha * A_i * B_i + beta * C item by item, in batch order (the reference's sequential loop, src/libxsmm_gemm.c:1778-1806)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+              for (int j = 0; j < TN; ++j) acc[i][j] = T(0);
+            }
+          }
           for (int k0 = 0; k0 < K; k0 += KC) {
             const int kc = (K - k0 < KC) ? (K - k0) : KC;
             unit_sync<G>(); // previous tile fully consumed
@@ -128,6 +151,13 @@ void smm_generic_kernel(DevAddr ad, int M, int N, int K, int lda, int ldb, int l
               }
             }
           }
+          if constexpr (GENERAL) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+              for (int j = 0; j < TN; ++j) cv[i][j] = (T(0) == beta) ? (alpha * acc[i][j]) : (alpha * acc[i][j] + beta * cv[i][j]);
+            }
+          }
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -137,10 +167,12 @@ void smm_generic_kernel(DevAddr ad, int M, int N, int K, int lda, int ldb, int l
             if (m < M && n < N) {
               T* const dst = pc + (size_t)n * ldc + m;
               if constexpr (GENERAL) {
-                *dst = (T(0) == beta) ? (alpha * acc[i][j]) : (alpha * acc[i][j] + beta * (*dst));
+                *dst = cv[i][j];
               }
               else if (SYNC_ATOMIC == sync) {
-                if (beta0) *dst = acc[i][j]; else atomicAdd(dst, acc[i][j]);
+                if (beta0) *dst = acc[i][j];
+                else if (0 != hw_atomics) atomicAdd(dst, acc[i][j]);
+                else cas_add(dst, acc[i][j]); // C in host memory the GPU maps: floating-point atomics do not reach it
               }
               else {
                 *dst = acc[i][j];
@@ -217,7 +249,8 @@ int launch_generic_t(const SmmBatch& s, hipStream_t stream)
   if (blocks > maxblocks) blocks = maxblocks;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL((smm_generic_kernel<T, TM, TM, TGM, TGM, GENERAL>), dim3((unsigned)blocks), dim3(256), smem, stream,
-    make_addr(s), s.m, s.n, s.k, s.lda, s.ldb, s.ldc, s.flags, s.sync, s.batch, KC, kshift, (T)s.alpha, (T)s.beta, tiles_m, tiles_n);
+    make_addr(s), s.m, s.n, s.k, s.lda, s.ldb, s.ldc, s.flags, s.sync, s.batch, KC, kshift, (T)s.alpha, (T)s.beta, tiles_m, tiles_n,
+    (SYNC_DEVICE == s.sync || SYNC_ATOMIC == s.sync) ? s.c_atomics : 1);
   return (int)hipGetLastError();
 }
 

@@ -51,6 +51,12 @@ LIBXSMM_API libxsmm_blocked_gemm_handle* libxsmm_blocked_gemm_handle_create(/*un
     if (0 != libxsmm_verbosity && once(&error_once)) fprintf(stderr, "LIBXSMM ERROR: BGEMM block-size is invalid!\n");
     return nullptr;
   }
+  if (iprec != oprec || (LIBXSMM_GEMM_PRECISION_F64 != iprec && LIBXSMM_GEMM_PRECISION_F32 != iprec)) {
+    // (the reference also has a 16-bit integer blocked GEMM, src/libxsmm_blocked_gemm.c:536-550; the copy and compute kernels
+    // here move 4- and 8-byte elements only)
+    if (0 != libxsmm_verbosity && once(&error_once)) fprintf(stderr, "LIBXSMM ERROR: BGEMM precision is not supported!\n");
+    return nullptr;
+  }
   libxsmm_descriptor_blob blob;
   const libxsmm_gemm_descriptor* const desc = libxsmm_gemm_descriptor_init2(&blob, iprec, oprec, mm, nn, kk, mm, kk, mm,
     alpha, beta, nullptr == gemm_flags ? LIBXSMM_GEMM_FLAG_NONE : *gemm_flags, LIBXSMM_GEMM_PREFETCH_NONE);
@@ -190,6 +196,7 @@ void bgemm_run(const libxsmm_blocked_gemm_handle* h, const void* a, const void* 
       j.uniform_run = h->kb; // every C block's k blocks follow each other in the work list
       if (smm_jit_eligible(j)) e = launch_smm_jit(j, device().stream, &name);
     }
+    flag_slot_commit();
   }
   if (e < 0) e = launch_smm_generic(s, device().stream, &name);
   note_launch(name);

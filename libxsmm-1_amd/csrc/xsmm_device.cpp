@@ -150,22 +150,46 @@ int library_gemm(int typesize, int transa, int transb, int m, int n, int k, doub
   return 0 == r.sgemm(tl_rocblas_handle, ta, tb, m, n, k, &al, static_cast<const float*>(a), lda, static_cast<const float*>(b), ldb, &be, static_cast<float*>(c), ldc) ? 0 : 1;
 }
 
+// Slots in device memory, one per batch call whose C ordering is inspected on the device: int[4] {equal pairs, decreasing
+// pairs, ticket counter, -} followed by a pair of counts per block of the check kernel. A slot is written (check kernel)
+// and read (compute kernels) by launches of one stream, in order; nothing has to be cleared between uses (the ticket
+// counter wraps back to zero, see c_order_kernel), only once at allocation. Every thread owns a ring of slots; a slot is
+// handed out again only after the launches that read it have completed (event recorded by flag_slot_commit) -- calls in
+// flight on several streams, or more calls in flight than the ring is long, never share a slot.
+namespace {
+constexpr unsigned FLAG_RING = 64, FLAG_INTS = 4 + 2 * FLAG_SLOT_BLOCKS;
+struct FlagSlot { hipEvent_t done = nullptr; void* stream = nullptr; int state = 0; /* 1: handed out, 2: committed */ };
+struct FlagRing {
+  int* mem = nullptr; FlagSlot slot[FLAG_RING]; unsigned next = 0;
+  ~FlagRing() { /* device memory and events are released with the process (the HIP runtime may be gone already) */ }
+};
+thread_local FlagRing tl_flags;
+}
+
 int* flag_slot()
-{ // Ring of slots in device memory, one per batch call whose C ordering is inspected on the device: int[4] {equal pairs,
-  // decreasing pairs, ticket counter, -} followed by a pair of counts per block of the check kernel. A slot is written
-  // (check kernel) and read (compute kernels) by launches of one stream, in order; nothing has to be cleared between uses
-  // (the ticket counter wraps back to zero, see c_order_kernel), only once here.
-  static int* ring = nullptr;
-  static std::once_flag once;
-  static std::atomic<unsigned> next{0};
-  constexpr unsigned SLOTS = 2048, INTS = 4 + 2 * FLAG_SLOT_BLOCKS;
-  std::call_once(once, []() {
+{
+  FlagRing& r = tl_flags;
+  if (nullptr == r.mem) {
     void* p = nullptr;
-    if (hipSuccess == hipMalloc(&p, (size_t)SLOTS * INTS * sizeof(int)) && hipSuccess == hipMemset(p, 0, (size_t)SLOTS * INTS * sizeof(int))) ring = static_cast<int*>(p);
-    else (void)hipGetLastError();
-  });
-  if (nullptr == ring) return nullptr;
-  return ring + (size_t)INTS * (next.fetch_add(1, std::memory_order_relaxed) % SLOTS);
+    if (hipSuccess == hipMalloc(&p, (size_t)FLAG_RING * FLAG_INTS * sizeof(int)) && hipSuccess == hipMemset(p, 0, (size_t)FLAG_RING * FLAG_INTS * sizeof(int))) r.mem = static_cast<int*>(p);
+    else { (void)hipGetLastError(); if (nullptr != p) (void)hipFree(p); return nullptr; }
+  }
+  const unsigned i = r.next++ % FLAG_RING;
+  FlagSlot& f = r.slot[i];
+  if (2 == f.state) (void)hipEventSynchronize(f.done);
+  else if (1 == f.state) (void)hipStreamSynchronize((hipStream_t)f.stream); // handed out but never committed (an error path)
+  if (nullptr == f.done && hipSuccess != hipEventCreateWithFlags(&f.done, hipEventDisableTiming)) { (void)hipGetLastError(); f.done = nullptr; return nullptr; }
+  f.stream = device().stream; f.state = 1;
+  return r.mem + (size_t)FLAG_INTS * i;
+}
+
+void flag_slot_commit()
+{
+  FlagRing& r = tl_flags;
+  for (unsigned i = 0; i < FLAG_RING; ++i) {
+    FlagSlot& f = r.slot[i];
+    if (1 == f.state) { if (hipSuccess == hipEventRecord(f.done, (hipStream_t)f.stream)) f.state = 2; else (void)hipGetLastError(); }
+  }
 }
 
 int flag_slot_set(int* slot, int equal_pairs, int decreasing_pairs)

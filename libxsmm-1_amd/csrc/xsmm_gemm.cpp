@@ -31,6 +31,7 @@ int run_smm(const SmmBatch& s)
     e = launch_smm_jit(s, device().stream, &name); // (SYNC_DEVICE: whatever the verdict on the device, one of its kernels works)
   }
   if (e < 0) e = launch_smm_generic(s, device().stream, &name);                     // any descriptor
+  if (SYNC_DEVICE == s.sync) flag_slot_commit(); // the launches that read the verdict are queued
   note_launch(name);
   if (0 != e) fprintf(stderr, "LIBXSMM-AMD ERROR: kernel launch failed (%s, hip error %d)\n", name, e);
   else if (ADDR_POINTER == s.mode) { // arrays of pointers: look at the first operands if the arrays can be read here
@@ -84,6 +85,75 @@ int choose_sync(SmmBatch& s, bool nosync)
   return 0;
 }
 
+// General form (alpha, beta, TRANS_A outside the SMM domain): C = alpha * op(A_i) * op(B_i) + beta * C item by item, in batch
+// order -- what the reference's libxsmm_mmbatch_blas does in a sequential loop (src/libxsmm_gemm.c:1778-1806). Items that
+// share a C cannot be done side by side (and no atomic expresses the scaling by beta): consecutive repeats are walked as
+// runs by one unit (SYNC_RUNS, the value of C carried from item to item); repeats out of order cut the batch into groups
+// without a repeat, launched one after the other in stream order. The verdict needs a host round trip here: this is the
+// BLAS-fallback path, not the hot path.
+int run_general(SmmBatch s)
+{
+  s.sync = SYNC_NONE;
+  if (s.batch < 2) return run_smm(s);
+  if ((ADDR_STRIDED == s.mode && 0 != s.sc)) return run_smm(s);
+  if ((ADDR_STRIDED == s.mode && 0 == s.sc) || (ADDR_INDEX == s.mode && nullptr == s.ic) || (ADDR_POINTER == s.mode && 0 == s.sc)) {
+    s.sync = SYNC_RUNS; return run_smm(s); // one C for the whole batch
+  }
+  int* const d_flags = flag_slot();
+  int verdict[2] = { 0, 1 };
+  if (nullptr == d_flags || 0 != launch_c_order_check(s, d_flags, device().stream)) return -1;
+  flag_slot_commit();
+  if (0 != d2h(verdict, d_flags, sizeof(verdict))) return -1;
+  if (0 == verdict[1]) { s.sync = (0 != verdict[0]) ? SYNC_RUNS : SYNC_NONE; return run_smm(s); }
+  // C blocks repeat out of order: where they are, item by item
+  std::vector<unsigned long long> key((size_t)s.batch);
+  if (ADDR_INDEX == s.mode) {
+    std::vector<char> raw((size_t)(s.batch - 1) * s.index_stride + sizeof(int));
+    if (0 != d2h(raw.data(), s.ic, raw.size())) return -1;
+    for (long long i = 0; i < s.batch; ++i) key[(size_t)i] = (unsigned long long)(long long)(*reinterpret_cast<const int*>(raw.data() + i * s.index_stride));
+  }
+  else { // ADDR_POINTER
+    std::vector<char> raw((size_t)(s.batch - 1) * s.sc + sizeof(void*));
+    if (0 != d2h(raw.data(), s.c, raw.size())) return -1;
+    for (long long i = 0; i < s.batch; ++i) key[(size_t)i] = (unsigned long long)reinterpret_cast<uintptr_t>(*reinterpret_cast<void* const*>(raw.data() + i * s.sc));
+  }
+  std::unordered_map<unsigned long long, char> seen;
+  long long begin = 0;
+  auto launch_group = [&](long long b0, long long b1) -> int {
+    SmmBatch g = s; g.batch = b1 - b0; g.sync = SYNC_NONE;
+    if (ADDR_INDEX == s.mode) {
+      if (nullptr != s.ia) g.ia = reinterpret_cast<const int*>(reinterpret_cast<const char*>(s.ia) + b0 * s.index_stride);
+      if (nullptr != s.ib) g.ib = reinterpret_cast<const int*>(reinterpret_cast<const char*>(s.ib) + b0 * s.index_stride);
+      g.ic = reinterpret_cast<const int*>(reinterpret_cast<const char*>(s.ic) + b0 * s.index_stride);
+    }
+    else { g.a = static_cast<const char*>(s.a) + b0 * s.sa; g.b = static_cast<const char*>(s.b) + b0 * s.sb; g.c = static_cast<char*>(s.c) + b0 * s.sc; }
+    return run_smm(g);
+  };
+  for (long long i = 0; i < s.batch; ++i) {
+    if (seen.end() != seen.find(key[(size_t)i])) { // item i's C is already part of the open group: close it
+      const int e = launch_group(begin, i);
+      if (0 != e) return e;
+      seen.clear(); begin = i;
+    }
+    seen.emplace(key[(size_t)i], 1);
+  }
+  return launch_group(begin, s.batch);
+}
+
+int choose_sync(SmmBatch& s, bool nosync);
+// decides how the C operands of a batch are kept apart, then launches
+int sync_and_run(SmmBatch& s, bool nosync)
+{
+  if (0 != s.general) return run_general(s);
+  if (0 != choose_sync(s, nosync)) return -1;
+  return run_smm(s);
+}
+
+// Slices of one libxsmm_mmbatch call that run on several threads AND stage C through private device copies (operands in
+// pageable host memory) must not overlap in time: a slice's copy-back would overwrite what another slice has just
+// written (the reference takes a lock per C, src/libxsmm_gemm.c:1366-1423; here the staged slices take turns).
+std::mutex g_staged_tasks_lock;
+
 struct IndexRange { long long lo, hi; }; // element index range [lo, hi] used by an index array
 
 IndexRange index_range(const int* idx, int index_stride, int index_base, long long n)
@@ -135,8 +205,8 @@ int batch_execute(SmmBatch s, libxsmm_blasint index_base, libxsmm_blasint index_
       s.ia = device_indexes(sa, index_stride, n, 0, &ok);
       s.ib = device_indexes(sb, index_stride, n, 1, &ok);
       s.ic = device_indexes(sc, index_stride, n, 2, &ok);
-      if (!ok || 0 != choose_sync(s, nosync)) { index_upload_commit(); return EXIT_FAILURE; }
-      const int e = run_smm(s);
+      if (!ok) { index_upload_commit(); return EXIT_FAILURE; }
+      const int e = sync_and_run(s, nosync);
       index_upload_commit();
       return 0 == e ? EXIT_SUCCESS : EXIT_FAILURE;
     }
@@ -145,6 +215,8 @@ int batch_execute(SmmBatch s, libxsmm_blasint index_base, libxsmm_blasint index_
       fprintf(stderr, "LIBXSMM-AMD ERROR: host matrices with device index arrays are not supported\n");
       return EXIT_FAILURE;
     }
+    std::unique_lock<std::mutex> turn(g_staged_tasks_lock, std::defer_lock);
+    if (1 < s.tasks) { turn.lock(); s.shared_across_calls = 0; } // staged slices of one call take turns: nothing is shared meanwhile
     const IndexRange ra = index_range(sa, index_stride, index_base, n), rb = index_range(sb, index_stride, index_base, n),
                      rc = index_range(sc, index_stride, index_base, n);
     const size_t ea = (size_t)(ra.hi - ra.lo) + span_a(s), eb = (size_t)(rb.hi - rb.lo) + span_b(s), ec = (size_t)(rc.hi - rc.lo) + span_c(s);
@@ -161,8 +233,8 @@ int batch_execute(SmmBatch s, libxsmm_blasint index_base, libxsmm_blasint index_
     s.ia = device_indexes(sa, index_stride, n, 0, &ok);
     s.ib = device_indexes(sb, index_stride, n, 1, &ok);
     s.ic = device_indexes(sc, index_stride, n, 2, &ok);
-    if (!ok || 0 != choose_sync(s, nosync)) { index_upload_commit(); return EXIT_FAILURE; }
-    const int e = run_smm(s);
+    if (!ok) { index_upload_commit(); return EXIT_FAILURE; }
+    const int e = sync_and_run(s, nosync);
     index_upload_commit();
     if (0 != e) return EXIT_FAILURE;
     return 0 == d2h(hc, dc, ec * ts) ? EXIT_SUCCESS : EXIT_FAILURE;
@@ -179,8 +251,7 @@ int batch_execute(SmmBatch s, libxsmm_blasint index_base, libxsmm_blasint index_
   char* const pc = static_cast<char*>(c) + dc * begin;
   if (is_device_ptr(a) && is_device_ptr(b) && is_device_ptr(c)) { // pointer arrays already on the device
     s.a = pa; s.b = pb; s.c = pc;
-    if (0 != choose_sync(s, nosync)) return EXIT_FAILURE;
-    return 0 == run_smm(s) ? EXIT_SUCCESS : EXIT_FAILURE;
+    return 0 == sync_and_run(s, nosync) ? EXIT_SUCCESS : EXIT_FAILURE;
   }
   // host arrays of pointers: look at the first operand of each to see where the matrices live
   const void* const a0 = *reinterpret_cast<const void* const*>(pa);
@@ -198,13 +269,14 @@ int batch_execute(SmmBatch s, libxsmm_blasint index_base, libxsmm_blasint index_
     if (nullptr == xa || nullptr == xb || nullptr == xc) { index_upload_commit(); return EXIT_FAILURE; }
     s.a = xa; s.b = xb; s.c = xc;
     s.sa = (0 != da ? (long long)sizeof(void*) : 0); s.sb = (0 != db ? (long long)sizeof(void*) : 0); s.sc = (0 != dc ? (long long)sizeof(void*) : 0);
-    if (0 != choose_sync(s, nosync)) { index_upload_commit(); return EXIT_FAILURE; }
-    const int e = run_smm(s);
+    const int e = sync_and_run(s, nosync);
     index_upload_commit();
     return 0 == e ? EXIT_SUCCESS : EXIT_FAILURE;
   }
   // host matrices behind host pointer arrays: pack every operand into a dense device buffer, keep aliasing of C
   {
+    std::unique_lock<std::mutex> turn(g_staged_tasks_lock, std::defer_lock);
+    if (1 < s.tasks) { turn.lock(); s.shared_across_calls = 0; } // staged slices of one call take turns
     const size_t sza = span_a(s), szb = span_b(s), szc = span_c(s);
     char* const ba = static_cast<char*>(scratch(3, na * sza * ts));
     char* const bb = static_cast<char*>(scratch(4, nb * szb * ts));
@@ -248,8 +320,7 @@ int batch_execute(SmmBatch s, libxsmm_blasint index_base, libxsmm_blasint index_
     if (0 != stream_sync()) return EXIT_FAILURE;
     s.a = xa; s.b = xb; s.c = xc;
     s.sa = (0 != da ? (long long)sizeof(void*) : 0); s.sb = (0 != db ? (long long)sizeof(void*) : 0); s.sc = (0 != dc ? (long long)sizeof(void*) : 0);
-    if (0 != choose_sync(s, nosync)) return EXIT_FAILURE;
-    if (0 != run_smm(s)) return EXIT_FAILURE;
+    if (0 != sync_and_run(s, nosync)) return EXIT_FAILURE;
     if (0 != d2h(hc.data(), bc, hc.size())) return EXIT_FAILURE; // (synchronises)
     for (size_t j = 0; j < uniq.size(); ++j) memcpy(uniq[j], hc.data() + j * szc * ts, szc * ts);
     return EXIT_SUCCESS;
@@ -488,6 +559,7 @@ LIBXSMM_API int libxsmm_mmbatch_kernel(libxsmm_xmmfunction kernel, libxsmm_blasi
   SmmBatch s = from_descriptor(k->desc);
   s.relaxed = relaxed_order(ntasks, index_stride, c) ? 1 : 0;
   s.shared_across_calls = (1 < ntasks && 0 <= batchsize) ? 1 : 0; // (a negative batchsize is the caller's promise that nothing is shared)
+  s.tasks = ntasks;
   // ntasks > 1: the tasks run concurrently on the caller's threads and may share C across slices; as in the
   // reference (lock per C, :1366-1423) correctness then needs atomic updates unless the caller opts out.
   const bool nosync = (batchsize < 0);
@@ -505,10 +577,11 @@ int batch_general(int typesize, const char* transa, const char* transb, libxsmm_
   const void* alpha, const void* a, const libxsmm_blasint* lda, const void* b, const libxsmm_blasint* ldb,
   const void* beta, void* c, const libxsmm_blasint* ldc, libxsmm_blasint index_base, libxsmm_blasint index_stride,
   const libxsmm_blasint stride_a[], const libxsmm_blasint stride_b[], const libxsmm_blasint stride_c[],
-  long long begin, long long end)
+  long long begin, long long end, int ntasks = 1)
 {
   const int flags = LIBXSMM_GEMM_PFLAGS(transa, transb, LIBXSMM_FLAGS);
   SmmBatch s; memset(&s, 0, sizeof(s));
+  s.tasks = ntasks;
   s.typesize = typesize; s.m = m; s.n = n; s.k = k;
   s.lda = (nullptr != lda ? *lda : (0 == (LIBXSMM_GEMM_FLAG_TRANS_A & flags) ? m : k));
   s.ldb = (nullptr != ldb ? *ldb : (0 == (LIBXSMM_GEMM_FLAG_TRANS_B & flags) ? k : n));
@@ -571,7 +644,7 @@ LIBXSMM_API void libxsmm_mmbatch(libxsmm_gemm_precision iprec, libxsmm_gemm_prec
     const long long tasksize = (size + nthreads - 1) / nthreads;
     const long long begin = (long long)tid * tasksize, span = begin + tasksize, end = (span < size ? span : size);
     result = batch_general(LIBXSMM_GEMM_PRECISION_F64 == iprec ? 8 : 4, transa, transb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc,
-      index_base, index_stride, stride_a, stride_b, stride_c, begin, end);
+      index_base, index_stride, stride_a, stride_b, stride_c, begin, end, nthreads);
   }
   if (EXIT_SUCCESS != result && 0 != libxsmm_verbosity && once(&error_once)) {
     fprintf(stderr, "LIBXSMM ERROR: libxsmm_mmbatch failed!\n");

@@ -60,6 +60,7 @@ struct SmmBatch {
   int c_atomics;            // SYNC_DEVICE: != 0 if floating-point atomics reach C (device memory, not host memory the GPU maps)
   int lowp; float scf;      // low-precision kernels (kernels/smm_lowp.hip): 1 i16->i32, 2 i16->f32 (times scf), 3 bf16->f32, 4 bf16->bf16; 0: f32/f64
   int shared_across_calls;  // != 0: other tasks of the same libxsmm_mmbatch update the same C blocks concurrently (ntasks > 1): atomics
+  int tasks;                // number of tasks of the libxsmm_mmbatch call this slice belongs to (0/1: the whole batch)
   long long uniform_run;    // > 0: the batch consists of runs of exactly this many consecutive items per C (blocked GEMM work lists)
   int jit_always;           // != 0: specialise with hiprtc whatever the batch size (batch-reduce kernels: short batches, called over and over)
   int relaxed;              // != 0: sums into a shared C may be formed in any order (the caller's reference path is multi-threaded)
@@ -145,6 +146,7 @@ void index_upload_commit();                                // after the launches
 int library_gemm(int typesize, int transa, int transb, int m, int n, int k, double alpha, const void* a, int lda,
                  const void* b, int ldb, double beta, void* c, int ldc); // rocBLAS on the engine's stream; -1: not available
 int* flag_slot();                         // device int[4] for one batch call's C-ordering verdict (nullptr: out of memory)
+void flag_slot_commit();                  // after the launches that read the calling thread's latest slot were queued
 void* dev_alloc(size_t bytes);
 void dev_free(void* p);
 int h2d(void* dst, const void* src, size_t bytes);

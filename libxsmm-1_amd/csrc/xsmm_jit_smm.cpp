@@ -944,7 +944,7 @@ bool smm_jit_eligible(const SmmBatch& s)
   const bool enabled = (nullptr == env_jit || 0 != atoi(env_jit));
   if (!enabled || 0 != s.general || SYNC_ATOMIC == s.sync) return false;
   if (SYNC_NONE != s.sync && 0 != (s.flags & LIBXSMM_GEMM_FLAG_BETA_0)) return false; // (never chosen: beta == 0 needs no care)
-  if (SYNC_DEVICE == s.sync && 0 == s.c_atomics) return false;  // the generic kernel's compare-and-swap path serves mapped host memory
+  if (SYNC_DEVICE == s.sync && 0 == s.c_atomics) return false;  // C in host memory the GPU maps: the generic kernel adds by compare-and-swap (cas_add, kernels/smm_generic.hip)
   const bool tight = (s.lda == s.m && s.ldc == s.m && (0 != (s.flags & LIBXSMM_GEMM_FLAG_TRANS_B) ? (s.ldb == s.n) : (s.ldb == s.k)));
   if (!tight) { // leading dimensions with gaps: the wave forms fetch an operand's whole span -- as long as the gaps stay moderate
     if (s.m > 32 || s.n > 32 || s.k > 64) return false;
@@ -1152,13 +1152,16 @@ int launch_smm_jit(const SmmBatch& s, void* stream, const char** name)
   // SYNC_DEVICE: both run forms are launched; each reads the device-side verdict (average run length) and one of them works
   *name = f64 ? "smm_f64_jit_shape_runs" : "smm_f32_jit_shape_runs";
   const int split = (0 != s.relaxed ? SMM_JIT_SPLIT : 0); // the caller's reference path is unordered as well
-  int e = smm_jit_launch_variant(s, width | split | SMM_JIT_RUNS | (wg_fits ? SMM_JIT_HASWG : 0), stream);
-  if (0 == e && wg_fits) {
-    e = smm_jit_launch_variant(s, width | split | SMM_JIT_WGRUNS, stream);
-    if (e < 0) { // the companion did not compile: fall back to the wave form alone (it must then take long runs as well)
-      e = smm_jit_launch_variant(s, width | split | SMM_JIT_RUNS, stream);
-    }
-  }
+  // (both kernels are resolved before anything is launched: a wave form that leaves long runs to a companion that then
+  // fails to compile would have to be followed by a second wave-form launch -- which would add the short runs twice)
+  auto available = [&](int variant) {
+    const SmmKey key = { s.typesize, s.m, s.n, s.k, s.flags & (LIBXSMM_GEMM_FLAG_BETA_0 | LIBXSMM_GEMM_FLAG_TRANS_B), variant, s.lda, s.ldb, s.ldc };
+    return nullptr != smm_jit_get(key);
+  };
+  const bool pair = wg_fits && available(width | split | SMM_JIT_WGRUNS) && available(width | split | SMM_JIT_RUNS | SMM_JIT_HASWG);
+  if (!pair) return smm_jit_launch_variant(s, width | split | SMM_JIT_RUNS, stream); // the wave form alone takes long runs as well
+  int e = smm_jit_launch_variant(s, width | split | SMM_JIT_RUNS | SMM_JIT_HASWG, stream);
+  if (0 == e) e = smm_jit_launch_variant(s, width | split | SMM_JIT_WGRUNS, stream);
   return e;
 }
 

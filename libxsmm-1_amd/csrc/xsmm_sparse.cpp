@@ -10,7 +10,7 @@
 #include <vector>
 
 namespace xsmm {
-int launch_spmdm_create_blocks(int M, int K, int bm, int bk, int mb, int first_slice, int nslices, int transa, const float* a,
+int launch_spmdm_create_blocks(int M, int K, int bm, int bk, int mb, int first_slice, int slice_step, int nslices, int transa, const float* a,
                                uint16_t* rowidx, uint16_t* colidx, float* values, void* stream, const char** name);
 int launch_spmdm_compute_generic(long long batch, int M, int N, int K, int bm, int bk, int mb, int kb, int transb, int transc, float beta,
                                  const uint16_t* rowidx, const uint16_t* colidx, const float* values, long long rowidx_stride, long long cap,
@@ -188,9 +188,12 @@ LIBXSMM_API int libxsmm_amd_sfsspmdm_execute_batch(const libxsmm_sfsspmdm* handl
 // bk 128). Here they are sized for the GPU: a block call is one launch, so blocks are as large as the uint16 slice-local
 // indexes and counters allow -- bm = 512 rows, bk = 64 columns (a slice holds at most 32 768 entries; 64 is also the
 // width of a wavefront: a row of a slice is one load per wave and at most one entry per lane), bn = 2048.
+// A createSparseSlice block is a row block of A: block id = mb covers the slices (kb, mb) of all column blocks kb (the
+// reference hands out one slice per id, mb * kb ids; a caller only sees libxsmm_spmdm_get_num_createSparseSlice_blocks
+// and the ids below it) -- one launch then has kb work-groups instead of one.
 // Contract kept from the reference (compute tpl :38-39, 509-558): a compute call writes the C tile of its block and
-// nothing else, whatever the other calls did; a create call writes its slice and nothing else. Calls are asynchronous
-// for device operands. The whole problem in one launch is an explicit extension: libxsmm_amd_spmdm_*_all.
+// nothing else, whatever the other calls did; a create call writes the slices of its block and nothing else. Calls are
+// asynchronous for device operands. The whole problem in one launch is an explicit extension: libxsmm_amd_spmdm_*_all.
 // ---------------------------------------------------------------------------------------------------------------
 namespace xsmm {
 int launch_spmdm_compute_tiled(int M, int N, int K, int bm, int bk, int mb, int kb, int transb, int transc, float beta,
@@ -245,7 +248,7 @@ LIBXSMM_API void libxsmm_spmdm_destroy(libxsmm_spmdm_handle* handle)
   free(handle->base_ptr_scratch_B_scratch_C); handle->base_ptr_scratch_B_scratch_C = nullptr;
 }
 
-LIBXSMM_API int libxsmm_spmdm_get_num_createSparseSlice_blocks(const libxsmm_spmdm_handle* handle) { return handle->mb * handle->kb; }
+LIBXSMM_API int libxsmm_spmdm_get_num_createSparseSlice_blocks(const libxsmm_spmdm_handle* handle) { return handle->mb; }
 LIBXSMM_API int libxsmm_spmdm_get_num_compute_blocks(const libxsmm_spmdm_handle* handle) { return handle->mb * handle->nb; }
 
 namespace {
@@ -292,13 +295,15 @@ SliceArrays slice_arrays(const libxsmm_spmdm_handle* handle)
   return s;
 }
 
-// slices [first, first + count) of the device-resident M x K (or K x M) fp32 matrix da
-int spmdm_create_slices(const libxsmm_spmdm_handle* handle, int ta, const float* da, int first, int count)
+// the slices of the row blocks [mb0, mb0 + mbn) of the device-resident M x K (or K x M) fp32 matrix da
+int spmdm_create_slices(const libxsmm_spmdm_handle* handle, int ta, const float* da, int mb0, int mbn)
 {
   const SliceArrays s = slice_arrays(handle);
   const char* name = "";
-  const int e = launch_spmdm_create_blocks(handle->m, handle->k, handle->bm, handle->bk, handle->mb, first, count, ta, da,
-    s.rowidx, s.colidx, s.values, device().stream, &name);
+  // one row block: slices mb0 + kb * mb; all row blocks: every slice
+  const bool all = (0 == mb0 && mbn == handle->mb);
+  const int e = launch_spmdm_create_blocks(handle->m, handle->k, handle->bm, handle->bk, handle->mb, all ? 0 : mb0, all ? 1 : handle->mb,
+    all ? handle->mb * handle->kb : handle->kb, ta, da, s.rowidx, s.colidx, s.values, device().stream, &name);
   note_launch(name);
   if (0 != e) fprintf(stderr, "LIBXSMM-AMD ERROR: kernel launch failed (%s, hip error %d)\n", name, e);
   return e;
@@ -323,26 +328,20 @@ int spmdm_compute_tiles(const libxsmm_spmdm_handle* handle, int tb, int tc, floa
 
 bool is_trans(char t) { return 'T' == t || 't' == t; }
 
-// one create call: `count` slices starting at `first`; a: float (widened already) or the caller's matrix
-void spmdm_create(const libxsmm_spmdm_handle* handle, char transa, const float* a, int first, int count, bool staged_input)
+// one create call: row block mb0 (mbn == 1) or all of them; a: float (widened already) or the caller's matrix
+void spmdm_create(const libxsmm_spmdm_handle* handle, char transa, const float* a, int mb0, int mbn, bool staged_input)
 {
   const int ta = is_trans(transa) ? 1 : 0;
   const float* da = a;
-  if (!staged_input && !is_device_ptr(a)) { // host matrix: only the rows/columns of these slices travel
+  if (!staged_input && !is_device_ptr(a)) { // host matrix: only the rows of these blocks travel
     float* const d = static_cast<float*>(scratch(3, (size_t)handle->m * handle->k * sizeof(float)));
     if (nullptr == d) return;
-    if (0 == first && count == handle->mb * handle->kb) { // all slices: the whole matrix in one piece
-      if (0 != h2d(d, a, (size_t)handle->m * handle->k * sizeof(float))) return;
-    }
-    else for (int sl = first; sl < first + count; ++sl) {
-      const int kb = sl / handle->mb, mb = sl % handle->mb;
-      const int r0 = mb * handle->bm, nr = LIBXSMM_MIN(handle->bm, handle->m - r0), c0 = kb * handle->bk, nc = LIBXSMM_MIN(handle->bk, handle->k - c0);
-      const int e = ta ? copy_window(d, const_cast<float*>(a), handle->m, c0, nc, r0, nr, true) : copy_window(d, const_cast<float*>(a), handle->k, r0, nr, c0, nc, true);
-      if (0 != e) return;
-    }
+    const int r0 = mb0 * handle->bm, nr = LIBXSMM_MIN(mbn * handle->bm, handle->m - r0);
+    const int e = ta ? copy_window(d, const_cast<float*>(a), handle->m, 0, handle->k, r0, nr, true) : copy_window(d, const_cast<float*>(a), handle->k, r0, nr, 0, handle->k, true);
+    if (0 != e) return;
     da = d; staged_input = true;
   }
-  if (0 != spmdm_create_slices(handle, ta, da, first, count)) return;
+  if (0 != spmdm_create_slices(handle, ta, da, mb0, mbn)) return;
   if (staged_input) (void)stream_sync(); // the staging buffer is reused by the next call
   else settle(a);
 }
@@ -397,7 +396,7 @@ LIBXSMM_API void libxsmm_spmdm_createSparseSlice_fp32_thread(const libxsmm_spmdm
   (void)tid; (void)nthreads;
   if (nullptr == handle || nullptr == a || nullptr == libxsmm_output_csr_a || nullptr == handle->base_ptr_scratch_A) return;
   if (!device_ready()) { fail_no_device("libxsmm_spmdm_createSparseSlice_fp32_thread"); return; }
-  if (!spmdm_block_ok(handle, block_id, handle->mb * handle->kb, "libxsmm_spmdm_createSparseSlice_fp32_thread")) return;
+  if (!spmdm_block_ok(handle, block_id, handle->mb, "libxsmm_spmdm_createSparseSlice_fp32_thread")) return;
   spmdm_create(handle, transa, a, block_id, 1, false);
 }
 
@@ -407,7 +406,7 @@ LIBXSMM_API void libxsmm_spmdm_createSparseSlice_bfloat16_thread(const libxsmm_s
   (void)tid; (void)nthreads;
   if (nullptr == handle || nullptr == a || nullptr == libxsmm_output_csr_a || nullptr == handle->base_ptr_scratch_A) return;
   if (!device_ready()) { fail_no_device("libxsmm_spmdm_createSparseSlice_bfloat16_thread"); return; }
-  if (!spmdm_block_ok(handle, block_id, handle->mb * handle->kb, "libxsmm_spmdm_createSparseSlice_bfloat16_thread")) return;
+  if (!spmdm_block_ok(handle, block_id, handle->mb, "libxsmm_spmdm_createSparseSlice_bfloat16_thread")) return;
   bool ok = true;
   const float* const da = widen_bf16(a, (size_t)handle->m * handle->k, 6, 3, &ok);
   if (!ok) return;
@@ -451,7 +450,7 @@ LIBXSMM_API int libxsmm_amd_spmdm_createSparseSlice_all(const libxsmm_spmdm_hand
 {
   if (nullptr == handle || nullptr == a || nullptr == libxsmm_output_csr_a || nullptr == handle->base_ptr_scratch_A) return EXIT_FAILURE;
   if (!device_ready()) { fail_no_device("libxsmm_amd_spmdm_createSparseSlice_all"); return EXIT_FAILURE; }
-  spmdm_create(handle, transa, a, 0, handle->mb * handle->kb, false);
+  spmdm_create(handle, transa, a, 0, handle->mb, false);
   return EXIT_SUCCESS;
 }
 
@@ -473,7 +472,7 @@ LIBXSMM_API int libxsmm_amd_spmdm_createSparseSlice_bfloat16_all(const libxsmm_s
   bool ok = true;
   const float* const da = widen_bf16(a, (size_t)handle->m * handle->k, 6, 3, &ok);
   if (!ok) return EXIT_FAILURE;
-  spmdm_create(handle, transa, da, 0, handle->mb * handle->kb, true);
+  spmdm_create(handle, transa, da, 0, handle->mb, true);
   return EXIT_SUCCESS;
 }
 

@@ -176,3 +176,15 @@ def test_blocked_gemm_on_the_specialised_run_kernels(xs, torch_gpu, dtype, geom,
     expect = A @ B + Cm
     tol = np.finfo(dtype).eps * np.sqrt(k) * 8
     assert np.max(np.abs(got.reshape(n, m).T - expect)) <= tol * np.max(np.abs(expect))
+
+
+def test_handle_rejects_low_precision(xs, torch_gpu):
+    """libxsmm_blocked_gemm_handle_create with 16-bit inputs: the copy / compute kernels here move 4- and 8-byte elements only
+    (the reference's I16 blocked GEMM, src/libxsmm_blocked_gemm.c:536-550, is not built) -- NULL, no handle that would read
+    past the caller's buffers."""
+    L = xs.lib()
+    bm = C.c_int(32)
+    for iprec, oprec in ((xs.I16, xs.I32), (xs.I16, xs.F32), (xs.BF16, xs.F32), (xs.BF16, xs.BF16), (xs.F32, xs.F64)):
+        h = L.libxsmm_blocked_gemm_handle_create(1, iprec, oprec, 64, 64, 64, C.byref(bm), C.byref(bm), C.byref(bm),
+                                                 None, None, None, None, None, None, None, None, None)
+        assert not h, (iprec, oprec)

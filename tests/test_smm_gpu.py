@@ -503,3 +503,119 @@ def test_mmbatch_tasks_on_threads_share_c_blocks(xs, orc, torch_gpu, big):
     torch.cuda.synchronize()
     out = dc.cpu().numpy()
     assert np.max(np.abs(out - ref)) <= 1e-12 * np.max(np.abs(ref))
+
+
+@pytest.mark.parametrize("where", ["device", "host"])
+def test_general_batch_repeated_c_is_sequential(xs, orc, torch_gpu, where):
+    """General form (alpha = 2, beta = -1: the BLAS-fallback domain of libxsmm_mmbatch, src/libxsmm_gemm.c:1842-1866 ->
+    libxsmm_mmbatch_blas :1778-1806, a sequential loop): items that share a C apply C = alpha*A_i*B_i + beta*C one after the
+    other in batch order -- consecutive repeats, shuffled repeats, and stride_c == NULL (one C for the whole batch)."""
+    torch = torch_gpu
+    m, n, k, batch, nblocks = 9, 7, 11, 60, 13
+    rng = np.random.default_rng(21)
+    a = rng.uniform(-1, 1, batch * m * k); b = rng.uniform(-1, 1, batch * k * n)
+    sa = (np.arange(batch) * m * k).astype(np.int32); sb = (np.arange(batch) * k * n).astype(np.int32)
+    cases = {
+        "runs": np.sort(rng.integers(0, nblocks, batch)),
+        "shuffled": rng.integers(0, nblocks, batch),
+        "alternating": np.arange(batch) % 2,
+        "single": None,
+    }
+    for name, blocks in cases.items():
+        c = rng.uniform(-1, 1, nblocks * m * n)
+        sc = None if blocks is None else (blocks * m * n).astype(np.int32)
+        ref = c.copy()
+        for i in range(batch):
+            off = 0 if blocks is None else int(blocks[i]) * m * n
+            A = a[i * m * k:(i + 1) * m * k].reshape(k, m).T; B = b[i * k * n:(i + 1) * k * n].reshape(n, k).T
+            Cm = ref[off:off + m * n].reshape(n, m).T
+            ref[off:off + m * n] = (2.0 * (A @ B) - 1.0 * Cm).T.reshape(-1)
+        if where == "device":
+            xa, xb, xc = (torch.from_numpy(x).cuda() for x in (a, b, c))
+        else:
+            xa, xb, xc = a, b, c.copy()
+        xs.gemm_batch(xs.F64, "N", "N", m, n, k, 2.0, xa, m, xb, k, -1.0, xc, m, 0, 4, sa, sb, sc, batch)
+        torch.cuda.synchronize()
+        out = xc.cpu().numpy() if where == "device" else xc
+        assert np.max(np.abs(out - ref)) <= 1e-11 * max(1.0, np.max(np.abs(ref))), name
+    # arrays of pointers with repeats (device matrices, host pointer arrays)
+    c = rng.uniform(-1, 1, nblocks * m * n); blocks = rng.integers(0, nblocks, batch)
+    ref = c.copy()
+    for i in range(batch):
+        off = int(blocks[i]) * m * n
+        A = a[i * m * k:(i + 1) * m * k].reshape(k, m).T; B = b[i * k * n:(i + 1) * k * n].reshape(n, k).T
+        ref[off:off + m * n] = (2.0 * (A @ B) - 1.0 * ref[off:off + m * n].reshape(n, m).T).T.reshape(-1)
+    da, db, dc = (torch.from_numpy(x).cuda() for x in (a, b, c))
+    pa = np.array([da.data_ptr() + 8 * i * m * k for i in range(batch)], dtype=np.uint64)
+    pb = np.array([db.data_ptr() + 8 * i * k * n for i in range(batch)], dtype=np.uint64)
+    pc = np.array([dc.data_ptr() + 8 * int(blocks[i]) * m * n for i in range(batch)], dtype=np.uint64)
+    eight = np.array([8], dtype=np.int32)
+    xs.gemm_batch(xs.F64, "N", "N", m, n, k, 2.0, pa, m, pb, k, -1.0, pc, m, 0, 0, eight, eight, eight, batch)
+    torch.cuda.synchronize()
+    assert np.max(np.abs(dc.cpu().numpy() - ref)) <= 1e-11 * max(1.0, np.max(np.abs(ref)))
+
+
+@pytest.mark.parametrize("negative", [False, True])
+def test_mmbatch_tasks_on_threads_with_host_operands(xs, orc, torch_gpu, negative):
+    """libxsmm_mmbatch(..., tid, ntasks) from ntasks threads with operands in pageable host memory (an unchanged CPU caller):
+    every task stages its slice through private device copies, so the staged slices take turns (the reference takes a lock
+    per C, src/libxsmm_gemm.c:1366-1423). Shared C blocks (positive batchsize) and disjoint but interleaved C blocks
+    (negative batchsize: the caller's promise that nothing is shared) -- no update and no finished block is lost."""
+    import threading
+    L = xs.lib()
+    m, n, k = 13, 5, 7
+    ntasks, per = 4, 50
+    batch = ntasks * per
+    rng = np.random.default_rng(8)
+    a = rng.uniform(-1, 1, batch * m * k); b = rng.uniform(-1, 1, batch * k * n)
+    sa = (np.arange(batch) * m * k).astype(np.int32); sb = (np.arange(batch) * k * n).astype(np.int32)
+    if negative:  # item i owns block perm[i]: the tasks' index ranges interleave, no block is shared
+        blocks = rng.permutation(batch)
+        c = rng.uniform(-1, 1, batch * m * n)
+    else:         # every task updates the same `per` blocks
+        blocks = np.arange(batch) % per
+        c = rng.uniform(-1, 1, per * m * n)
+    sc = (blocks * m * n).astype(np.int32)
+    ref = c.copy()
+    assert 0 == orc.gemm_batch_idx(orc.FMA, 0, m, n, k, m, k, m, a, b, ref, 0, sa, sb, sc, batch)
+    one = C.c_double(1.0)
+    errors = []
+
+    def work(tid):
+        try:
+            L.libxsmm_mmbatch(xs.F64, xs.F64, b"N", b"N", m, n, k, C.byref(one), a.ctypes.data, None, b.ctypes.data, None, C.byref(one), c.ctypes.data, None,
+                              0, 4, sa.ctypes.data, sb.ctypes.data, sc.ctypes.data, -batch if negative else batch, tid, ntasks)
+        except Exception as exc:
+            errors.append(repr(exc))
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(ntasks)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert np.max(np.abs(c - ref)) <= 1e-12 * max(1.0, np.max(np.abs(ref)))
+
+
+def test_shuffled_duplicate_c_in_pinned_host_memory(xs, orc, torch_gpu):
+    """C in libxsmm_malloc memory (pinned host memory the GPU works on in place) with C blocks that repeat out of order:
+    hardware floating-point atomics do not reach such memory, the sums join C by compare-and-swap (kernels/smm_generic.hip)."""
+    torch = torch_gpu
+    L = xs.lib()
+    m, n, k, batch, nblocks = 8, 8, 8, 500, 17
+    rng = np.random.default_rng(12)
+    for dtype, prec, tol in ((np.float64, xs.F64, 1e-12), (np.float32, xs.F32, 1e-5)):
+        a = rng.uniform(-1, 1, batch * m * k).astype(dtype); b = rng.uniform(-1, 1, batch * k * n).astype(dtype)
+        c0 = rng.uniform(-1, 1, nblocks * m * n).astype(dtype)
+        blocks = rng.integers(0, nblocks, batch)
+        sa = (np.arange(batch) * m * k).astype(np.int32); sb = (np.arange(batch) * k * n).astype(np.int32); sc = (blocks * m * n).astype(np.int32)
+        ref = c0.copy()
+        assert 0 == orc.gemm_batch_idx(orc.FMA, 0, m, n, k, m, k, m, a, b, ref, 0, sa, sb, sc, batch)
+        bufs = []
+        for x in (a, b, c0):
+            ptr = L.libxsmm_malloc(x.nbytes); assert ptr
+            C.memmove(ptr, x.ctypes.data, x.nbytes); bufs.append(ptr)
+        xs.gemm_batch(prec, "N", "N", m, n, k, 1.0, bufs[0], m, bufs[1], k, 1.0, bufs[2], m, 0, 4, sa, sb, sc, batch)  # returns when C is written
+        out = np.frombuffer((C.c_char * c0.nbytes).from_address(bufs[2]), dtype=dtype).copy()
+        for ptr in bufs:
+            L.libxsmm_free(ptr)
+        assert np.max(np.abs(out.astype(np.float64) - ref.astype(np.float64))) <= tol * max(1.0, float(np.max(np.abs(ref)))) * 8

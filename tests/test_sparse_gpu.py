@@ -320,7 +320,7 @@ def test_spmdm_reference_slices_bitexact(xs, orc, torch_gpu, transa):
     oh, osl = orc.spmdm_slices(M, N, K, 48, transa, a, handle=orc.spmdm_geometry(M, N, K, h.bm, h.bn, h.bk))
     da = torch.from_numpy(a).cuda()
     nblk = L.libxsmm_spmdm_get_num_createSparseSlice_blocks(C.byref(h))
-    assert nblk == h.mb * h.kb == len(osl)
+    assert nblk == h.mb and h.mb * h.kb == len(osl)  # a create block is a row block of A: the slices of all its column blocks
     for how in ("blocks", "all", "host"):
         if how == "blocks":
             for blk in reversed(range(nblk)):
@@ -348,7 +348,7 @@ def test_spmdm_block_contract(xs, orc, torch_gpu):
     call touches the C tile resp. the slice of its block id and nothing else, with the operands of THAT call.
     (i) every compute block with its own B and beta = 1; (ii) a subset of the blocks: the other tiles keep their NaN
     canaries bit for bit; (iii) B changed in place between two block calls; (iv) a subset of the create blocks after A
-    changed: only those slices change."""
+    changed: only the slices of those blocks change."""
     torch = torch_gpu
     M, N, K = 1100, 2300, 150   # mb = 3, nb = 2, kb = 3 with the engine's geometry
     a, b, c = spmdm_inputs(M, N, K, 0.85, 3, orc)
@@ -356,7 +356,7 @@ def test_spmdm_block_contract(xs, orc, torch_gpu):
     h = xs.SpmdmHandle(); slices = C.POINTER(xs.CSRSlice)()
     L.libxsmm_spmdm_init(M, N, K, 1, C.byref(h), C.byref(slices))
     ncreate, ncomp = L.libxsmm_spmdm_get_num_createSparseSlice_blocks(C.byref(h)), L.libxsmm_spmdm_get_num_compute_blocks(C.byref(h))
-    assert ncreate >= 4 and ncomp >= 4 and h.nb >= 2 and h.mb >= 2
+    assert ncreate >= 3 and ncomp >= 4 and h.nb >= 2 and h.mb >= 2
     geom = lambda: orc.spmdm_geometry(M, N, K, h.bm, h.bn, h.bk)
     da, db, dc = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), torch.from_numpy(c).cuda()
     alpha = C.c_float(1.0)
@@ -377,7 +377,7 @@ def test_spmdm_block_contract(xs, orc, torch_gpu):
     for i in range(ncomp):
         compute(i, 1.0, dbs[i])
     assert L.libxsmm_amd_launch_count() == launches + ncomp
-    assert xs.last_kernel() == "spmdm_compute_tiled"
+    assert xs.last_kernel().startswith("spmdm_compute_tiled")
     torch.cuda.synchronize()
     ref = c.copy()
     for i in range(ncomp):
@@ -424,8 +424,8 @@ def test_spmdm_block_contract(xs, orc, torch_gpu):
     torch.cuda.synchronize()
     after = _device_slices(xs, h, slices)
     _, o2 = orc.spmdm_slices(M, N, K, 48, "N", a2, handle=geom())
-    for blk in range(ncreate):
-        want = o2[blk] if blk in redo else before[blk]
+    for blk in range(h.mb * h.kb):  # slice kb * mb_count + mb belongs to create block mb
+        want = o2[blk] if (blk % h.mb) in redo else before[blk]
         for x, y in zip(after[blk], want):
             assert np.array_equal(x.view(np.uint16 if x.dtype == np.uint16 else np.uint32), y.view(np.uint16 if y.dtype == np.uint16 else np.uint32)), blk
     L.libxsmm_spmdm_destroy(C.byref(h))
@@ -466,7 +466,7 @@ def test_spmdm_whole_problem_calls(xs, orc, torch_gpu, case):
         assert 0 == L.libxsmm_amd_spmdm_createSparseSlice_all(C.byref(h), ta.encode(), xs.dptr(xa), slices)
         assert 0 == L.libxsmm_amd_spmdm_compute_all(C.byref(h), ta.encode(), tb.encode(), C.byref(alpha), slices, xs.dptr(xb), tc.encode(), C.byref(be), xs.dptr(xc))
         assert L.libxsmm_amd_launch_count() == launches + 2
-        assert xs.last_kernel() == "spmdm_compute_tiled"
+        assert xs.last_kernel().startswith("spmdm_compute_tiled")
         torch.cuda.synchronize()
         out = xc.cpu().numpy() if on_device else xc
         L.libxsmm_spmdm_destroy(C.byref(h))

@@ -780,61 +780,30 @@ void spmdm_compute_mfma_kernel(long long batch, int M_arg, int K_arg, float beta
 // A work-group of sixteen waves owns a 64 x 256 tile of C for the whole sum over k: per slice column block (bk = 64 columns
 // of A = 64 rows of B) the B panel [64][256] and the CSR entries of the tile's 64 rows are staged in LDS (loads of the next
 // block in flight in registers meanwhile), C stays in registers. All 64 lanes of a wave work on ONE row at a time, a lane
-// owning four adjacent columns: the row's entries (at most 64) are fetched with a single ds_read_b64 -- one entry per lane
-// -- and handed round with v_readlane, so that the LDS pipe only carries the gathered B rows (one conflict-free
-// ds_read_b128 per entry and wave). Row r = 16 i + w of the tile belongs to wave w, round i. Per C element:
-// acc = beta * C; acc = fma(val_p, B[col_p][n], acc) over the column blocks in order and the row's entries in order --
-// the chain of the reference (compute tpl :321-371); beta == 0 never reads C.
+// owning four adjacent columns: per entry one broadcast ds_read_b64 ({B row offset, value}, the same address in every lane)
+// and one conflict-free ds_read_b128 of the B row, then four fma. Row r = 16 i + w of the tile belongs to wave w, round i.
+// Per C element: acc = beta * C; acc = fma(val_p, B[col_p][n], acc) over the column blocks in order and the row's entries
+// in order -- the chain of the reference (compute tpl :321-371); beta == 0 never reads C.
+// (Measured alternatives, tools/probe/readlane_cost.hip and A/B builds of this kernel on 2048^3 at 15 %: a row's entries held
+// one per lane and handed round with v_readlane -- 7 cycles per value with a run-time lane select, 2.9 with an immediate --
+// 0.141 ms against 0.123 ms for the broadcast reads; the B panel brought in by global_load_lds into a second buffer
+// (one barrier per column block, no ds_write) 0.163 ms; eight waves per tile 0.167 ms.)
 constexpr int SPT_BK = 64, SPT_TN = 256, SPT_TM = 64, SPT_CAP = 1536, SPT_WAVES = 16, SPT_THREADS = 64 * SPT_WAVES;
 constexpr int SPT_RW = SPT_TM / SPT_WAVES;                        // rows per wave
 constexpr int SPT_NB = SPT_BK * SPT_TN / 4 / SPT_THREADS;         // 16-byte pieces of the B panel per thread
 constexpr size_t SPT_LDS = (size_t)SPT_BK * SPT_TN * 4 + (size_t)SPT_CAP * 8 + 160;
 static_assert(2 * SPT_THREADS >= SPT_CAP, "one pair of entries per thread covers a window");
 
-template<int U>
-__device__ __forceinline__ void spt_fold(const sp_f32x2 ent, int j0, const float* __restrict__ brow, sp_f32x4& acc)
+// entries [0, cnt) of one row (row_meta: wave-uniform) folded into the row's accumulators, in order
+__device__ __forceinline__ void spt_row(const float2* __restrict__ row_meta, int cnt, const float* __restrict__ brow, sp_f32x4& acc)
 {
-  sp_f32x4 bv[U]; float av[U];
-#pragma unroll
-  for (int u = 0; u < U; ++u) {
-#if defined(SPT_DIAG_NO_READLANE)
-    const int off = (j0 + u) * SPT_TN; av[u] = 0.5f;
-#else
-    const int off = __builtin_amdgcn_readlane(__float_as_int(ent[0]), j0 + u);
-    av[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ent[1]), j0 + u));
-#endif
-#if defined(SPT_DIAG_NO_BREAD)
-    bv[u] = sp_f32x4{ (float)off, 1.f, 2.f, 3.f };
-#else
-    bv[u] = *reinterpret_cast<const sp_f32x4*>(brow + off);
-#endif
-  }
-#if defined(SPT_FMA_ASM)
-  float c0 = acc[0], c1 = acc[1], c2 = acc[2], c3 = acc[3];
-#pragma unroll
-  for (int u = 0; u < U; ++u) { // four v_fma_f32 (left to the compiler they are paired into v_pk_fma_f32)
-    asm("v_fma_f32 %0, %1, %2, %0" : "+v"(c0) : "s"(av[u]), "v"(bv[u][0]));
-    asm("v_fma_f32 %0, %1, %2, %0" : "+v"(c1) : "s"(av[u]), "v"(bv[u][1]));
-    asm("v_fma_f32 %0, %1, %2, %0" : "+v"(c2) : "s"(av[u]), "v"(bv[u][2]));
-    asm("v_fma_f32 %0, %1, %2, %0" : "+v"(c3) : "s"(av[u]), "v"(bv[u][3]));
-  }
-  acc = sp_f32x4{ c0, c1, c2, c3 };
-#else
-#pragma unroll
-  for (int u = 0; u < U; ++u) {
-    acc[0] = xfma(av[u], bv[u][0], acc[0]); acc[1] = xfma(av[u], bv[u][1], acc[1]);
-    acc[2] = xfma(av[u], bv[u][2], acc[2]); acc[3] = xfma(av[u], bv[u][3], acc[3]);
-  }
-#endif
-}
-
-// the same with the entries fetched from LDS by every lane (one broadcast ds_read_b64 per entry): no v_readlane
-template<int U>
-__device__ __forceinline__ void spt_fold_bcast(const float2* __restrict__ row_meta, const float* __restrict__ brow, sp_f32x4& acc)
-{
-  SpwEntries<U> s;
-  s.issue(row_meta); s.landed();
-  spw_apply<U>(s.e, brow, acc);
+  int j = 0;
+  for (; j + 8 <= cnt; j += 8) spw_fold<8>(row_meta + j, brow, acc);
+  // (the tail of a row as one padded group of 4 or 8 -- one LDS round trip instead of up to three -- was measured 10 % slower:
+  // the LDS bandwidth of the padding costs more than the round trips)
+  if (cnt & 4) { spw_fold<4>(row_meta + j, brow, acc); j += 4; }
+  if (cnt & 2) { spw_fold<2>(row_meta + j, brow, acc); j += 2; }
+  if (cnt & 1) spw_fold<1>(row_meta + j, brow, acc);
 }
 
 // VEC: N % 4 == 0 (K % 4 == 0 for a transposed B) and 16-byte aligned B and C: 16-byte global accesses
@@ -981,11 +950,7 @@ void spmdm_tiled_kernel(int M, int N, int K, int bm, int mb_count, int kb_count,
     // ---- the next column block's loads go out now
     int base2, pend2;
     entry_range(kb + 2, base2, pend2);
-#if defined(SPT_DIAG_NO_STAGE)
-    if (kb + 1 < kb_count && 0 == kb) fetch(kb + 1, base1, pend1);
-#else
     if (kb + 1 < kb_count) fetch(kb + 1, base1, pend1);
-#endif
     spw_lds_barrier();
     // ---- rounds of sixteen rows; a window holds the entries of as many consecutive rounds as fit the buffer
     int round0 = 0;
@@ -1013,38 +978,8 @@ void spmdm_tiled_kernel(int M, int N, int K, int bm, int mb_count, int kb_count,
         const int r = SPT_WAVES * lane + wave;
         if (lane >= round0 && lane < round1 && r < rows) { vp0 = (int)ris[r] - wbase; vcnt = (int)ris[r + 1] - wbase - vp0; }
       }
-      // a row's entries: one per lane (a single ds_read_b64), fetched one row ahead of the arithmetic
-      auto row_entries = [&](int i, int& cnt) -> sp_f32x2 {
-        const int p0 = __builtin_amdgcn_readlane(vp0, i);
-        cnt = __builtin_amdgcn_readlane(vcnt, i);
-        sp_f32x2 ent = sp_f32x2{ 0.f, 0.f };
-        if (lane < cnt) { const float2 e2 = meta[p0 + lane]; ent = sp_f32x2{ e2.x, e2.y }; }
-        return ent;
-      };
-      int cnt_next = 0;
-      sp_f32x2 ent_next = row_entries(0, cnt_next);
 #pragma unroll
-      for (int i = 0; i < SPT_RW; ++i) {
-        const sp_f32x2 ent = ent_next; const int cnt = cnt_next;
-        if (i + 1 < SPT_RW) ent_next = row_entries(i + 1, cnt_next);
-#if defined(SPT_DIAG_NO_FOLD)
-        acc[i][0] += ent[1] + (float)cnt;
-#elif defined(SPT_LDS_BCAST)
-        const float2* const rm = meta + __builtin_amdgcn_readlane(vp0, i);
-        int j = 0;
-        for (; j + 8 <= cnt; j += 8) spt_fold_bcast<8>(rm + j, brow, acc[i]);
-        if (cnt & 4) { spt_fold_bcast<4>(rm + j, brow, acc[i]); j += 4; }
-        if (cnt & 2) { spt_fold_bcast<2>(rm + j, brow, acc[i]); j += 2; }
-        if (cnt & 1) spt_fold_bcast<1>(rm + j, brow, acc[i]);
-        (void)ent;
-#else
-        int j = 0;
-        for (; j + 8 <= cnt; j += 8) spt_fold<8>(ent, j, brow, acc[i]);
-        if (cnt & 4) { spt_fold<4>(ent, j, brow, acc[i]); j += 4; }
-        if (cnt & 2) { spt_fold<2>(ent, j, brow, acc[i]); j += 2; }
-        if (cnt & 1) spt_fold<1>(ent, j, brow, acc[i]);
-#endif
-      }
+      for (int i = 0; i < SPT_RW; ++i) spt_row(meta + __builtin_amdgcn_readlane(vp0, i), __builtin_amdgcn_readlane(vcnt, i), brow, acc[i]);
       spw_lds_barrier(); // the buffers are overwritten next
       round0 = round1;
     }
@@ -1069,172 +1004,6 @@ void spmdm_tiled_kernel(int M, int N, int K, int bm, int mb_count, int kb_count,
         for (int q = 0; q < 4; ++q) if (q < nvalid) c[(size_t)(n0 + nl + q) * M + m0 + r] = acc[i][q];
       }
     }
-  }
-}
-
-// ---- the same tile plan with the B panel brought in by LDS-DMA (B not transposed, 16-byte accesses) ----------------------
-// global_load_lds_dwordx4 writes a wave's 64 x 16 bytes -- one row of the panel -- straight into LDS: no registers, no
-// ds_write on the way. Two panel buffers and two entry buffers: while column block kb is multiplied out of one pair, block
-// kb + 1 lands in the other (its CSR entries travel through registers one block further ahead, as in the kernel above);
-// one barrier per column block. The entries of a row reach the lanes as broadcast ds_read_b64 (v_readlane with a run-time
-// lane select costs 7 cycles per value on this chip, tools/probe/readlane_cost.hip; the LDS pipe has the room).
-constexpr size_t SPD_LDS = 2 * ((size_t)SPT_BK * SPT_TN * 4 + (size_t)SPT_CAP * 8 + 144);
-
-__global__ __launch_bounds__(SPT_THREADS)
-void spmdm_tiled_dma_kernel(int M, int N, int K, int bm, int mb_count, int kb_count, float beta,
-                            const uint16_t* __restrict__ rowidx, const uint16_t* __restrict__ colidx, const float* __restrict__ values,
-                            long long rstride, long long cap, const float* __restrict__ b, float* __restrict__ c,
-                            int mb_begin, int mb_n, int n_begin, int n_end)
-{
-  extern __shared__ __align__(16) unsigned char spd_raw[];
-  constexpr int BUF = SPT_BK * SPT_TN * 4 + SPT_CAP * 8 + 144; // bytes of one {panel, entries, row starts} set
-  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int tiles_per_mb = (bm + SPT_TM - 1) / SPT_TM;
-  const int tiles_m = mb_n * tiles_per_mb, tiles_n = (n_end - n_begin + SPT_TN - 1) / SPT_TN;
-  const int total = tiles_m * tiles_n, per_xcd = (total + 7) / 8;
-  const int linear = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
-  if ((int)(blockIdx.x >> 3) >= per_xcd || linear >= total) return;
-  const int tn = linear / tiles_m, tmi = linear - tn * tiles_m;
-  const int mbi = mb_begin + tmi / tiles_per_mb, ml0 = (tmi % tiles_per_mb) * SPT_TM;
-  const int nrows_mb = ((mbi + 1) * bm > M) ? (M - mbi * bm) : bm;
-  if (ml0 >= nrows_mb) return;
-  const int rows = (nrows_mb - ml0 < SPT_TM) ? (nrows_mb - ml0) : SPT_TM;
-  const int n0 = n_begin + tn * SPT_TN;
-  const int ncols = (n_end - n0 < SPT_TN) ? (n_end - n0) : SPT_TN;
-  const int m0 = mbi * bm + ml0;
-  const int nl = 4 * lane;
-  const bool lane_ok = (nl < ncols); // (ncols is a multiple of four on this path)
-  auto panel = [&](int set) { return reinterpret_cast<float*>(spd_raw + (size_t)set * BUF); };
-  auto entries = [&](int set) { return reinterpret_cast<float2*>(spd_raw + (size_t)set * BUF + SPT_BK * SPT_TN * 4); };
-  auto rowstarts = [&](int set) { return reinterpret_cast<unsigned short*>(spd_raw + (size_t)set * BUF + SPT_BK * SPT_TN * 4 + SPT_CAP * 8); };
-
-  // rows w, w + 16, ... of column block kb's panel -> LDS set `set` (a row = one wave instruction)
-  auto dma_panel = [&](int kb, int set) {
-    const int k0 = kb * SPT_BK, kc = (K - k0 < SPT_BK) ? (K - k0) : SPT_BK;
-    float* const dst = panel(set);
-#pragma unroll
-    for (int j = 0; j < SPT_BK / SPT_WAVES; ++j) {
-      const int kr = wave + SPT_WAVES * j;
-      if (kr < kc && lane_ok) {
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b + (size_t)(k0 + kr) * N + n0 + nl),
-                                         (__attribute__((address_space(3))) void*)(dst + kr * SPT_TN), 16, 0, 0);
-      }
-    }
-  };
-  unsigned short rix = 0; unsigned cols = 0; sp_f32x2 vals = sp_f32x2{ 0.f, 0.f };
-  auto fetch_entries = [&](int kb, int base, int pend) {
-    const long long s = (long long)kb * mb_count + mbi;
-    if (t <= rows) rix = rowidx[s * rstride + ml0 + t];
-    if (pend - base <= SPT_CAP) {
-      const int e = 2 * t;
-      if (e < pend - base) {
-        cols = *reinterpret_cast<const unsigned*>(colidx + s * cap + base + e);
-        vals = *reinterpret_cast<const sp_f32x2*>(values + s * cap + base + e);
-      }
-    }
-  };
-  auto park_entries = [&](int set, int base, int pend) {
-    if (t <= rows) rowstarts(set)[t] = rix;
-    if (pend - base <= SPT_CAP) {
-      const int e = 2 * t;
-      if (e < pend - base) {
-        const int o0 = (int)(cols & 0xFFFFu) * SPT_TN, o1 = (int)(cols >> 16) * SPT_TN;
-        *reinterpret_cast<sp_f32x4*>(entries(set) + e) = sp_f32x4{ __int_as_float(o0), vals[0], __int_as_float(o1), vals[1] };
-      }
-    }
-  };
-  int vbase = 0, vpend = 0;
-  auto entry_range = [&](int kb, int& base, int& pend) {
-    if (0 == (kb & 63) && kb < kb_count) {
-      const int kq = kb + lane;
-      if (kq < kb_count) {
-        const uint16_t* const ri = rowidx + ((long long)kq * mb_count + mbi) * rstride + ml0;
-        vbase = (int)ri[0] & ~1; vpend = (int)ri[rows];
-      }
-    }
-    if (kb < kb_count) { base = __builtin_amdgcn_readlane(vbase, kb & 63); pend = __builtin_amdgcn_readlane(vpend, kb & 63); }
-    else { base = 0; pend = 0; }
-  };
-
-  sp_f32x4 acc[SPT_RW];
-#pragma unroll
-  for (int i = 0; i < SPT_RW; ++i) {
-    acc[i] = sp_f32x4{ 0.f, 0.f, 0.f, 0.f };
-    const int r = SPT_WAVES * i + wave;
-    if (0.f != beta && r < rows && lane_ok) {
-      const sp_f32x4 cv = *reinterpret_cast<const sp_f32x4*>(c + (size_t)(m0 + r) * N + n0 + nl);
-      acc[i] = (1.f == beta) ? cv : beta * cv;
-    }
-  }
-
-  int base, pend, base1, pend1;
-  entry_range(0, base, pend);
-  entry_range(1, base1, pend1);
-  dma_panel(0, 0);
-  fetch_entries(0, base, pend);
-  park_entries(0, base, pend); // (waits for the loads just issued)
-  if (1 < kb_count) fetch_entries(1, base1, pend1);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  spw_lds_barrier();
-  for (int kb = 0; kb < kb_count; ++kb) {
-    const int cur = kb & 1, nxt = cur ^ 1;
-    int base2, pend2;
-    entry_range(kb + 2, base2, pend2);
-    if (kb + 1 < kb_count) { // block kb + 1: entries from the registers into the other set, panel by DMA; block kb + 2's entries into the registers
-      park_entries(nxt, base1, pend1);
-      dma_panel(kb + 1, nxt);
-      if (kb + 2 < kb_count) fetch_entries(kb + 2, base2, pend2);
-    }
-    const float* const brow = panel(cur) + nl;
-    float2* const meta = entries(cur);
-    const unsigned short* const ris = rowstarts(cur);
-    const bool one_window = (pend - base <= SPT_CAP);
-    int round0 = 0;
-    const int nrounds = (rows + SPT_WAVES - 1) / SPT_WAVES;
-    while (round0 < nrounds) {
-      int round1 = nrounds, wbase = base;
-      if (!one_window) { // dense rows: the entries of as many rounds of sixteen rows as fit the buffer, straight from global memory
-        const uint16_t* const ci = colidx + ((long long)kb * mb_count + mbi) * cap;
-        const float* const va = values + ((long long)kb * mb_count + mbi) * cap;
-        wbase = __builtin_amdgcn_readfirstlane((int)ris[SPT_WAVES * round0]);
-        round1 = round0 + 1;
-        while (round1 < nrounds) {
-          const int rend = (SPT_WAVES * (round1 + 1) < rows) ? SPT_WAVES * (round1 + 1) : rows;
-          if ((int)ris[rend] - wbase > SPT_CAP) break;
-          ++round1;
-        }
-        round1 = __builtin_amdgcn_readfirstlane(round1);
-        const int wend = (int)ris[(SPT_WAVES * round1 < rows) ? SPT_WAVES * round1 : rows];
-        if (0 < round0) spw_lds_barrier(); // the previous window's readers are done
-        for (int e = t; e < wend - wbase; e += SPT_THREADS) meta[e] = float2{ __int_as_float((int)ci[wbase + e] * SPT_TN), va[wbase + e] };
-        spw_lds_barrier();
-      }
-      int vp0 = 0, vcnt = 0;
-      if (lane < SPT_RW) {
-        const int r = SPT_WAVES * lane + wave;
-        if (lane >= round0 && lane < round1 && r < rows) { vp0 = (int)ris[r] - wbase; vcnt = (int)ris[r + 1] - wbase - vp0; }
-      }
-#pragma unroll
-      for (int i = 0; i < SPT_RW; ++i) {
-        const float2* const rm = meta + __builtin_amdgcn_readlane(vp0, i);
-        const int cnt = __builtin_amdgcn_readlane(vcnt, i);
-        int j = 0;
-        for (; j + 8 <= cnt; j += 8) spt_fold_bcast<8>(rm + j, brow, acc[i]);
-        if (cnt & 4) { spt_fold_bcast<4>(rm + j, brow, acc[i]); j += 4; }
-        if (cnt & 2) { spt_fold_bcast<2>(rm + j, brow, acc[i]); j += 2; }
-        if (cnt & 1) spt_fold_bcast<1>(rm + j, brow, acc[i]);
-      }
-      round0 = round1;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's share of the next panel has landed (and the entries two blocks ahead)
-    spw_lds_barrier();
-    base = base1; pend = pend1; base1 = base2; pend1 = pend2;
-  }
-
-#pragma unroll
-  for (int i = 0; i < SPT_RW; ++i) {
-    const int r = SPT_WAVES * i + wave;
-    if (r < rows && lane_ok) *reinterpret_cast<sp_f32x4*>(c + (size_t)(m0 + r) * N + n0 + nl) = acc[i];
   }
 }
 
@@ -1333,18 +1102,6 @@ int launch_spmdm_compute_tiled(int M, int N, int K, int bm, int bk, int mb, int 
   const unsigned grid = (unsigned)(8 * ((total + 7) / 8));
   const uintptr_t bits = reinterpret_cast<uintptr_t>(b) | (0 == transc ? reinterpret_cast<uintptr_t>(c) : 0); // (a transposed C moves element by element anyway)
   const bool vec = (0 == (bits & 15)) && 0 == (N & 3) && 0 == (n_begin & 3) && (0 == transb || 0 == (K & 3));
-  static const int dma_env = []() { const char* e = getenv("XSMM_SPMDM_DMA"); return (nullptr != e && 0 != *e) ? atoi(e) : 1; }(); // developer knob
-  if (vec && 0 == transb && 0 == transc && 0 != dma_env) {
-    static const bool attr_dma = []() {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spmdm_tiled_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SPD_LDS);
-      return true;
-    }();
-    (void)attr_dma;
-    *name = "spmdm_compute_tiled_dma";
-    hipLaunchKernelGGL(spmdm_tiled_dma_kernel, dim3(grid), dim3(SPT_THREADS), SPD_LDS, (hipStream_t)stream,
-      M, N, K, bm, mb, kb, beta, rowidx, colidx, values, rowidx_stride, cap, b, c, mb_begin, mb_n, n_begin, n_end);
-    return (int)hipGetLastError();
-  }
   *name = "spmdm_compute_tiled";
 #define XSMM_SPT(V, TB) hipLaunchKernelGGL((spmdm_tiled_kernel<V, TB>), dim3(grid), dim3(SPT_THREADS), SPT_LDS, (hipStream_t)stream, \
       M, N, K, bm, mb, kb, transc, beta, rowidx, colidx, values, rowidx_stride, cap, b, c, mb_begin, mb_n, n_begin, n_end)

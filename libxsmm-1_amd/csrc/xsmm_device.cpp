@@ -159,35 +159,55 @@ int library_gemm(int typesize, int transa, int transb, int m, int n, int k, doub
 namespace {
 constexpr unsigned FLAG_RING = 64, FLAG_INTS = 4 + 2 * FLAG_SLOT_BLOCKS;
 struct FlagSlot { hipEvent_t done = nullptr; void* stream = nullptr; int state = 0; /* 1: handed out, 2: committed */ };
-struct FlagRing {
-  int* mem = nullptr; FlagSlot slot[FLAG_RING]; unsigned next = 0;
-  ~FlagRing() { /* device memory and events are released with the process (the HIP runtime may be gone already) */ }
+struct FlagRing { int* mem = nullptr; FlagSlot slot[FLAG_RING]; unsigned next = 0; };
+// rings outlive their threads: a thread that ends hands its ring to the next thread that needs one (no HIP call at thread exit)
+std::mutex g_flag_rings_lock;
+std::vector<FlagRing*> g_flag_rings_idle;
+struct FlagRingHolder {
+  FlagRing* ring = nullptr;
+  ~FlagRingHolder() { if (nullptr != ring) { std::lock_guard<std::mutex> guard(g_flag_rings_lock); g_flag_rings_idle.push_back(ring); } }
 };
-thread_local FlagRing tl_flags;
+thread_local FlagRingHolder tl_flags;
+FlagRing* flag_ring()
+{
+  if (nullptr != tl_flags.ring) return tl_flags.ring;
+  {
+    std::lock_guard<std::mutex> guard(g_flag_rings_lock);
+    if (!g_flag_rings_idle.empty()) { tl_flags.ring = g_flag_rings_idle.back(); g_flag_rings_idle.pop_back(); return tl_flags.ring; }
+  }
+  // a new ring: cleared once, and the clearing is complete before the first slot is handed out (a check kernel on another
+  // stream must never run ahead of it)
+  void* p = nullptr;
+  const size_t bytes = (size_t)FLAG_RING * FLAG_INTS * sizeof(int);
+  hipStream_t st = (hipStream_t)device().stream;
+  if (hipSuccess != hipMalloc(&p, bytes)) { (void)hipGetLastError(); return nullptr; }
+  if (hipSuccess != hipMemsetAsync(p, 0, bytes, st) || hipSuccess != hipStreamSynchronize(st)) { (void)hipGetLastError(); (void)hipFree(p); return nullptr; }
+  FlagRing* const r = new FlagRing();
+  r->mem = static_cast<int*>(p);
+  tl_flags.ring = r;
+  return r;
+}
 }
 
 int* flag_slot()
 {
-  FlagRing& r = tl_flags;
-  if (nullptr == r.mem) {
-    void* p = nullptr;
-    if (hipSuccess == hipMalloc(&p, (size_t)FLAG_RING * FLAG_INTS * sizeof(int)) && hipSuccess == hipMemset(p, 0, (size_t)FLAG_RING * FLAG_INTS * sizeof(int))) r.mem = static_cast<int*>(p);
-    else { (void)hipGetLastError(); if (nullptr != p) (void)hipFree(p); return nullptr; }
-  }
-  const unsigned i = r.next++ % FLAG_RING;
-  FlagSlot& f = r.slot[i];
+  FlagRing* const r = flag_ring();
+  if (nullptr == r) return nullptr;
+  const unsigned i = r->next++ % FLAG_RING;
+  FlagSlot& f = r->slot[i];
   if (2 == f.state) (void)hipEventSynchronize(f.done);
   else if (1 == f.state) (void)hipStreamSynchronize((hipStream_t)f.stream); // handed out but never committed (an error path)
   if (nullptr == f.done && hipSuccess != hipEventCreateWithFlags(&f.done, hipEventDisableTiming)) { (void)hipGetLastError(); f.done = nullptr; return nullptr; }
   f.stream = device().stream; f.state = 1;
-  return r.mem + (size_t)FLAG_INTS * i;
+  return r->mem + (size_t)FLAG_INTS * i;
 }
 
 void flag_slot_commit()
 {
-  FlagRing& r = tl_flags;
+  FlagRing* const r = tl_flags.ring;
+  if (nullptr == r) return;
   for (unsigned i = 0; i < FLAG_RING; ++i) {
-    FlagSlot& f = r.slot[i];
+    FlagSlot& f = r->slot[i];
     if (1 == f.state) { if (hipSuccess == hipEventRecord(f.done, (hipStream_t)f.stream)) f.state = 2; else (void)hipGetLastError(); }
   }
 }

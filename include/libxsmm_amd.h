@@ -129,6 +129,17 @@ LIBXSMM_API void libxsmm_amd_spgemm_destroy(const libxsmm_amd_spgemm* handle);
 LIBXSMM_API int libxsmm_amd_spgemm_source(const libxsmm_gemm_descriptor* descriptor, int is_csr, const unsigned int* row_idx,
   const unsigned int* column_idx, int fma, char* buffer, size_t buffer_size, int compile);
 
+/** The MatrixMarket coordinate reader that libxsmm_generator_spgemm uses for its input file (reference:
+ *  libxsmm_sparse_csr_reader / libxsmm_sparse_csc_reader, src/generator_spgemm_csr_reader.c:46-170 and
+ *  src/generator_spgemm_csc_reader.c:46-170 -- internal to the reference's generator library). '%' lines are comments,
+ *  the first other line is "rows cols nnz", then 1-based "row col value" triples grouped by row (is_csr != 0) or by
+ *  column (is_csr == 0); rows / columns without an entry are back-filled. *o_ptr receives rows + 1 (columns + 1) offsets,
+ *  *o_idx the 0-based column (row) of every entry, *o_values the values as double; the three arrays are the caller's, to be
+ *  released with free(). Returns 0, or the reference's error code (LIBXSMM_ERR_CSR_INPUT 90035, _READ_LEN 90036,
+ *  _READ_DESC 90037, _READ_ELEMS 90038, _LEN 90039; CSC: 90011 ... 90015; see libxsmm_strerror) with nothing allocated. */
+LIBXSMM_API int libxsmm_amd_sparse_reader(const char* path, int is_csr, unsigned int** o_ptr, unsigned int** o_idx, double** o_values,
+  unsigned int* o_row_count, unsigned int* o_column_count, unsigned int* o_element_count);
+
 /** SOA width v of the libxsmm_create_*_soa kernels for a precision (8 for fp64, 16 for fp32; 0 if unsupported). */
 LIBXSMM_API int libxsmm_amd_soa_width(libxsmm_gemm_precision precision);
 /** Batch form of a kernel made by libxsmm_create_{xcsr,xcsc,rm_ac,rm_bc}_soa: `batch` products that share the operator

@@ -226,6 +226,8 @@ def _declare(L):
     sig("libxsmm_create_rm_ac_soa", vp, vp)
     sig("libxsmm_create_rm_bc_soa", vp, vp)
     sig("libxsmm_amd_soa_width", i, i)
+    sig("libxsmm_amd_sparse_reader", i, C.c_char_p, i, C.POINTER(C.POINTER(C.c_uint)), C.POINTER(C.POINTER(C.c_uint)), C.POINTER(C.POINTER(C.c_double)),
+        C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(C.c_uint))
     sig("libxsmm_amd_kernel_execute_batch", i, vp, vp, vp, vp, ll, ll, ll)
     sig("libxsmm_amd_spgemm_create", vp, vp, i, vp, vp, i)
     sig("libxsmm_amd_spgemm_execute_batch", i, vp, vp, vp, vp, ll, ll, ll)
@@ -273,6 +275,25 @@ def gemm_batch(prec, transa, transb, m, n, k, alpha, a, lda, b, ldb, beta, c, ld
     f(prec, prec, C.c_char_p(transa.encode()) if transa else None, C.c_char_p(transb.encode()) if transb else None,
       m, n, k, al, dptr(a), iptr(lda), dptr(b), iptr(ldb), be, dptr(c), iptr(ldc), index_base, index_stride,
       dptr(stride_a), dptr(stride_b), dptr(stride_c), batchsize)
+
+
+def read_mtx(path, is_csr):
+    """libxsmm_amd_sparse_reader -> (error code, ptr, idx, values, rows, cols, nnz) as numpy arrays (None on error)"""
+    import numpy as np
+    ptr, idx, val = C.POINTER(C.c_uint)(), C.POINTER(C.c_uint)(), C.POINTER(C.c_double)()
+    r, c, z = C.c_uint(0), C.c_uint(0), C.c_uint(0)
+    rc = lib().libxsmm_amd_sparse_reader(str(path).encode(), 1 if is_csr else 0, C.byref(ptr), C.byref(idx), C.byref(val), C.byref(r), C.byref(c), C.byref(z))
+    if 0 != rc:
+        assert not ptr and not idx and not val
+        return rc, None, None, None, 0, 0, 0
+    nmajor = r.value if is_csr else c.value
+    out = (rc, np.ctypeslib.as_array(ptr, (nmajor + 1,)).copy(), np.ctypeslib.as_array(idx, (z.value,)).copy(),
+           np.ctypeslib.as_array(val, (z.value,)).copy(), r.value, c.value, z.value)
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    for p in (ptr, idx, val):
+        libc.free(C.cast(p, C.c_void_p))
+    return out
 
 
 def call_kernel(fn_ptr, a, b, c, x3=None):

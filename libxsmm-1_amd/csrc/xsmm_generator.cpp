@@ -493,6 +493,29 @@ LIBXSMM_API void libxsmm_generator_spgemm(const char* i_file_out, const char* i_
   write_or_die(i_file_out, text, "libxsmm_generator_spgemm");
 }
 
+// The MatrixMarket readers behind libxsmm_generator_spgemm as a call of their own (the reference's libxsmm_sparse_csr_reader /
+// libxsmm_sparse_csc_reader, src/generator_spgemm_csr_reader.c:46-170, src/generator_spgemm_csc_reader.c:46-170, are
+// internal to its generator library; its samples carry copies, samples/edge/common_edge_proxy.h:50-280).
+LIBXSMM_API int libxsmm_amd_sparse_reader(const char* path, int is_csr, unsigned int** o_ptr, unsigned int** o_idx, double** o_values,
+  unsigned int* o_row_count, unsigned int* o_column_count, unsigned int* o_element_count)
+{
+  if (nullptr == o_ptr || nullptr == o_idx || nullptr == o_values || nullptr == o_row_count || nullptr == o_column_count || nullptr == o_element_count) return (int)ERR_SPGEMM_GEN;
+  *o_ptr = nullptr; *o_idx = nullptr; *o_values = nullptr; *o_row_count = *o_column_count = *o_element_count = 0;
+  std::vector<unsigned> ptr, idx; std::vector<double> values;
+  unsigned rows = 0, cols = 0, nnz = 0;
+  const unsigned err = read_coordinate_file(path, 0 != is_csr, ptr, idx, values, rows, cols, nnz);
+  if (0 != err) return (int)err;
+  unsigned* const p = static_cast<unsigned*>(malloc(sizeof(unsigned) * ptr.size()));
+  unsigned* const i = static_cast<unsigned*>(malloc(sizeof(unsigned) * (idx.empty() ? 1 : idx.size())));
+  double* const v = static_cast<double*>(malloc(sizeof(double) * (values.empty() ? 1 : values.size())));
+  if (nullptr == p || nullptr == i || nullptr == v) { free(p); free(i); free(v); return (int)(0 != is_csr ? ERR_CSR_ALLOC_DATA : ERR_CSC_ALLOC_DATA); }
+  memcpy(p, ptr.data(), sizeof(unsigned) * ptr.size());
+  if (!idx.empty()) memcpy(i, idx.data(), sizeof(unsigned) * idx.size());
+  if (!values.empty()) memcpy(v, values.data(), sizeof(double) * values.size());
+  *o_ptr = p; *o_idx = i; *o_values = v; *o_row_count = rows; *o_column_count = cols; *o_element_count = nnz;
+  return 0;
+}
+
 // ---- executable form -----------------------------------------------------------------------------------------------
 struct libxsmm_amd_spgemm {
   JitKernel* kernel;

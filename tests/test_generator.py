@@ -110,6 +110,156 @@ def test_generator_entry_points_and_errors(xs, orc):
     assert code.last_error == 90007
 
 
+def parse_mtx(path):
+    """independent reading of a MatrixMarket coordinate file: (rows, cols, [(row, col, value)] 0-based, in file order)"""
+    rows = cols = nnz = None
+    ent = []
+    with open(path) as f:
+        for line in f:
+            if line.startswith("%"):
+                continue
+            t = line.split()
+            if rows is None:
+                rows, cols, nnz = int(t[0]), int(t[1]), int(t[2])
+            else:
+                ent.append((int(t[0]) - 1, int(t[1]) - 1, float(t[2])))
+    assert len(ent) == nnz
+    return rows, cols, ent
+
+
+def all_fixture_files():
+    out = []
+    for root, _, files in os.walk(os.path.join(ROOT, "tests", "golden", "mtx")):
+        out += [os.path.join(root, f) for f in sorted(files) if f.endswith(".mtx")]
+    return sorted(f for f in out if "coordinate" in open(f).readline())  # (the *-de.mtx files are dense "array" files)
+
+
+def test_product_reader_known_answers(xs, orc):
+    """The library's own MatrixMarket reader (what libxsmm_generator_spgemm reads its input with; reference
+    src/generator_spgemm_csr_reader.c:46-170, generator_spgemm_csc_reader.c) against known answers: every fixture the
+    reference ships for this path (samples/generator/*.mtx, samples/pyfr/mats/**, samples/edge/mats) read as CSR and as
+    CSC where the file's grouping allows it, compared with an independent parse of the text and with the oracle's reader."""
+    files = all_fixture_files()
+    assert len(files) >= 19
+    checked = 0
+    for path in files:
+        rows, cols, ent = parse_mtx(path)
+        for is_csr in (True, False):
+            major = [e[0] if is_csr else e[1] for e in ent]
+            if major != sorted(major):
+                continue  # the file is grouped the other way (the reader assumes grouping, :147-149)
+            rc, ptr, idx, val, r, c, z = xs.read_mtx(path, is_csr)
+            assert rc == 0 and (r, c, z) == (rows, cols, len(ent)), path
+            counts = np.bincount(major, minlength=rows if is_csr else cols)
+            assert np.array_equal(ptr, np.concatenate([[0], np.cumsum(counts)]).astype(np.uint32)), path   # empty majors back-filled
+            assert np.array_equal(idx, np.array([e[1] if is_csr else e[0] for e in ent], dtype=np.uint32)), path
+            assert np.array_equal(val, np.array([e[2] for e in ent])), path                                   # bit-equal doubles
+            optr, oidx, oval, o_r, o_c, o_z = (orc.read_csr if is_csr else orc.read_csc)(path)
+            assert np.array_equal(ptr, optr) and np.array_equal(idx, oidx) and np.array_equal(val, oval) and (o_r, o_c, o_z) == (r, c, z)
+            checked += 1
+    assert checked >= 19
+    # first lines of samples/generator/left_sparse_test_csr.mtx: "1 2 2", "1 6 1"
+    rc, ptr, idx, val, r, c, z = xs.read_mtx(os.path.join(GEN, "left_sparse_test_csr.mtx"), True)
+    assert (r, c, z) == (84, 84, 686) and (idx[0], val[0], idx[1], val[1]) == (1, 2.0, 5, 1.0)
+    rc, ptr, idx, val, r, c, z = xs.read_mtx(os.path.join(GEN, "right_sparse_test_csc.mtx"), False)
+    assert (r, c, z) == (9, 9, 24)
+
+
+def test_product_reader_malformed_files(xs, tmp_path):
+    """error codes of the reference's readers (src/generator_common.h:278-305): missing file, over-long line, header that does
+    not parse or holds a zero, element line that does not parse, fewer / more elements than announced; comments and rows
+    without entries are fine."""
+    def write(name, text):
+        f = tmp_path / name
+        f.write_text(text)
+        return str(f)
+    cases = [
+        (str(tmp_path / "missing.mtx"), 90035, 90011),
+        (write("long.mtx", "3 3 1\n1 1 " + "1" * 600 + "\n"), 90036, 90012),
+        (write("zero.mtx", "% c\n0 3 1\n1 1 1.0\n"), 90037, 90013),
+        (write("header.mtx", "three 3 1\n1 1 1.0\n"), 90037, 90013),
+        (write("elem.mtx", "3 3 2\n1 1 1.0\n2 x 1.0\n"), 90038, 90014),
+        (write("short.mtx", "%%MatrixMarket matrix coordinate real general\n3 3 2\n1 1 1.0\n"), 90039, 90015),
+        (write("empty.mtx", "% nothing but comments\n"), 90039, 90015),
+        (write("many.mtx", "3 3 1\n1 1 1.0\n2 2 2.0\n"), 90038, 90014),   # (the reference would write past its arrays here)
+        (write("range.mtx", "3 3 1\n4 4 1.0\n"), 90038, 90014),             # (likewise: an index beyond the header's shape)
+    ]
+    for path, csr_code, csc_code in cases:
+        assert xs.read_mtx(path, True)[0] == csr_code, path
+        assert xs.read_mtx(path, False)[0] == csc_code, path
+        assert ("#%d" % csr_code) in xs.lib().libxsmm_strerror(csr_code).decode()
+    gap = write("gap.mtx", "% comment\n%another\n4 3 2\n1 2 5.0\n4 1 -1.5\n")
+    rc, ptr, idx, val, r, c, z = xs.read_mtx(gap, True)
+    assert rc == 0 and list(ptr) == [0, 1, 1, 1, 2] and list(idx) == [1, 0] and list(val) == [5.0, -1.5]  # empty rows back-filled (:158-163)
+    gapc = write("gapc.mtx", "3 4 2\n2 1 5.0\n1 4 -1.5\n")
+    rc, ptr, idx, val, r, c, z = xs.read_mtx(gapc, False)
+    assert rc == 0 and list(ptr) == [0, 1, 1, 1, 2] and list(idx) == [1, 0]
+
+
+def test_file_front_door_text_equals_text_from_arrays(xs, tmp_path):
+    """libxsmm_generator_spgemm(file): the kernel text written for a file is the text the array entry points
+    (libxsmm_generator_spgemm_{csr,csc,csr_reg}_kernel) emit for an independent parse of that file -- pattern (unrolled
+    kernels) and values (csr_reg kernel: values baked in) both go through the library's reader."""
+    L = xs.lib()
+    jobs = [("left_sparse_test_csr.mtx", 1, xs.F64, (84, 9, 84, 0, 9, 9)), ("left_sparse_test_csc.mtx", 0, xs.F32, (84, 9, 84, 0, 84, 84)),
+            ("right_sparse_test_csc.mtx", 0, xs.F64, (20, 9, 9, 20, 0, 20)), ("left_sparse_test_csr.mtx", 3, xs.F64, (84, 8, 84, 0, 8, 8))]
+    for fname, mode, prec, (m, n, k, lda, ldb, ldc) in jobs:
+        path = os.path.join(GEN, fname)
+        rows, cols, ent = parse_mtx(path)
+        is_csr = mode in (1, 3)
+        major = [e[0] if is_csr else e[1] for e in ent]
+        ptr = np.concatenate([[0], np.cumsum(np.bincount(major, minlength=rows if is_csr else cols))]).astype(np.uint32)
+        idx = np.array([e[1] if is_csr else e[0] for e in ent], dtype=np.uint32)
+        val = np.array([e[2] for e in ent])
+        blob, d = sparse_desc(xs, prec, m, n, k, lda, ldb, ldc)
+        code = xs.GeneratedCode()
+        if mode == 1:
+            L.libxsmm_generator_spgemm_csr_kernel(C.byref(code), d, b"gfx950", xs.dptr(ptr), xs.dptr(idx), xs.dptr(val))
+        elif mode == 3:
+            L.libxsmm_generator_spgemm_csr_reg_kernel(C.byref(code), d, b"gfx950", xs.dptr(ptr), xs.dptr(idx), xs.dptr(val))
+        else:
+            L.libxsmm_generator_spgemm_csc_kernel(C.byref(code), d, b"gfx950", xs.dptr(idx), xs.dptr(ptr), xs.dptr(val))
+        assert code.last_error == 0
+        from_arrays = code.text()
+        code.release()
+        out = tmp_path / ("k%d_%s.hip" % (mode, fname))
+        L.libxsmm_generator_spgemm(str(out).encode(), b"routine", d, b"gfx950", path.encode(), mode)
+        from_file = out.read_text()
+        if mode == 3:
+            # (a file gets the runtime header included once; otherwise the same text)
+            assert from_file.replace("#include <hip/hip_runtime.h>\n", "", 1) == from_arrays.replace("xsmm_csr_op", "routine")
+        else:
+            assert from_arrays in from_file and from_file.count("= XACC(") == from_arrays.count("= XACC(") > 0
+
+
+@pytest.mark.gpu
+def test_kernels_built_from_the_product_reader(xs, orc, torch_gpu):
+    """A kernel whose pattern and values come from the library's own reader (not the oracle's) against the oracle's arithmetic
+    on an independent parse: the csr_asparse fixture as an executable text kernel, bit for bit."""
+    torch = torch_gpu
+    L = xs.lib()
+    path = os.path.join(GEN, "left_sparse_test_csr.mtx")
+    rc, ptr, idx, val, M, K, nnz = xs.read_mtx(path, True)
+    assert rc == 0
+    n, batch = 9, 37
+    rng = np.random.default_rng(3)
+    b = rng.uniform(-1, 1, batch * K * n); c = rng.uniform(-1, 1, batch * M * n)
+    rows, cols, ent = parse_mtx(path)
+    optr = np.concatenate([[0], np.cumsum(np.bincount([e[0] for e in ent], minlength=rows))]).astype(np.uint32)
+    oidx = np.array([e[1] for e in ent], dtype=np.uint32); oval = np.array([e[2] for e in ent])
+    ref = c.copy()
+    for i in range(batch):
+        orc.csr_asparse(orc.FMA, 0, M, n, K, n, n, optr, oidx, oval, b[i * K * n:(i + 1) * K * n], ref[i * M * n:(i + 1) * M * n])
+    blob, d = sparse_desc(xs, xs.F64, M, n, K, 0, n, n)
+    h = L.libxsmm_amd_spgemm_create(d, 1, xs.dptr(ptr), xs.dptr(idx), 1)
+    assert h
+    dv, db, dc = torch.from_numpy(val).cuda(), torch.from_numpy(b).cuda(), torch.from_numpy(c).cuda()
+    assert 0 == L.libxsmm_amd_spgemm_execute_batch(h, xs.dptr(dv), xs.dptr(db), xs.dptr(dc), K * n, M * n, batch)
+    torch.cuda.synchronize()
+    L.libxsmm_amd_spgemm_destroy(h)
+    assert np.array_equal(dc.cpu().numpy(), ref)
+
+
 def hipcc_compiles(path):
     res = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "--cuda-device-only", "-x", "hip", "-c", str(path), "-o", str(path) + ".o"],
                          capture_output=True, text=True)

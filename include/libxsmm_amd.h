@@ -59,6 +59,24 @@ LIBXSMM_API int libxsmm_amd_gemm_batch_strided(const libxsmm_gemm_descriptor* de
   const void* a, const void* b, void* c, long long stride_a, long long stride_b, long long stride_c,
   long long batchsize);
 
+/** Several index-array batches in one call -- CP2K-style stacks: one batch per shape (samples/cp2k/cp2k.cpp:328-360;
+ *  the reference's one-call form for pointer arrays is libxsmm_?gemm_batch with its groups, src/libxsmm_gemm.c:1231-1262).
+ *  Equivalent to libxsmm_gemm_batch(iprec, oprec, &transa[g], &transb[g], m[g], n[g], k[g], alpha, a[g], &lda[g], b[g],
+ *  &ldb[g], beta, c[g], &ldc[g], index_base, index_stride, stride_a[g], stride_b[g], stride_c[g], group_size[g]) for every
+ *  g < ngroups, with the groups' launches fused: the C-ordering check of all groups is one launch and, where the
+ *  shape-specialised run kernels apply (M, N <= 32, K <= 64), so is the multiplication -- the accumulation chains of all
+ *  shapes are resident at the same time instead of one shape after the other. Per C block the products are added in batch
+ *  order as in libxsmm_gemm_batch (relaxed != 0: any order, as libxsmm_gemm_batch_omp). The groups must be independent of
+ *  each other: no C block is written by two groups. transa/transb/lda/ldb/ldc may be NULL ('N', tight leading dimensions);
+ *  alpha/beta: scalars of the precision (NULL: 1), the SMM domain only (alpha = 1, beta in {0, 1}, no TRANS_A). Matrices in
+ *  device memory (or libxsmm_malloc memory); index arrays in device or host memory. Returns EXIT_SUCCESS/EXIT_FAILURE. */
+LIBXSMM_API int libxsmm_amd_gemm_batch_groups(libxsmm_gemm_precision iprec, libxsmm_gemm_precision oprec, int ngroups,
+  const char transa[], const char transb[], const libxsmm_blasint m[], const libxsmm_blasint n[], const libxsmm_blasint k[],
+  const libxsmm_blasint lda[], const libxsmm_blasint ldb[], const libxsmm_blasint ldc[], const void* alpha, const void* beta,
+  const void* const a[], const void* const b[], void* const c[], libxsmm_blasint index_base, libxsmm_blasint index_stride,
+  const libxsmm_blasint* const stride_a[], const libxsmm_blasint* const stride_b[], const libxsmm_blasint* const stride_c[],
+  const libxsmm_blasint group_size[], int relaxed);
+
 /** Batched spmdm: `batch` independent problems of the handle's geometry (M,N,K), operands back to back
  *  (A: M*K, B: K*N, C: M*N elements per item, layouts/transposes as libxsmm_spmdm_*_thread).
  *  The CSR scratch lives in HBM and is owned by the returned object. */
@@ -111,6 +129,10 @@ LIBXSMM_API int libxsmm_amd_csr_kernel_source(int typesize, int M, int K, const 
  *  variant: 0 = strided batch of 16-byte aligned items (widest loads); bit 0 = element-wide accesses (index and pointer
  *  batches); bit 1 = consecutive items with one C accumulate in registers (CP2K stacks, batch-reduce). */
 LIBXSMM_API int libxsmm_amd_smm_kernel_source(const libxsmm_gemm_descriptor* descriptor, int variant, char* buffer, size_t buffer_size, int compile);
+
+/** The text a grouped launch (libxsmm_amd_gemm_batch_groups) compiles for index batches of these descriptors: the run forms
+ *  of every shape, each in a namespace of its own, behind one dispatching kernel. Conventions as above. */
+LIBXSMM_API int libxsmm_amd_smm_grouped_kernel_source(const libxsmm_gemm_descriptor* const descriptors[], int ndescriptors, char* buffer, size_t buffer_size, int compile);
 
 /** Executable form of the sparse text kernels (libxsmm_generator_spgemm_{csr,csc}_kernel): the pattern is compiled into
  *  a kernel with hiprtc, the values of the sparse operand stay a run-time argument (as for the reference's generated C

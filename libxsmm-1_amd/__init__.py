@@ -236,6 +236,9 @@ def _declare(L):
     sig("libxsmm_amd_smm_kernel_source", i, vp, i, vp, C.c_size_t, i)
     sig("libxsmm_amd_device_malloc", vp, C.c_size_t)
     sig("libxsmm_amd_device_free", None, vp)
+    sig("libxsmm_amd_smm_grouped_kernel_source", i, C.POINTER(vp), i, vp, C.c_size_t, i)
+    sig("libxsmm_amd_gemm_batch_groups", i, i, i, i, C.c_char_p, C.c_char_p, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p, vp, vp,
+        C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i, i, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), c_int_p, i)
 
 
 # ---- thin helpers used by tests and bench (argument marshalling only) -------------------------------------------------
@@ -294,6 +297,18 @@ def read_mtx(path, is_csr):
     for p in (ptr, idx, val):
         libc.free(C.cast(p, C.c_void_p))
     return out
+
+
+def gemm_batch_groups(prec, shapes, a, b, c, stride_a, stride_b, stride_c, sizes, index_base=0, index_stride=4, beta=1.0, relaxed=False):
+    """libxsmm_amd_gemm_batch_groups: shapes = [(m, n, k)], a/b/c/stride_* = per-group tensors / arrays, sizes = per-group batch sizes"""
+    n = len(shapes)
+    ints = lambda v: (C.c_int * n)(*[int(x) for x in v])
+    ptrs = lambda v: (C.c_void_p * n)(*[dptr(x).value if x is not None else None for x in v])
+    ct = C.c_double if prec == F64 else C.c_float
+    be = ct(beta)
+    return lib().libxsmm_amd_gemm_batch_groups(prec, prec, n, None, None, ints(s[0] for s in shapes), ints(s[1] for s in shapes), ints(s[2] for s in shapes),
+                                               None, None, None, None, C.byref(be), ptrs(a), ptrs(b), ptrs(c), index_base, index_stride,
+                                               ptrs(stride_a), ptrs(stride_b), ptrs(stride_c), ints(sizes), 1 if relaxed else 0)
 
 
 def call_kernel(fn_ptr, a, b, c, x3=None):

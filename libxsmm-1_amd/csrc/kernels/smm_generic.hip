@@ -11,6 +11,7 @@
 // contiguous axis, every thread keeps a TM x TN register tile of C, C is read/written directly in HBM.
 // Units stride over the batch, so consecutive units stream consecutive problems.
 #include "smm_common.cuh"
+#include <cstring>
 
 namespace xsmm {
 namespace {
@@ -188,13 +189,14 @@ void smm_generic_kernel(DevAddr ad, int M, int N, int K, int lda, int ldb, int l
 // Counts adjacent C operands that are equal (out[0]) or decreasing (out[1]). No launch in front of it has to clear
 // anything: every block leaves its counts in its own pair out[4 + 2*block ..], the block that arrives last (a ticket
 // counter, out[2], which atomicInc wraps back to zero) adds the pairs up and writes the totals.
+// (bid, nblocks: this block's index among the blocks that inspect this batch)
 template<typename T>
-__global__ __launch_bounds__(256) void c_order_kernel(DevAddr ad, long long batch, int* out)
+__device__ __forceinline__ void c_order_body(const DevAddr& ad, long long batch, int* out, unsigned bid, unsigned nblocks)
 {
   __shared__ int red[2][4];
   __shared__ bool last;
   int eq = 0, dec = 0;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x + 1; i < batch; i += (long long)gridDim.x * blockDim.x) {
+  for (long long i = (long long)bid * blockDim.x + threadIdx.x + 1; i < batch; i += (long long)nblocks * blockDim.x) {
     const T* const c0 = addr_c<T>(ad, i - 1);
     const T* const c1 = addr_c<T>(ad, i);
     eq += (c1 == c0) ? 1 : 0;
@@ -204,16 +206,16 @@ __global__ __launch_bounds__(256) void c_order_kernel(DevAddr ad, long long batc
   if (0 == (threadIdx.x & 63)) { red[0][threadIdx.x >> 6] = eq; red[1][threadIdx.x >> 6] = dec; }
   __syncthreads();
   if (0 == threadIdx.x) {
-    __hip_atomic_store(out + 4 + 2 * blockIdx.x, red[0][0] + red[0][1] + red[0][2] + red[0][3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(out + 5 + 2 * blockIdx.x, red[1][0] + red[1][1] + red[1][2] + red[1][3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(out + 4 + 2 * bid, red[0][0] + red[0][1] + red[0][2] + red[0][3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(out + 5 + 2 * bid, red[1][0] + red[1][1] + red[1][2] + red[1][3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __threadfence();
-    last = (gridDim.x - 1 == atomicInc(reinterpret_cast<unsigned*>(out + 2), gridDim.x - 1));
+    last = (nblocks - 1 == atomicInc(reinterpret_cast<unsigned*>(out + 2), nblocks - 1));
   }
   __syncthreads();
   if (!last) return;
   __threadfence();
   eq = dec = 0;
-  for (unsigned b = threadIdx.x; b < gridDim.x; b += blockDim.x) {
+  for (unsigned b = threadIdx.x; b < nblocks; b += blockDim.x) {
     eq += __hip_atomic_load(out + 4 + 2 * b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     dec += __hip_atomic_load(out + 5 + 2 * b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
@@ -225,6 +227,24 @@ __global__ __launch_bounds__(256) void c_order_kernel(DevAddr ad, long long batc
     out[0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
     out[1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
   }
+}
+
+template<typename T>
+__global__ __launch_bounds__(256) void c_order_kernel(DevAddr ad, long long batch, int* out)
+{
+  c_order_body<T>(ad, batch, out, blockIdx.x, gridDim.x);
+}
+
+// the same for up to ORDER_GROUPS batches in one launch (one verdict slot each): CP2K-style calls with a batch per shape
+constexpr int ORDER_GROUPS = 32, ORDER_GROUP_BLOCKS = 16;
+struct OrderGroup { DevAddr ad; long long batch; int* out; };
+struct OrderGroups { OrderGroup g[ORDER_GROUPS]; };
+static_assert(sizeof(OrderGroups) <= 4096, "passed by value");
+template<typename T>
+__global__ __launch_bounds__(256) void c_order_groups_kernel(OrderGroups tab)
+{
+  const unsigned g = blockIdx.x / ORDER_GROUP_BLOCKS;
+  c_order_body<T>(tab.g[g].ad, tab.g[g].batch, tab.g[g].out, blockIdx.x % ORDER_GROUP_BLOCKS, ORDER_GROUP_BLOCKS);
 }
 
 template<typename T, int TM, int TGM, bool GENERAL>
@@ -292,6 +312,21 @@ int launch_c_order_check(const SmmBatch& s, int* d_out, void* stream)
   if (blocks < 1) blocks = 1;
   if (8 == s.typesize) hipLaunchKernelGGL((c_order_kernel<double>), dim3((unsigned)blocks), dim3(256), 0, st, make_addr(s), s.batch, d_out);
   else hipLaunchKernelGGL((c_order_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, st, make_addr(s), s.batch, d_out);
+  return (int)hipGetLastError();
+}
+
+int launch_c_order_check_groups(const SmmBatch* groups, int ngroups, void* stream)
+{
+  if (ngroups < 1 || ngroups > ORDER_GROUPS) return -1;
+  OrderGroups tab; memset(&tab, 0, sizeof(tab));
+  for (int g = 0; g < ngroups; ++g) {
+    if (groups[g].typesize != groups[0].typesize || nullptr == groups[g].devflags) return -1;
+    SmmBatch s = groups[g]; s.sync = SYNC_NONE; // (make_addr: no flags pointer needed here)
+    tab.g[g].ad = make_addr(s); tab.g[g].batch = s.batch; tab.g[g].out = const_cast<int*>(groups[g].devflags);
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (8 == groups[0].typesize) hipLaunchKernelGGL((c_order_groups_kernel<double>), dim3((unsigned)(ngroups * ORDER_GROUP_BLOCKS)), dim3(256), 0, st, tab);
+  else hipLaunchKernelGGL((c_order_groups_kernel<float>), dim3((unsigned)(ngroups * ORDER_GROUP_BLOCKS)), dim3(256), 0, st, tab);
   return (int)hipGetLastError();
 }
 

@@ -43,6 +43,17 @@ void fail_no_device(const char* what)
                   "there is no CPU fallback in this library.\n", what);
 }
 
+int pointer_kind(const void* p)
+{ // one driver query: bit 0 = the GPU reaches it (device, managed, pinned host), bit 1 = the CPU addresses it as well (pinned, managed)
+  if (nullptr == p || !device_ready()) return 0;
+  hipPointerAttribute_t attr;
+  memset(&attr, 0, sizeof(attr));
+  if (hipSuccess != hipPointerGetAttributes(&attr, p)) { (void)hipGetLastError(); return 0; } // plain host memory on older runtimes
+  const bool reach = (hipMemoryTypeDevice == attr.type || hipMemoryTypeManaged == attr.type || hipMemoryTypeHost == attr.type || hipMemoryTypeArray == attr.type);
+  const bool host = (hipMemoryTypeHost == attr.type || hipMemoryTypeManaged == attr.type);
+  return (reach ? 1 : 0) | (host ? 2 : 0);
+}
+
 bool is_device_ptr(const void* p)
 {
   if (nullptr == p || !device_ready()) return false;
@@ -157,7 +168,7 @@ int library_gemm(int typesize, int transa, int transb, int m, int n, int k, doub
 // handed out again only after the launches that read it have completed (event recorded by flag_slot_commit) -- calls in
 // flight on several streams, or more calls in flight than the ring is long, never share a slot.
 namespace {
-constexpr unsigned FLAG_RING = 64, FLAG_INTS = 4 + 2 * FLAG_SLOT_BLOCKS;
+constexpr unsigned FLAG_RING = 256, FLAG_INTS = 4 + 2 * FLAG_SLOT_BLOCKS;
 struct FlagSlot { hipEvent_t done = nullptr; void* stream = nullptr; int state = 0; /* 1: handed out, 2: committed */ };
 struct FlagRing { int* mem = nullptr; FlagSlot slot[FLAG_RING]; unsigned next = 0; };
 // rings outlive their threads: a thread that ends hands its ring to the next thread that needs one (no HIP call at thread exit)
@@ -195,8 +206,12 @@ int* flag_slot()
   if (nullptr == r) return nullptr;
   const unsigned i = r->next++ % FLAG_RING;
   FlagSlot& f = r->slot[i];
-  if (2 == f.state) (void)hipEventSynchronize(f.done);
-  else if (1 == f.state) (void)hipStreamSynchronize((hipStream_t)f.stream); // handed out but never committed (an error path)
+  hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+  if (hipSuccess != hipStreamIsCapturing((hipStream_t)device().stream, &capturing)) { (void)hipGetLastError(); capturing = hipStreamCaptureStatusNone; }
+  if (hipStreamCaptureStatusNone == capturing) { // (inside a stream capture nothing may be waited for: the slot's last use lies a whole ring back)
+    if (2 == f.state) { if (hipSuccess != hipEventSynchronize(f.done)) (void)hipGetLastError(); } // (an event recorded inside a capture cannot be waited for: treated as done)
+    else if (1 == f.state) (void)hipStreamSynchronize((hipStream_t)f.stream); // handed out but never committed (an error path)
+  }
   if (nullptr == f.done && hipSuccess != hipEventCreateWithFlags(&f.done, hipEventDisableTiming)) { (void)hipGetLastError(); f.done = nullptr; return nullptr; }
   f.stream = device().stream; f.state = 1;
   return r->mem + (size_t)FLAG_INTS * i;
@@ -224,7 +239,7 @@ int flag_slot_set(int* slot, int equal_pairs, int decreasing_pairs)
 // reused INDEX_RING calls later; by then the launch that read it (event recorded by index_upload_commit) is normally long done.
 namespace {
 struct IndexStage { void* host = nullptr; void* dev = nullptr; size_t size = 0; hipEvent_t done = nullptr; void* stream = nullptr; int state = 0; /* 1: filled, 2: committed */ };
-constexpr int INDEX_RING = 24;
+constexpr int INDEX_RING = 256; // (a grouped call stages three arrays per group plus its table)
 thread_local IndexStage tl_index_ring[INDEX_RING];
 thread_local unsigned tl_index_next = 0;
 }

@@ -18,6 +18,8 @@ int launch_smm_generic(const SmmBatch& s, void* stream, const char** name);
 int launch_smm_special(const SmmBatch& s, void* stream, const char** name); // returns -1 if no specialised variant applies
 }
 
+namespace xsmm { bool relaxed_order(int ntasks, libxsmm_blasint index_stride, const void* c); }
+
 using namespace xsmm;
 
 namespace {
@@ -147,6 +149,41 @@ int sync_and_run(SmmBatch& s, bool nosync)
   if (0 != s.general) return run_general(s);
   if (0 != choose_sync(s, nosync)) return -1;
   return run_smm(s);
+}
+
+// Several batches of one precision whose operands the GPU reaches, independent of each other (no C block is written by two
+// of them): the batches that need the C-ordering verdict are checked with one launch and -- where the shape-specialised run
+// kernels apply -- multiplied with one launch (launch_smm_jit_grouped), so that the chains of all batches are resident
+// together. Whatever does not fit that form is launched batch by batch. Every s[i] arrives with its addressing resolved
+// (device index / pointer arrays) and s[i].sync == SYNC_DEVICE (verdict needed) or SYNC_NONE.
+int run_groups(std::vector<SmmBatch>& groups)
+{
+  int result = 0;
+  std::vector<SmmBatch> wanted; std::vector<size_t> where;
+  for (size_t i = 0; i < groups.size(); ++i) {
+    if (SYNC_DEVICE == groups[i].sync && 1 < groups[i].batch && 0 == groups[i].general) { wanted.push_back(groups[i]); where.push_back(i); }
+    else if (0 < groups[i].batch) { groups[i].sync = SYNC_NONE; const int e = run_smm(groups[i]); if (0 != e) result = e; }
+  }
+  for (size_t first = 0; first < wanted.size(); first += 32) { // (a check launch takes up to 32 batches)
+    const int n = (int)((wanted.size() - first < 32) ? (wanted.size() - first) : 32);
+    SmmBatch* const g = wanted.data() + first;
+    bool ok = true;
+    for (int i = 0; i < n && ok; ++i) {
+      int* const slot = flag_slot();
+      if (nullptr == slot) { ok = false; break; }
+      g[i].devflags = slot; // (c_atomics: set by the caller, who has looked at where C lives)
+    }
+    if (ok) ok = (0 == launch_c_order_check_groups(g, n, device().stream));
+    if (!ok) { flag_slot_commit(); return -1; }
+    const char* name = "";
+    int e = launch_smm_jit_grouped(g, n, device().stream, &name);
+    if (0 <= e) { note_launch(name); if (0 != e) { fprintf(stderr, "LIBXSMM-AMD ERROR: kernel launch failed (%s, hip error %d)\n", name, e); result = e; } }
+    else { // batch by batch (each reads its verdict slot)
+      for (int i = 0; i < n; ++i) { e = run_smm(g[i]); if (0 != e) result = e; }
+    }
+    flag_slot_commit();
+  }
+  return result;
 }
 
 // Slices of one libxsmm_mmbatch call that run on several threads AND stage C through private device copies (operands in
@@ -676,7 +713,63 @@ LIBXSMM_APIEXT void libxsmm_gemm_batch_omp(libxsmm_gemm_precision iprec, libxsmm
   --tl_relaxed_order;
 }
 
-#define XSMM_GROUP_BATCH(NAME, T, PREC, CALL)                                                                      \
+namespace {
+// libxsmm_?gemm_batch[_omp] with several groups whose matrices live on the device: the groups as one fused launch (run_groups)
+// instead of one batch call after the other. Only when every group is in the SMM domain and no C matrix of one group overlaps
+// the C matrices of another (the reference works the groups off one after the other, so overlapping groups must stay in that
+// order). false: not applicable, nothing was done.
+template<typename T>
+bool try_grouped_pointer_batches(libxsmm_gemm_precision prec, bool relaxed, const char transa_array[], const char transb_array[],
+  const libxsmm_blasint m_array[], const libxsmm_blasint n_array[], const libxsmm_blasint k_array[],
+  const T alpha_array[], const T* a_array[], const libxsmm_blasint lda_array[], const T* b_array[], const libxsmm_blasint ldb_array[],
+  const T beta_array[], T* c_array[], const libxsmm_blasint ldc_array[], libxsmm_blasint ngroups, const libxsmm_blasint group_size[])
+{
+  if (ngroups < 2 || !device_ready()) return false;
+  if (is_device_ptr(a_array) || is_device_ptr(b_array) || is_device_ptr(c_array)) return false; // (pointer arrays the CPU cannot read: group by group)
+  std::vector<SmmBatch> groups; groups.reserve((size_t)ngroups);
+  struct Range { uintptr_t lo, hi; };
+  std::vector<Range> ranges; ranges.reserve((size_t)ngroups);
+  long long j = 0;
+  for (libxsmm_blasint g = 0; g < ngroups; ++g) {
+    const long long size = LIBXSMM_ABS(group_size[g]);
+    if (0 == size) continue;
+    const int flags = LIBXSMM_GEMM_PFLAGS(transa_array + g, transb_array + g, LIBXSMM_FLAGS);
+    libxsmm_descriptor_blob blob;
+    const libxsmm_gemm_descriptor* const desc = libxsmm_gemm_descriptor_init2(&blob, prec, prec, m_array[g], n_array[g], k_array[g],
+      lda_array[g], ldb_array[g], ldc_array[g], alpha_array + g, beta_array + g, flags, LIBXSMM_GEMM_PREFETCH_NONE);
+    const Kernel* const kern = (nullptr != desc ? kernel_from_pointer(reinterpret_cast<const void*>(libxsmm_xmmdispatch(desc).xmm)) : nullptr);
+    if (nullptr == kern || KC_DENSE != kern->kclass) return false;
+    const int kc = pointer_kind(c_array[j]);
+    if (0 == (pointer_kind(a_array[j]) & pointer_kind(b_array[j]) & kc & 1) || 0 != (kc & 2)) return false; // host matrices: the staging path
+    SmmBatch s = from_descriptor(kern->desc);
+    s.mode = ADDR_POINTER; s.sa = s.sb = s.sc = (long long)sizeof(void*); s.batch = size;
+    s.relaxed = relaxed_order(relaxed ? 2 : 1, 0, c_array + j) ? 1 : 0; s.c_atomics = 1;
+    s.sync = (0 != (s.flags & LIBXSMM_GEMM_FLAG_BETA_0) || group_size[g] < 0 || size < 2) ? SYNC_NONE : SYNC_DEVICE;
+    uintptr_t lo = reinterpret_cast<uintptr_t>(c_array[j]), hi = lo;
+    for (long long i = 1; i < size; ++i) { const uintptr_t p = reinterpret_cast<uintptr_t>(c_array[j + i]); if (p < lo) lo = p; if (p > hi) hi = p; }
+    ranges.push_back(Range{ lo, hi + span_c(s) * sizeof(T) });
+    s.a = a_array + j; s.b = b_array + j; s.c = c_array + j; // (host arrays for now: uploaded below, once all groups have passed)
+    groups.push_back(s);
+    j += size;
+  }
+  for (size_t x = 0; x < ranges.size(); ++x) for (size_t y = x + 1; y < ranges.size(); ++y) {
+    if (ranges[x].lo < ranges[y].hi && ranges[y].lo < ranges[x].hi) return false; // C of two groups may overlap: keep the groups in order
+  }
+  bool ok = true;
+  for (SmmBatch& s : groups) {
+    void* const xa = index_upload(s.a, (size_t)s.batch * sizeof(void*)); void* const xb = index_upload(s.b, (size_t)s.batch * sizeof(void*));
+    void* const xc = index_upload(s.c, (size_t)s.batch * sizeof(void*));
+    if (nullptr == xa || nullptr == xb || nullptr == xc) { ok = false; break; }
+    s.a = xa; s.b = xb; s.c = xc;
+  }
+  if (ok) ok = (0 == run_groups(groups));
+  index_upload_commit();
+  if (!ok) { static int error_once = 0; if (0 != libxsmm_verbosity && once(&error_once)) fprintf(stderr, "LIBXSMM ERROR: libxsmm_?gemm_batch failed!\n"); }
+  return true;
+}
+}
+
+#define XSMM_GROUP_BATCH(NAME, T, PREC, CALL, RELAXED)                                                                     \
 LIBXSMM_API void NAME(const char transa_array[], const char transb_array[],                                   \
   const libxsmm_blasint m_array[], const libxsmm_blasint n_array[], const libxsmm_blasint k_array[],         \
   const T alpha_array[], const T* a_array[], const libxsmm_blasint lda_array[],                              \
@@ -686,6 +779,9 @@ LIBXSMM_API void NAME(const char transa_array[], const char transb_array[],     
 { /* reference src/libxsmm_gemm.c:1231-1262: one pointer-array batch per homogeneous group */                \
   const libxsmm_blasint ngroups = LIBXSMM_ABS(*group_count), ptrsize = (libxsmm_blasint)sizeof(void*);       \
   libxsmm_blasint i, j = 0;                                                                                    \
+  libxsmm_init();                                                                                              \
+  if (try_grouped_pointer_batches<T>(PREC, RELAXED, transa_array, transb_array, m_array, n_array, k_array, alpha_array, a_array, lda_array, \
+        b_array, ldb_array, beta_array, c_array, ldc_array, ngroups, group_size)) return;                      \
   for (i = 0; i < ngroups; ++i) {                                                                              \
     const libxsmm_blasint size = group_size[i];                                                                \
     CALL(PREC, PREC, transa_array + i, transb_array + i, m_array[i], n_array[i], k_array[i],  \
@@ -694,10 +790,10 @@ LIBXSMM_API void NAME(const char transa_array[], const char transb_array[],     
     j += LIBXSMM_ABS(size);                                                                                    \
   }                                                                                                            \
 }
-XSMM_GROUP_BATCH(libxsmm_dgemm_batch, double, LIBXSMM_GEMM_PRECISION_F64, libxsmm_gemm_batch)
-XSMM_GROUP_BATCH(libxsmm_sgemm_batch, float, LIBXSMM_GEMM_PRECISION_F32, libxsmm_gemm_batch)
-XSMM_GROUP_BATCH(libxsmm_dgemm_batch_omp, double, LIBXSMM_GEMM_PRECISION_F64, libxsmm_gemm_batch_omp)
-XSMM_GROUP_BATCH(libxsmm_sgemm_batch_omp, float, LIBXSMM_GEMM_PRECISION_F32, libxsmm_gemm_batch_omp)
+XSMM_GROUP_BATCH(libxsmm_dgemm_batch, double, LIBXSMM_GEMM_PRECISION_F64, libxsmm_gemm_batch, false)
+XSMM_GROUP_BATCH(libxsmm_sgemm_batch, float, LIBXSMM_GEMM_PRECISION_F32, libxsmm_gemm_batch, false)
+XSMM_GROUP_BATCH(libxsmm_dgemm_batch_omp, double, LIBXSMM_GEMM_PRECISION_F64, libxsmm_gemm_batch_omp, true)
+XSMM_GROUP_BATCH(libxsmm_sgemm_batch_omp, float, LIBXSMM_GEMM_PRECISION_F32, libxsmm_gemm_batch_omp, true)
 
 LIBXSMM_API int libxsmm_amd_gemm_batch_strided(const libxsmm_gemm_descriptor* descriptor,
   const void* a, const void* b, void* c, long long stride_a, long long stride_b, long long stride_c, long long batchsize)
@@ -723,6 +819,61 @@ LIBXSMM_API int libxsmm_amd_gemm_batch_strided(const libxsmm_gemm_descriptor* de
   s.mode = ADDR_STRIDED; s.a = a; s.b = b; s.c = c; s.sa = stride_a; s.sb = stride_b; s.sc = stride_c; s.batch = batchsize;
   s.sync = (0 == stride_c && 0 == (s.flags & LIBXSMM_GEMM_FLAG_BETA_0) && 1 < batchsize) ? SYNC_RUNS : SYNC_NONE;
   return 0 == run_smm(s) ? EXIT_SUCCESS : EXIT_FAILURE;
+}
+
+LIBXSMM_API int libxsmm_amd_gemm_batch_groups(libxsmm_gemm_precision iprec, libxsmm_gemm_precision oprec, int ngroups,
+  const char transa[], const char transb[], const libxsmm_blasint m[], const libxsmm_blasint n[], const libxsmm_blasint k[],
+  const libxsmm_blasint lda[], const libxsmm_blasint ldb[], const libxsmm_blasint ldc[], const void* alpha, const void* beta,
+  const void* const a[], const void* const b[], void* const c[], libxsmm_blasint index_base, libxsmm_blasint index_stride,
+  const libxsmm_blasint* const stride_a[], const libxsmm_blasint* const stride_b[], const libxsmm_blasint* const stride_c[],
+  const libxsmm_blasint group_size[], int relaxed)
+{ // ngroups calls of libxsmm_gemm_batch (index arrays) as one call, see include/libxsmm_amd.h
+  if (ngroups < 0 || (0 < ngroups && (nullptr == m || nullptr == n || nullptr == k || nullptr == a || nullptr == b || nullptr == c || nullptr == group_size)) || 0 == index_stride) return EXIT_FAILURE;
+  if (0 == ngroups) return EXIT_SUCCESS;
+  libxsmm_init();
+  if (!device_ready()) { fail_no_device("libxsmm_amd_gemm_batch_groups"); return EXIT_FAILURE; }
+  std::vector<SmmBatch> groups; groups.reserve((size_t)ngroups);
+  bool ok = true, host_visible = false;
+  static const int order_env = []() { const char* e = getenv("LIBXSMM_AMD_BATCH_ORDER"); return (nullptr == e || 0 == *e) ? 0 : (('r' == *e || 'R' == *e) ? 1 : -1); }();
+  for (int g = 0; g < ngroups && ok; ++g) {
+    const char ta = (nullptr != transa ? transa[g] : 'N'), tb = (nullptr != transb ? transb[g] : 'N');
+    const int flags = LIBXSMM_GEMM_PFLAGS(&ta, &tb, LIBXSMM_FLAGS);
+    libxsmm_descriptor_blob blob;
+    const libxsmm_gemm_descriptor* const desc = libxsmm_gemm_descriptor_init2(&blob, iprec, oprec, m[g], n[g], k[g],
+      nullptr != lda ? lda[g] : (0 == (LIBXSMM_GEMM_FLAG_TRANS_A & flags) ? m[g] : k[g]),
+      nullptr != ldb ? ldb[g] : (0 == (LIBXSMM_GEMM_FLAG_TRANS_B & flags) ? k[g] : n[g]),
+      nullptr != ldc ? ldc[g] : m[g], alpha, beta, flags, LIBXSMM_GEMM_PREFETCH_NONE);
+    const Kernel* const kern = (nullptr != desc ? kernel_from_pointer(reinterpret_cast<const void*>(libxsmm_xmmdispatch(desc).xmm)) : nullptr);
+    if (nullptr == kern || KC_DENSE != kern->kclass) { ok = false; break; } // outside the SMM domain (alpha, beta, TRANS_A, precision)
+    const long long size = (group_size[g] < 0 ? -(long long)group_size[g] : group_size[g]);
+    const int ka = pointer_kind(a[g]), kb = pointer_kind(b[g]), kc = pointer_kind(c[g]); // (one driver query per operand)
+    if (0 == (ka & kb & kc & 1)) {
+      fprintf(stderr, "LIBXSMM-AMD ERROR: libxsmm_amd_gemm_batch_groups needs operands the GPU can reach (device memory or libxsmm_malloc)\n");
+      ok = false; break;
+    }
+    host_visible = host_visible || 0 != ((ka | kb | kc) & 2);
+    SmmBatch s = from_descriptor(kern->desc);
+    s.mode = ADDR_INDEX; s.index_base = index_base; s.index_stride = index_stride; s.a = a[g]; s.b = b[g]; s.c = c[g]; s.batch = size;
+    // any order of the sums only where the caller allows it (or LIBXSMM_AMD_BATCH_ORDER=relaxed) and never for C the CPU addresses
+    s.relaxed = ((0 != relaxed || 0 < order_env) && 0 <= order_env && 0 == (kc & 2)) ? 1 : 0;
+    s.c_atomics = (0 != (kc & 2)) ? 0 : 1;
+    if (0 < size) {
+      s.ia = device_indexes(nullptr != stride_a ? stride_a[g] : nullptr, index_stride, size, 0, &ok);
+      s.ib = device_indexes(nullptr != stride_b ? stride_b[g] : nullptr, index_stride, size, 1, &ok);
+      s.ic = device_indexes(nullptr != stride_c ? stride_c[g] : nullptr, index_stride, size, 2, &ok);
+    }
+    // how C blocks repeat inside the group: nobody cares (beta == 0, or the caller's promise of a negative size), one C for
+    // the whole group (runs), or to be found out on the device
+    if (0 != (s.flags & LIBXSMM_GEMM_FLAG_BETA_0) || group_size[g] < 0 || size < 2) s.sync = SYNC_NONE;
+    else s.sync = SYNC_DEVICE; // (stride_c == NULL -- one C for the group -- is found out on the device as well: all neighbours equal)
+    groups.push_back(s);
+  }
+  int e = -1;
+  if (ok) e = run_groups(groups);
+  index_upload_commit();
+  if (0 != e) return EXIT_FAILURE;
+  if (host_visible) (void)stream_sync(); // operands the CPU addresses directly are done with when the call returns
+  return EXIT_SUCCESS;
 }
 
 // ---- BLAS-like single GEMM (reference LIBXSMM_XGEMM, include/libxsmm_frontend.h:371-411) ---------------------------
@@ -830,6 +981,34 @@ LIBXSMM_API int libxsmm_amd_smm_kernel_source(const libxsmm_gemm_descriptor* des
   const int ip = LIBXSMM_GETENUM_INP(d.datatype);
   if (LIBXSMM_GEMM_PRECISION_F64 != ip && LIBXSMM_GEMM_PRECISION_F32 != ip) return -1;
   const std::string src = gen_smm_source(LIBXSMM_GEMM_PRECISION_F64 == ip ? 8 : 4, (int)d.m, (int)d.n, (int)d.k, d.flags, variant & 0x1F3F, (int)d.lda, (int)d.ldb, (int)d.ldc);
+  if (nullptr != buffer && 0 < buffer_size) {
+    const size_t n = (src.size() < buffer_size - 1 ? src.size() : buffer_size - 1);
+    memcpy(buffer, src.data(), n); buffer[n] = 0;
+  }
+  if (0 != compile) {
+    std::string log;
+    const int rc = jit_check_source(src, &log);
+    if (0 != rc && 0 != libxsmm_verbosity) fprintf(stderr, "LIBXSMM-AMD: hiprtc: %s\n", log.c_str());
+    return rc;
+  }
+  return (int)src.size();
+}
+
+LIBXSMM_API int libxsmm_amd_smm_grouped_kernel_source(const libxsmm_gemm_descriptor* const descriptors[], int ndescriptors, char* buffer, size_t buffer_size, int compile)
+{ // the HIP text one grouped launch (libxsmm_amd_gemm_batch_groups) of index batches with these descriptors compiles: the run
+  // forms of every shape behind one dispatcher; same buffer/compile/return conventions as libxsmm_amd_smm_kernel_source
+  if (nullptr == descriptors || ndescriptors < 1) return -1;
+  std::vector<SmmBatch> groups;
+  for (int i = 0; i < ndescriptors; ++i) {
+    if (nullptr == descriptors[i]) return -1;
+    const int ip = LIBXSMM_GETENUM_INP(descriptors[i]->datatype);
+    if (LIBXSMM_GEMM_PRECISION_F64 != ip && LIBXSMM_GEMM_PRECISION_F32 != ip) return -1;
+    SmmBatch s = from_descriptor(*descriptors[i]);
+    s.mode = ADDR_INDEX; s.batch = 1 << 20; s.sync = SYNC_DEVICE;
+    groups.push_back(s);
+  }
+  const std::string src = gen_smm_grouped_source_for(groups.data(), (int)groups.size());
+  if (src.empty()) return -1;
   if (nullptr != buffer && 0 < buffer_size) {
     const size_t n = (src.size() < buffer_size - 1 ? src.size() : buffer_size - 1);
     memcpy(buffer, src.data(), n); buffer[n] = 0;

@@ -111,6 +111,11 @@ std::string gen_smm_source(int typesize, int m, int n, int k, int flags, int var
 bool smm_jit_eligible(const SmmBatch& s);
 int launch_smm_jit(const SmmBatch& s, void* stream, const char** name); // -1: not available
 int launch_smm_jit_lowp(const SmmBatch& s, void* stream, const char** name); // 16-bit inputs on the specialised streaming form; -1: not applicable
+bool smm_jit_grouped_eligible(const SmmBatch& s);
+std::string gen_smm_grouped_source_for(const SmmBatch* groups, int ngroups);
+int launch_smm_jit_grouped(const SmmBatch* groups, int ngroups, void* stream, const char** name); // several batches, one launch; -1: not available
+int launch_c_order_check_groups(const SmmBatch* groups, int ngroups, void* stream); // one check launch for up to 32 batches (each with its devflags slot)
+int jit_launch_dyn(JitKernel* k, unsigned blocks, unsigned threads, unsigned lds_bytes, void** args, void* stream);
 
 // spmdm batch
 struct SpmdmGeom {
@@ -138,6 +143,7 @@ Device& device();
 bool device_ready();                      // probes once; false if no HIP device
 void fail_no_device(const char* what);    // prints a loud error (always) -- the product has no CPU compute path
 bool is_device_ptr(const void* p);
+int pointer_kind(const void* p);         // bit 0: the GPU reaches it; bit 1: pinned host / managed memory (the CPU addresses it as well)
 bool is_host_visible(const void* p);      // pinned host or managed memory (processed in place, but the CPU reads it directly)
 void settle(const void* p0, const void* p1 = nullptr, const void* p2 = nullptr); // wait for the stream if an operand is host-visible
 int flag_slot_set(int* slot, int equal_pairs, int decreasing_pairs); // the verdict without a check kernel (0: ok)

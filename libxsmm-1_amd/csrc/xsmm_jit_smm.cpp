@@ -14,13 +14,15 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <algorithm>
 #include <unordered_map>
+#include <vector>
 
 namespace xsmm {
 
 namespace {
 
-const char* const SMM_JIT_BODY = R"XSMM(
+const char* const SMM_JIT_PRELUDE = R"XSMM(
 #if XFLAT
 #define XGLOBAL
 #else
@@ -51,6 +53,10 @@ __device__ __forceinline__ void wave_lds_sync()
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+)XSMM";
+
+// the part that depends on the shape (macros XM, XN, XK, ...); XGROUPED: instantiated once per shape inside a namespace
+const char* const SMM_JIT_SHAPE = R"XSMM(
 // (XLOWP 1, i16 -> i32: the k pairs stay packed -- one v_dot2_i32_i16 per pair -- so the kernel's k runs over pairs)
 constexpr int M = XM, N = XN, K = (1 == XLOWP) ? (XK / 2) : XK;
 // XPACK items that follow each other in memory (tight strided batches) are handled by a wave at a time: their operands are
@@ -464,9 +470,15 @@ __device__ __forceinline__ const T* window_pick(unsigned long long v, int src)
 // keeps them in registers for the whole run, each element still receiving its products in batch order, k ascending --
 // the sequential reference's chain. A long run is a latency chain (HBM round trip per product): the depth of the register
 // ring, not the thread count, is what shortens it.
+#if XGROUPED
+__device__ __attribute__((noinline)) void xsmm_entry(const DevAddr& ad, long long batch, unsigned xbid, unsigned xgrid, T* lds)
+{
+#else
 extern "C" __global__ __launch_bounds__(256) void xsmm_smm_op(DevAddr ad, long long batch)
 {
   __shared__ __attribute__((aligned(16))) T lds[WG_NBUF * WG_BUF];
+  const unsigned xbid = blockIdx.x, xgrid = gridDim.x;
+#endif
   const int t = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
   const int tx = lane & (TGM - 1), ty = lane >> 4;
   const int ncol0 = wave * NQ + ty * TN;
@@ -478,9 +490,9 @@ extern "C" __global__ __launch_bounds__(256) void xsmm_smm_op(DevAddr ad, long l
   int buf = 0;
   // every work-group takes a contiguous range of chunks (dealt round-robin, runs of a uniform length of 128, 256, ... items
   // would put all run heads into the chunks of every 2nd, 4th, ... work-group)
-  const long long nchunks = (batch + 63) / 64, cpw = (nchunks + gridDim.x - 1) / gridDim.x;
-  const long long c_end = ((long long)(blockIdx.x + 1) * cpw < nchunks) ? (long long)(blockIdx.x + 1) * cpw : nchunks;
-  for (long long ci = (long long)blockIdx.x * cpw; ci < c_end; ++ci) {
+  const long long nchunks = (batch + 63) / 64, cpw = (nchunks + xgrid - 1) / xgrid;
+  const long long c_end = ((long long)(xbid + 1) * cpw < nchunks) ? (long long)(xbid + 1) * cpw : nchunks;
+  for (long long ci = (long long)xbid * cpw; ci < c_end; ++ci) {
     const long long chunk = ci * 64;
     unsigned long long heads; long long first, end;
     if (!chain_of_chunk(ad, chunk, lane, batch, heads, first, end)) continue; // identical in the four waves
@@ -541,16 +553,23 @@ extern "C" __global__ __launch_bounds__(256) void xsmm_smm_op(DevAddr ad, long l
   }
 }
 #else
+#if XGROUPED
+__device__ __attribute__((noinline)) void xsmm_entry(const DevAddr& ad, long long batch, unsigned xbid, unsigned xgrid, T* lds)
+{
+  if ((int)(threadIdx.x >> 6) >= XWAVES) return; // (the grouped kernel's work-groups have four waves)
+#else
 extern "C" __global__ __launch_bounds__(64 * XWAVES) void xsmm_smm_op(DevAddr ad, long long batch)
 {
   __shared__ __attribute__((aligned(16))) T lds[XWAVES * WAVE_LDS];
+  const unsigned xbid = blockIdx.x, xgrid = gridDim.x;
+#endif
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   constexpr int LPI = 64 / G;                      // lanes per item
   const int grp = lane / LPI, tx = (lane % LPI) % TGM, ty = (lane % LPI) / TGM;
   T* const As = lds + wave * WAVE_LDS;
   T* const Bs = As + AS_SIZE;
   T* const Cs = Bs + BS_SIZE;
-  const long long w = (long long)blockIdx.x * XWAVES + wave, W = (long long)gridDim.x * XWAVES;
+  const long long w = (long long)xbid * XWAVES + wave, W = (long long)xgrid * XWAVES;
 #if XRUNS
   // Consecutive items that share one C form a run (CP2K stacks, batch-reduce): the wave that owns the run's first item
   // keeps C in registers and adds the products in batch order -- what the reference's sequential loop does. Chunks of 64
@@ -915,7 +934,9 @@ std::string gen_smm_source(int typesize, int m, int n, int k, int flags, int var
   s += "#define XDEPTH " + std::to_string(smm_jit_depth(typesize, m, n, k, variant)) + "\n";  // register stages of the run forms
   s += std::string("#define XSPLIT ") + ((variant & SMM_JIT_SPLIT) ? "1" : "0") + "\n";  // relaxed order: few long runs are cut into segments (atomics)
   s += std::string("#define XHASWG ") + ((variant & SMM_JIT_HASWG) ? "1" : "0") + "\n";   // wave form: leave long runs to the work-group form
-  s += SMM_JIT_BODY;
+  s += "#define XGROUPED 0\n";
+  s += SMM_JIT_PRELUDE;
+  s += SMM_JIT_SHAPE;
   return s;
 }
 
@@ -1086,6 +1107,176 @@ static int smm_jit_pack(const SmmBatch& s, int width)
   while (1 < pack && ((size_t)pack * ((size_t)s.m * s.k + (size_t)s.k * s.n + (size_t)s.m * s.n) * s.typesize > 24576
                    || 0 == smm_jit_waves(s.typesize, s.m, s.n, s.k, s.flags, pack))) pack /= 2;
   return pack;
+}
+
+// ---- one launch for several batches (CP2K-style stacks: a batch per shape) -----------------------------------------------
+// A batch of few long runs leaves the chip nearly empty (one sequential chain per C block: 172 chains per shape in the
+// per-GPU share of BASELINE config 5), and batches issued one after the other on a stream run one after the other. Here
+// the run kernels of all batches of a call become ONE kernel: the shape-dependent part of the generated source is
+// instantiated once per (shape, form) in a namespace of its own, a dispatcher maps every work-group to its batch by its
+// index (a small table in device memory: addressing, batch size, first work-group, which body) and calls that body -- all
+// chains of all shapes are resident at the same time. Same code per shape as the single-batch kernels, same chains, same
+// bits; one verdict slot per batch (fused check kernel).
+namespace {
+struct GroupedBody { int m, n, k, flags, variant, lda, ldb, ldc; };
+inline bool operator==(const GroupedBody& a, const GroupedBody& b) { return 0 == memcmp(&a, &b, sizeof(a)); }
+
+std::string gen_smm_grouped_source(int typesize, const std::vector<GroupedBody>& bodies, int threads)
+{
+  std::string s = "// generated by libxsmm-amd (dense SMM run kernels of several shapes behind one dispatcher)\n";
+  s += std::string("typedef ") + (8 == typesize ? "double" : "float") + " T;\n#define XLOWP 0\n#define XFLAT 0\n#define XGROUPED 1\n";
+  s += SMM_JIT_PRELUDE;
+  for (size_t i = 0; i < bodies.size(); ++i) {
+    const GroupedBody& b = bodies[i];
+    s += "namespace xg" + std::to_string(i) + " {\n";
+    s += "#define XM " + std::to_string(b.m) + "\n#define XN " + std::to_string(b.n) + "\n#define XK " + std::to_string(b.k) + "\n";
+    s += std::string("#define XBETA0 ") + ((b.flags & LIBXSMM_GEMM_FLAG_BETA_0) ? "1" : "0") + "\n";
+    s += std::string("#define XTRANSB ") + ((b.flags & LIBXSMM_GEMM_FLAG_TRANS_B) ? "1" : "0") + "\n";
+    s += "#define XLDA " + std::to_string(b.lda) + "\n#define XLDB " + std::to_string(b.ldb) + "\n#define XLDC " + std::to_string(b.ldc) + "\n";
+    s += "#define XPACK 1\n";
+    s += "#define XWAVES 1\n"; // (wave bodies: a work-group is one wave, see below)
+    s += std::string("#define XSCALAR ") + ((b.variant & SMM_JIT_SCALAR) ? "1" : "0") + "\n";
+    s += std::string("#define XRUNS ") + ((b.variant & SMM_JIT_WGRUNS) ? "2" : "1") + "\n";
+    s += "#define XDEPTH " + std::to_string(smm_jit_depth(typesize, b.m, b.n, b.k, b.variant)) + "\n";
+    s += std::string("#define XSPLIT ") + ((b.variant & SMM_JIT_SPLIT) ? "1" : "0") + "\n";
+    s += std::string("#define XHASWG ") + ((b.variant & SMM_JIT_HASWG) ? "1" : "0") + "\n";
+    s += SMM_JIT_SHAPE;
+    s += "#undef XM\n#undef XN\n#undef XK\n#undef XBETA0\n#undef XTRANSB\n#undef XLDA\n#undef XLDB\n#undef XLDC\n#undef XPACK\n#undef XWAVES\n"
+         "#undef XSCALAR\n#undef XRUNS\n#undef XDEPTH\n#undef XSPLIT\n#undef XHASWG\n#undef WINDOW_AB\n}\n";
+  }
+  s += "struct GroupEntry { DevAddr ad; long long batch; unsigned block_begin, nblocks; int body, pad; };\n";
+  // Work-groups of ONE wave: a wave whose chunk holds no run head leaves at once and its slot goes to the next work-group --
+  // with four waves per work-group the slot of a whole work-group stayed taken until its longest chain was done (measured
+  // on the 27 CP2K shapes: 1.37 ms with four waves per work-group).
+  // (two waves per SIMD: the bodies are called, not inlined; without the bound the kernel is given the registers of the
+  // hungriest body plus its own -- 308 for the 27 CP2K shapes in fp64 -- and one wave per SIMD)
+  s += "extern \"C\" __global__ __launch_bounds__(" + std::to_string(threads) + ", 2) void xsmm_smm_grouped(const GroupEntry* __restrict__ tab, int nentries)\n{\n";
+  s += "  extern __shared__ __attribute__((aligned(16))) unsigned char xsmm_dyn_lds[];\n";
+  s += "  int e = 0;\n  while (e + 1 < nentries && blockIdx.x >= tab[e + 1].block_begin) ++e;\n";
+  s += "  const GroupEntry g = tab[e];\n  const unsigned bid = blockIdx.x - g.block_begin;\n  T* const lds = reinterpret_cast<T*>(xsmm_dyn_lds);\n";
+  s += "  switch (g.body) {\n";
+  for (size_t i = 0; i < bodies.size(); ++i) s += "    case " + std::to_string(i) + ": xg" + std::to_string(i) + "::xsmm_entry(g.ad, g.batch, bid, g.nblocks, lds); break;\n";
+  s += "    default: break;\n  }\n}\n";
+  return s;
+}
+
+struct GroupedKey {
+  int typesize, threads; std::vector<GroupedBody> bodies;
+  bool operator==(const GroupedKey& o) const { return typesize == o.typesize && threads == o.threads && bodies == o.bodies; }
+};
+struct GroupedKeyHash {
+  size_t operator()(const GroupedKey& k) const {
+    size_t h = (size_t)k.typesize * 1024 + (size_t)k.threads;
+    for (const GroupedBody& b : k.bodies) h = h * 1000003u + (size_t)(((b.m * 131 + b.n) * 131 + b.k) * 64 + b.variant + b.flags * 7 + b.lda + b.ldb * 3 + b.ldc * 5);
+    return h;
+  }
+};
+std::unordered_map<GroupedKey, JitKernel*, GroupedKeyHash> g_grouped_cache; // (guarded by g_smm_lock; nullptr: compilation failed)
+
+// work-groups and LDS bytes one batch needs under a run-form body (the sizing of smm_jit_launch_variant)
+void grouped_geometry(const SmmBatch& s, int variant, long long* blocks, size_t* lds)
+{
+  (void)variant;
+  *lds = smm_jit_wave_lds(s.typesize, s.m, s.n, s.k, s.flags, 1); // one wave per work-group
+  // a wave per chunk of 64 items (a wave whose chunk holds no run head leaves at once; if the verdict on the device cuts the
+  // batch into shorter segments, a wave takes several). Sized for segments of 8 -- eight times as many work-groups, most of
+  // them without work -- the 27 CP2K shapes took 0.95 ms instead of 0.6: the dispatcher, not the chains, set the pace.
+  long long b = (s.batch + 63) / 64;
+  if (b > 256 * 16) b = 256 * 16;
+  *blocks = (b < 1 ? 1 : b);
+}
+} // namespace
+
+// Can batch s be part of a grouped launch? (the run forms of the wave / work-group kernels: M, N <= 32, K <= 64)
+bool smm_jit_grouped_eligible(const SmmBatch& s)
+{
+  if (!smm_jit_eligible(s)) return false;
+  if (s.m > 32 || s.n > 32 || s.k > 64 || 0 != s.lowp) return false;
+  if (SYNC_DEVICE != s.sync) return false;
+  return 0 != smm_jit_waves(s.typesize, s.m, s.n, s.k, s.flags, 1);
+}
+
+// All batches (same precision, each with its verdict slot in devflags) in one launch. -1: not available (the caller launches
+// them one by one).
+namespace {
+struct GroupedEntry { int group, body; long long blocks; };
+struct GroupedPlan { GroupedKey key; std::vector<GroupedEntry> entries; size_t lds_max = 0; };
+// which bodies (one per shape) a set of batches needs and how many work-groups each batch gets. Only the wave form: the
+// work-group form (four waves share a product; better for a batch of large shapes on its own) as a second kernel beside
+// the first was measured slower -- 27 CP2K shapes, fp64: 1.36 ms with it (its kernel took 0.94 ms next to the wave kernel,
+// 0.32 ms alone), 1.18 ms with all chains on the wave form.
+bool grouped_plan(const SmmBatch* groups, int ngroups, bool check_eligible, GroupedPlan& plan)
+{
+  plan.key.typesize = groups[0].typesize; plan.key.threads = 64; plan.key.bodies.clear(); plan.entries.clear(); plan.lds_max = 0;
+  for (int g = 0; g < ngroups; ++g) {
+    const SmmBatch& s = groups[g];
+    if (s.typesize != groups[0].typesize || (check_eligible && !smm_jit_grouped_eligible(s))) return false;
+    const int variant = smm_jit_width_variant(s) | (0 != s.relaxed ? SMM_JIT_SPLIT : 0) | SMM_JIT_RUNS;
+    const GroupedBody body = { s.m, s.n, s.k, s.flags & (LIBXSMM_GEMM_FLAG_BETA_0 | LIBXSMM_GEMM_FLAG_TRANS_B), variant, s.lda, s.ldb, s.ldc };
+    size_t bi = 0;
+    while (bi < plan.key.bodies.size() && !(plan.key.bodies[bi] == body)) ++bi;
+    if (bi == plan.key.bodies.size()) plan.key.bodies.push_back(body);
+    GroupedEntry e; e.group = g; e.body = (int)bi; size_t lds = 0;
+    grouped_geometry(s, variant, &e.blocks, &lds);
+    if (lds > plan.lds_max) plan.lds_max = lds;
+    plan.entries.push_back(e);
+  }
+  // the work-groups of a launch start in the order of their indexes: the batches with the longest chains go first, the short
+  // ones fill the tail
+  std::stable_sort(plan.entries.begin(), plan.entries.end(), [&](const GroupedEntry& x, const GroupedEntry& y) {
+    const SmmBatch& a = groups[x.group]; const SmmBatch& b = groups[y.group];
+    return (long long)a.m * a.k + (long long)a.k * a.n + (long long)a.m * a.n > (long long)b.m * b.k + (long long)b.k * b.n + (long long)b.m * b.n;
+  });
+  return true;
+}
+
+JitKernel* grouped_kernel(const GroupedKey& key)
+{
+  std::lock_guard<std::mutex> guard(g_smm_lock);
+  auto it = g_grouped_cache.find(key);
+  if (it != g_grouped_cache.end()) return it->second;
+  std::string log;
+  JitKernel* const k = jit_compile(gen_smm_grouped_source(key.typesize, key.bodies, key.threads), "xsmm_smm_grouped", &log);
+  if (nullptr == k && 0 != verbosity()) fprintf(stderr, "LIBXSMM WARNING: grouped SMM JIT failed (%s); launching the batches one by one\n", log.c_str());
+  g_grouped_cache.emplace(key, k);
+  return k;
+}
+}
+
+// the text a grouped launch of these batches compiles (tests: valid gfx950 code without a device)
+std::string gen_smm_grouped_source_for(const SmmBatch* groups, int ngroups)
+{
+  GroupedPlan plan;
+  if (ngroups < 1 || !grouped_plan(groups, ngroups, false, plan)) return std::string();
+  return gen_smm_grouped_source(plan.key.typesize, plan.key.bodies, plan.key.threads);
+}
+
+int launch_smm_jit_grouped(const SmmBatch* groups, int ngroups, void* stream, const char** name)
+{
+  if (ngroups < 1) return -1;
+  GroupedPlan plan;
+  if (!grouped_plan(groups, ngroups, true, plan) || plan.lds_max > 65536) return -1;
+  JitKernel* const kern = grouped_kernel(plan.key);
+  if (nullptr == kern) return -1;
+  struct DevAddrH { const char* a; const char* b; char* c; const char* ia; const char* ib; const char* ic; long long sa, sb, sc; int index_base, index_stride, mode; const int* flags; };
+  struct GroupEntryH { DevAddrH ad; long long batch; unsigned block_begin, nblocks; int body, pad; };
+  *name = (8 == groups[0].typesize) ? "smm_f64_jit_shape_runs_grouped" : "smm_f32_jit_shape_runs_grouped";
+  std::vector<GroupEntryH> tab(plan.entries.size());
+  unsigned total = 0;
+  for (size_t i = 0; i < plan.entries.size(); ++i) {
+    const SmmBatch& s = groups[plan.entries[i].group];
+    GroupEntryH& t = tab[i]; memset(&t, 0, sizeof(t));
+    t.ad.a = (const char*)s.a; t.ad.b = (const char*)s.b; t.ad.c = (char*)s.c; t.ad.ia = (const char*)s.ia; t.ad.ib = (const char*)s.ib; t.ad.ic = (const char*)s.ic;
+    t.ad.sa = s.sa; t.ad.sb = s.sb; t.ad.sc = s.sc; t.ad.index_base = s.index_base; t.ad.index_stride = s.index_stride; t.ad.mode = s.mode;
+    t.ad.flags = s.devflags;
+    t.batch = s.batch; t.block_begin = total; t.nblocks = (unsigned)plan.entries[i].blocks; t.body = plan.entries[i].body;
+    total += t.nblocks;
+  }
+  void* d_tab = index_upload(tab.data(), tab.size() * sizeof(GroupEntryH));
+  if (nullptr == d_tab) return 1;
+  int nentries = (int)tab.size();
+  void* args[] = { (void*)&d_tab, &nentries };
+  return jit_launch_dyn(kern, total, (unsigned)plan.key.threads, (unsigned)plan.lds_max, args, stream);
 }
 
 // 16-bit inputs (args.lowp 1: i16 -> i32, 3: bf16 -> f32): strided batches of tightly packed items with independent C go through

@@ -129,6 +129,84 @@ class _JitForced:
             os.environ["LIBXSMM_AMD_JIT_MINBATCH"] = self.old_env
 
 
+def test_grouped_source_compiles_for_gfx950(xs):
+    """the text of a grouped launch (libxsmm_amd_gemm_batch_groups): the run forms of several shapes, each in its own
+    namespace, behind one dispatching kernel -- valid gfx950 code (no device needed)"""
+    L = xs.lib()
+    buf = C.create_string_buffer(1 << 21)
+    for prec in (xs.F64, xs.F32):
+        shapes = [(13, 13, 13), (23, 13, 32), (32, 32, 32), (5, 7, 3), (13, 13, 13)]  # (a repeated shape shares its body)
+        keep, arr = [], (C.c_void_p * len(shapes))()
+        for i, (m, n, k) in enumerate(shapes):
+            blob, d = xs.descriptor(prec, m, n, k)
+            keep.append(blob); arr[i] = C.cast(d, C.c_void_p)
+        rc = L.libxsmm_amd_smm_grouped_kernel_source(arr, len(shapes), buf, len(buf), 1)
+        if rc == -1:
+            pytest.skip("libhiprtc is not available here")
+        assert rc == 0
+        src = buf.value.decode()
+        nbodies = src.count("namespace xg")
+        assert "xsmm_smm_grouped" in src and 4 <= nbodies <= 8 and src.count("::xsmm_entry(") == nbodies
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("relaxed", [False, True])
+def test_grouped_batches_one_launch(xs, orc, torch_gpu, dtype, relaxed):
+    """libxsmm_amd_gemm_batch_groups: CP2K-style stacks of several shapes (samples/cp2k/cp2k.cpp:328-360) in one call. The
+    C-ordering check of all groups is one launch and the multiplication another; every group equals libxsmm_gemm_batch on
+    its own -- the sequential chain per C block, bit for bit (relaxed: the order of the sums is open, tolerance). Groups with
+    runs of different lengths, a group of distinct C blocks, a group with one C (stride_c NULL), an empty group, host index
+    arrays, and a group whose C blocks repeat out of order (its sums join C with atomics)."""
+    torch = torch_gpu
+    L = xs.lib()
+    prec = xs.F64 if dtype == np.float64 else xs.F32
+    rng = np.random.default_rng(77)
+    shapes = [(13, 13, 13), (23, 23, 23), (32, 32, 32), (32, 13, 23), (13, 32, 32), (5, 7, 3), (13, 13, 13), (8, 8, 8)]
+    sizes = [900, 700, 640, 811, 500, 333, 0, 600]
+    groups, keep = [], []
+    for gi, ((m, n, k), s) in enumerate(zip(shapes, sizes)):
+        a = rng.uniform(-1, 1, max(s, 1) * m * k).astype(dtype); b = rng.uniform(-1, 1, max(s, 1) * k * n).astype(dtype)
+        if gi == 4:       # every product its own C
+            cidx = np.arange(s)
+        elif gi == 5:     # one C for the whole group
+            cidx = None
+        elif gi == 7:     # C blocks repeat out of order
+            cidx = rng.integers(0, 40, s)
+        else:             # runs of ~ u consecutive products per C (cp2k.cpp:155)
+            u = max(1, int(np.sqrt(max(s, 1) * 160 / 240)))
+            cidx = np.arange(s) // u
+        nc = 1 if cidx is None else (int(cidx.max()) + 1 if s else 1)
+        c = rng.uniform(-1, 1, nc * m * n).astype(dtype)
+        sa = (rng.permutation(max(s, 1))[:s] * m * k).astype(np.int32); sb = (np.arange(s) * k * n).astype(np.int32)
+        sc = None if cidx is None else (cidx * m * n).astype(np.int32)
+        ref = c.copy()
+        if s:
+            sc_ref = sc if sc is not None else np.zeros(s, dtype=np.int32)
+            assert 0 == orc.gemm_batch_idx(orc.FMA, 0, m, n, k, m, k, m, a, b, ref, 0, sa, sb, sc_ref, s)
+        da, db, dc = (torch.from_numpy(x).cuda() for x in (a, b, c))
+        on_host = (gi % 2 == 1)  # index arrays of every other group stay in host memory
+        dsa, dsb = (x if on_host else torch.from_numpy(x).cuda() for x in (sa, sb))
+        dsc = None if sc is None else (sc if on_host else torch.from_numpy(sc).cuda())
+        groups.append((da, db, dc, dsa, dsb, dsc, ref, gi))
+        keep.append((sa, sb, sc))
+    with _JitForced(xs):
+        launches = L.libxsmm_amd_launch_count()
+        rc = xs.gemm_batch_groups(prec, shapes, [g[0] for g in groups], [g[1] for g in groups], [g[2] for g in groups],
+                                  [g[3] for g in groups], [g[4] for g in groups], [g[5] for g in groups], sizes, relaxed=relaxed)
+        assert rc == 0
+        torch.cuda.synchronize()
+        assert xs.last_kernel().endswith("_jit_shape_runs_grouped"), xs.last_kernel()
+        assert L.libxsmm_amd_launch_count() == launches + 1  # (note_launch counts the multiplication; the check is not a compute kernel)
+    for (da, db, dc, dsa, dsb, dsc, ref, gi) in groups:
+        out = dc.cpu().numpy()
+        if relaxed or gi == 7:  # segments / out-of-order repeats: atomics, any order
+            tol = (1e-12 if dtype == np.float64 else 2e-5) * max(1.0, float(np.max(np.abs(ref)))) * 16
+            assert np.max(np.abs(out.astype(np.float64) - ref.astype(np.float64))) <= tol, gi
+        else:
+            assert np.array_equal(out, ref), gi
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("shape", [(23, 23, 23), (13, 13, 13), (13, 23, 32), (32, 32, 32), (5, 7, 3)])

@@ -20,6 +20,7 @@ products = int(sys.argv[1]) if len(sys.argv) > 1 else 524288
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 7
 OMP = bool(int(sys.argv[3])) if len(sys.argv) > 3 else False
 HOST_IDX = bool(int(sys.argv[4])) if len(sys.argv) > 4 else False  # index arrays in host memory, as an unchanged caller has them
+ONLY_GROUPED = bool(int(sys.argv[5])) if len(sys.argv) > 5 else False  # stop after the one-call form (profiling runs)
 torch.cuda.set_device(0)
 g = torch.Generator(device="cuda"); g.manual_seed(1)
 L.libxsmm_amd_set_mfma(0)
@@ -69,6 +70,28 @@ def one_pass(streams):
         ev = torch.cuda.Event(); ev.record(st); main.wait_event(ev)
 
 
+# ONE call for all groups: libxsmm_amd_gemm_batch_groups (one check launch + one multiplication launch, all chains resident)
+if not HOST_IDX:
+    shapes_ = [(g_[0], g_[1], g_[2]) for g_ in groups]
+
+    def one_call():
+        assert 0 == xs.gemm_batch_groups(xs.F64, shapes_, [g_[4] for g_ in groups], [g_[5] for g_ in groups], [g_[6] for g_ in groups],
+                                         [g_[7] for g_ in groups], [g_[8] for g_ in groups], [g_[9] for g_ in groups], [g_[3] for g_ in groups], relaxed=OMP)
+    import time as _time
+    t0 = _time.perf_counter(); one_call(); torch.cuda.synchronize()
+    print("first grouped call (hiprtc unless the code object is cached on disk): %.2f s" % (_time.perf_counter() - t0))
+    times = []
+    for it in range(reps + 2):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); one_call(); e1.record(); torch.cuda.synchronize()
+        if it >= 2:
+            times.append(e0.elapsed_time(e1))
+    t = sorted(times)[len(times) // 2]
+    print("cp2k stacks%s, ONE grouped call: kernel %s  median %.3f ms (min %.3f)  %.0f GB/s (%.1f%% of 8 TB/s)  %.0f GFLOP/s"
+          % (" (relaxed)" if OMP else "", xs.last_kernel(), t, min(times), tot_bytes / t / 1e6, tot_bytes / t / 1e6 / 80.0, tot_flops / t / 1e6))
+
+if ONLY_GROUPED:
+    sys.exit(0)
 for nstreams in (0, 4, 8, 27):
     streams = [torch.cuda.Stream() for _ in range(nstreams)]
     times = []

@@ -134,6 +134,18 @@ LIBXSMM_API int libxsmm_amd_smm_kernel_source(const libxsmm_gemm_descriptor* des
  *  of every shape, each in a namespace of its own, behind one dispatching kernel. Conventions as above. */
 LIBXSMM_API int libxsmm_amd_smm_grouped_kernel_source(const libxsmm_gemm_descriptor* const descriptors[], int ndescriptors, char* buffer, size_t buffer_size, int compile);
 
+/** Run-time specialisation off the caller's path. A batch call never waits for the compiler (hiprtc: 0.3-0.5 s per kernel,
+ *  seconds for a grouped kernel of many shapes): the kernel is built on a helper thread while the call -- and the following
+ *  ones -- are served by the next best kernel (pre-compiled; the same results bit for bit), and loaded from the code-object
+ *  cache on disk when a previous process (or libxsmm_amd_jit_prebuild) has left it there. LIBXSMM_AMD_JIT_ASYNC=0 compiles
+ *  in the calling thread instead. libxsmm_amd_jit_wait blocks until the helper thread has nothing left to do (benchmarks:
+ *  after the warm-up). libxsmm_amd_jit_prebuild compiles, without needing a device, the code objects batch calls with these
+ *  descriptors may ask for (strided, index and pointer batches, shared C in batch order and relaxed; grouped != 0: also the
+ *  fused kernel of libxsmm_amd_gemm_batch_groups over all of them) into the cache directory (LIBXSMM_AMD_CACHE, default
+ *  jit_cache/ next to the library); returns the number of code objects now present, or -(number of failures). */
+LIBXSMM_API void libxsmm_amd_jit_wait(void);
+LIBXSMM_API int libxsmm_amd_jit_prebuild(const libxsmm_gemm_descriptor* const descriptors[], int ndescriptors, int grouped);
+
 /** Executable form of the sparse text kernels (libxsmm_generator_spgemm_{csr,csc}_kernel): the pattern is compiled into
  *  a kernel with hiprtc, the values of the sparse operand stay a run-time argument (as for the reference's generated C
  *  functions, samples/generator/validation.c). descriptor: lda == 0 marks A sparse, ldb == 0 marks B sparse; is_csr != 0:

@@ -80,6 +80,29 @@ def build(verbose=False):
     return LIB_PATH
 
 
+# shapes whose code objects build() leaves in lib/jit_cache (they travel with the library): the BASELINE configurations
+PREBUILD_F64 = [(m, n, k) for m in (13, 23, 32) for n in (13, 23, 32) for k in (13, 23, 32)]  # config 1 and 5 (CP2K stacks: also grouped)
+PREBUILD_F32 = [(32, 32, 32), (23, 23, 23), (13, 13, 13)]
+
+
+def prebuild_kernels(verbose=False):
+    """hiprtc ahead of time (no device needed): see libxsmm_amd_jit_prebuild"""
+    L = lib()
+    total = 0
+    for prec, shapes, grouped in ((F64, PREBUILD_F64, 1), (F32, PREBUILD_F32, 0)):
+        keep, arr = [], (C.c_void_p * len(shapes))()
+        for idx, (m, n, k) in enumerate(shapes):
+            blob, d = descriptor(prec, m, n, k)
+            keep.append(blob); arr[idx] = C.cast(d, C.c_void_p)
+        rc = L.libxsmm_amd_jit_prebuild(arr, len(shapes), grouped)
+        if verbose:
+            print("prebuild: precision %d, %d shapes -> %d" % (prec, len(shapes), rc))
+        if rc < 0:
+            raise RuntimeError("libxsmm_amd_jit_prebuild failed for %d code objects" % -rc)
+        total += rc
+    return total
+
+
 _lib = None
 
 
@@ -237,6 +260,8 @@ def _declare(L):
     sig("libxsmm_amd_device_malloc", vp, C.c_size_t)
     sig("libxsmm_amd_device_free", None, vp)
     sig("libxsmm_amd_smm_grouped_kernel_source", i, C.POINTER(vp), i, vp, C.c_size_t, i)
+    sig("libxsmm_amd_jit_prebuild", i, C.POINTER(vp), i, i)
+    sig("libxsmm_amd_jit_wait", None)
     sig("libxsmm_amd_gemm_batch_groups", i, i, i, i, C.c_char_p, C.c_char_p, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p, vp, vp,
         C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i, i, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), c_int_p, i)
 

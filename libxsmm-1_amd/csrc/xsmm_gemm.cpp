@@ -1022,6 +1022,24 @@ LIBXSMM_API int libxsmm_amd_smm_grouped_kernel_source(const libxsmm_gemm_descrip
   return (int)src.size();
 }
 
+LIBXSMM_API int libxsmm_amd_jit_prebuild(const libxsmm_gemm_descriptor* const descriptors[], int ndescriptors, int grouped)
+{ // see include/libxsmm_amd.h
+  if (nullptr == descriptors || ndescriptors < 1) return -1;
+  std::vector<SmmBatch> shapes;
+  for (int i = 0; i < ndescriptors; ++i) {
+    if (nullptr == descriptors[i]) return -1;
+    const int ip = LIBXSMM_GETENUM_INP(descriptors[i]->datatype), op = LIBXSMM_GETENUM_OUT(descriptors[i]->datatype);
+    if (ip != op || (LIBXSMM_GEMM_PRECISION_F64 != ip && LIBXSMM_GEMM_PRECISION_F32 != ip)) continue;
+    shapes.push_back(from_descriptor(*descriptors[i]));
+  }
+  if (shapes.empty()) return 0;
+  int built = 0;
+  const int failed = smm_jit_prebuild(shapes.data(), (int)shapes.size(), grouped, &built);
+  return 0 == failed ? built : -failed;
+}
+
+LIBXSMM_API void libxsmm_amd_jit_wait(void) { jit_async_wait(); }
+
 // ---- measurement aid -----------------------------------------------------------------------------------------------
 namespace xsmm { int launch_stream_abc(const void* a, const void* b, void* c, long long bytes, void* stream); }
 

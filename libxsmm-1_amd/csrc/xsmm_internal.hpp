@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <functional>
 #include <string>
 
 #include "../../include/libxsmm.h"
@@ -99,6 +100,11 @@ struct JitKernel;
 std::string gen_csr_panels_source(int typesize, int M, int K, const unsigned* rowptr, const unsigned* colidx, const double* values,
                                   int beta0, int skip_empty_rows, int vec, const char* fname);
 JitKernel* jit_compile(const std::string& src, const char* fname, std::string* log);
+JitKernel* jit_from_cache(const std::string& src, const char* fname); // only if the code-object cache on disk holds it
+int jit_build_offline(const std::string& src, std::string* log);      // compile into the cache on disk (no device needed); 0: there
+bool jit_async_enabled();                                             // LIBXSMM_AMD_JIT_ASYNC (default on)
+void jit_async(std::function<void()> job);                            // run on the compiler thread
+void jit_async_wait();                                                // until the compiler thread has nothing left to do
 int jit_check_source(const std::string& src, std::string* log);
 void jit_release(JitKernel* k);
 int jit_launch_panels(JitKernel* k, const void* B, void* C, long long ncols, long long ldb, long long ldc, int vec, void* stream);
@@ -112,6 +118,7 @@ bool smm_jit_eligible(const SmmBatch& s);
 int launch_smm_jit(const SmmBatch& s, void* stream, const char** name); // -1: not available
 int launch_smm_jit_lowp(const SmmBatch& s, void* stream, const char** name); // 16-bit inputs on the specialised streaming form; -1: not applicable
 bool smm_jit_grouped_eligible(const SmmBatch& s);
+int smm_jit_prebuild(const SmmBatch* shapes, int nshapes, int grouped, int* built); // code objects into the cache on disk; returns failures
 std::string gen_smm_grouped_source_for(const SmmBatch* groups, int ngroups);
 int launch_smm_jit_grouped(const SmmBatch* groups, int ngroups, void* stream, const char** name); // several batches, one launch; -1: not available
 int launch_c_order_check_groups(const SmmBatch* groups, int ngroups, void* stream); // one check launch for up to 32 batches (each with its devflags slot)

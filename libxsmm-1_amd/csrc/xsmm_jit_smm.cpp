@@ -861,8 +861,42 @@ struct SmmKey {
 };
 struct SmmKeyHash { size_t operator()(const SmmKey& k) const { return (size_t)(((((k.m * 131 + k.n) * 131 + k.k) * 8 + k.flags * 2 + (k.typesize == 8)) * 64 + k.variant) * 31 + k.lda * 7 + k.ldb * 3 + k.ldc); } };
 
+// A specialised kernel is absent (never asked for), being compiled on the helper thread, ready, or failed (not retried).
+struct JitSlot { int state; JitKernel* kernel; }; // state 0: compiling, 1: ready, 2: failed
 std::mutex g_smm_lock;
-std::unordered_map<SmmKey, JitKernel*, SmmKeyHash> g_smm_cache; // nullptr value: compilation failed, do not retry
+std::unordered_map<SmmKey, JitSlot, SmmKeyHash> g_smm_cache;
+
+// The kernel for `key`: from the table, else from the code-object cache on disk (milliseconds), else from the compiler -- on
+// the helper thread (nullptr now: the caller falls back to the next best kernel, a later call finds this one ready) unless
+// LIBXSMM_AMD_JIT_ASYNC=0 or `wait`.
+template<typename KEY, typename MAP, typename GEN>
+JitKernel* jit_resolve(MAP& table, const KEY& key, const char* fname, bool wait, GEN gen_source)
+{
+  {
+    std::lock_guard<std::mutex> guard(g_smm_lock);
+    auto it = table.find(key);
+    if (it != table.end()) return (1 == it->second.state) ? it->second.kernel : nullptr;
+    table.emplace(key, JitSlot{ 0, nullptr }); // this caller is in charge of it
+  }
+  const std::string src = gen_source();
+  auto publish = [&table, key](JitKernel* k) {
+    std::lock_guard<std::mutex> guard(g_smm_lock);
+    JitSlot& slot = table[key];
+    slot.kernel = k; slot.state = (nullptr != k ? 1 : 2);
+  };
+  JitKernel* k = jit_from_cache(src, fname);
+  if (nullptr != k) { publish(k); return k; }
+  auto compile = [src, fname, publish]() {
+    std::string log;
+    JitKernel* const kk = jit_compile(src, fname, &log);
+    if (nullptr == kk && 0 != verbosity()) fprintf(stderr, "LIBXSMM WARNING: SMM JIT failed (%s); using the pre-compiled kernel\n", log.c_str());
+    publish(kk);
+    return kk;
+  };
+  if (wait || !jit_async_enabled()) return compile();
+  jit_async([compile]() { (void)compile(); });
+  return nullptr;
+}
 
 } // namespace
 
@@ -983,9 +1017,11 @@ bool smm_jit_eligible(const SmmBatch& s)
     if (s.k > 64) return false;                                                // 8x8 lanes x (<=4x4) tile, whole K in LDS
     if (0 == smm_jit_waves(s.typesize, s.m, s.n, s.k, s.flags)) return false; // static LDS limit per work-group
   }
+  // (the compiler works on a helper thread and its output is kept on disk, so a modest batch is enough of a reason: below
+  // about a thousand items a launch is bound by its fixed costs whatever the kernel)
   const char* const env_min = getenv("LIBXSMM_AMD_JIT_MINBATCH");
-  const long long min_batch = (nullptr != env_min && 0 != *env_min) ? atoll(env_min) : 16384LL;
-  if (s.batch < min_batch && 0 == s.jit_always) return false;                 // compile time must be worth it
+  const long long min_batch = (nullptr != env_min && 0 != *env_min) ? atoll(env_min) : 1024LL;
+  if (s.batch < min_batch && 0 == s.jit_always) return false;
   return true;
 }
 
@@ -1014,16 +1050,10 @@ static int smm_jit_width_variant(const SmmBatch& s)
   return wide ? 0 : SMM_JIT_SCALAR;
 }
 
-static JitKernel* smm_jit_get(const SmmKey& key)
+static JitKernel* smm_jit_get(const SmmKey& key, bool wait = false)
 {
-  std::lock_guard<std::mutex> guard(g_smm_lock);
-  auto it = g_smm_cache.find(key);
-  if (it != g_smm_cache.end()) return it->second;
-  std::string log;
-  JitKernel* const k = jit_compile(gen_smm_source(key.typesize, key.m, key.n, key.k, key.flags, key.variant, key.lda, key.ldb, key.ldc), "xsmm_smm_op", &log);
-  if (nullptr == k && 0 != verbosity()) fprintf(stderr, "LIBXSMM WARNING: SMM JIT failed (%s); using the pre-compiled kernel\n", log.c_str());
-  g_smm_cache.emplace(key, k);
-  return k;
+  return jit_resolve(g_smm_cache, key, "xsmm_smm_op", wait, [&key]() {
+    return gen_smm_source(key.typesize, key.m, key.n, key.k, key.flags, key.variant, key.lda, key.ldb, key.ldc); });
 }
 
 // one launch of one flavour; -1 when the kernel is not available
@@ -1171,7 +1201,7 @@ struct GroupedKeyHash {
     return h;
   }
 };
-std::unordered_map<GroupedKey, JitKernel*, GroupedKeyHash> g_grouped_cache; // (guarded by g_smm_lock; nullptr: compilation failed)
+std::unordered_map<GroupedKey, JitSlot, GroupedKeyHash> g_grouped_cache; // (guarded by g_smm_lock)
 
 // work-groups and LDS bytes one batch needs under a run-form body (the sizing of smm_jit_launch_variant)
 void grouped_geometry(const SmmBatch& s, int variant, long long* blocks, size_t* lds)
@@ -1221,6 +1251,15 @@ bool grouped_plan(const SmmBatch* groups, int ngroups, bool check_eligible, Grou
     if (lds > plan.lds_max) plan.lds_max = lds;
     plan.entries.push_back(e);
   }
+  { // bodies in a canonical order: the same set of shapes gives the same kernel (and cache file) whatever the order of the groups
+    std::vector<size_t> order(plan.key.bodies.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](size_t x, size_t y) { return 0 > memcmp(&plan.key.bodies[x], &plan.key.bodies[y], sizeof(GroupedBody)); });
+    std::vector<GroupedBody> sorted(order.size()); std::vector<int> where(order.size());
+    for (size_t i = 0; i < order.size(); ++i) { sorted[i] = plan.key.bodies[order[i]]; where[order[i]] = (int)i; }
+    plan.key.bodies.swap(sorted);
+    for (GroupedEntry& e : plan.entries) e.body = where[(size_t)e.body];
+  }
   // the work-groups of a launch start in the order of their indexes: the batches with the longest chains go first, the short
   // ones fill the tail
   std::stable_sort(plan.entries.begin(), plan.entries.end(), [&](const GroupedEntry& x, const GroupedEntry& y) {
@@ -1232,14 +1271,7 @@ bool grouped_plan(const SmmBatch* groups, int ngroups, bool check_eligible, Grou
 
 JitKernel* grouped_kernel(const GroupedKey& key)
 {
-  std::lock_guard<std::mutex> guard(g_smm_lock);
-  auto it = g_grouped_cache.find(key);
-  if (it != g_grouped_cache.end()) return it->second;
-  std::string log;
-  JitKernel* const k = jit_compile(gen_smm_grouped_source(key.typesize, key.bodies, key.threads), "xsmm_smm_grouped", &log);
-  if (nullptr == k && 0 != verbosity()) fprintf(stderr, "LIBXSMM WARNING: grouped SMM JIT failed (%s); launching the batches one by one\n", log.c_str());
-  g_grouped_cache.emplace(key, k);
-  return k;
+  return jit_resolve(g_grouped_cache, key, "xsmm_smm_grouped", false, [&key]() { return gen_smm_grouped_source(key.typesize, key.bodies, key.threads); });
 }
 }
 
@@ -1290,7 +1322,7 @@ int launch_smm_jit_lowp(const SmmBatch& s, void* stream, const char** name)
   if (s.m > 32 || s.n > 32 || s.k > 64 || 0 != (s.k & 1) || s.lda != s.m || s.ldb != s.k || s.ldc != s.m) return -1;
   if (s.sa != (long long)s.m * s.k || s.sb != (long long)s.k * s.n || s.sc != (long long)s.m * s.n) return -1;
   const char* const env_min = getenv("LIBXSMM_AMD_JIT_MINBATCH");
-  if (s.batch < ((nullptr != env_min && 0 != *env_min) ? atoll(env_min) : 16384LL)) return -1;
+  if (s.batch < ((nullptr != env_min && 0 != *env_min) ? atoll(env_min) : 1024LL)) return -1;
   if (0 == smm_jit_waves(4, s.m, s.n, s.k, s.flags)) return -1;
   SmmBatch j = s;
   j.typesize = 4; j.lowp = 0; j.sync = SYNC_NONE;
@@ -1354,6 +1386,51 @@ int launch_smm_jit(const SmmBatch& s, void* stream, const char** name)
   int e = smm_jit_launch_variant(s, width | split | SMM_JIT_RUNS | SMM_JIT_HASWG, stream);
   if (0 == e) e = smm_jit_launch_variant(s, width | split | SMM_JIT_WGRUNS, stream);
   return e;
+}
+
+// Code objects ahead of time (no device needed): for every shape the flavours a batch call may ask for -- strided batches
+// (wide accesses, several items per wave where that is chosen), index / pointer batches (element-wide accesses: streaming,
+// run forms and their relaxed-order twins) -- and, if `grouped`, the fused kernel of all shapes for index batches. Returns
+// the number of code objects that could not be built.
+int smm_jit_prebuild(const SmmBatch* shapes, int nshapes, int grouped, int* built)
+{
+  int failed = 0, done = 0;
+  static const int wg_env = []() { const char* e = getenv("XSMM_SMMJIT_WG"); return (nullptr != e && 0 != *e) ? atoi(e) : 1; }();
+  auto build = [&](const std::string& src) { std::string log; if (src.empty()) return; if (0 == jit_build_offline(src, &log)) ++done; else { ++failed; if (0 != verbosity()) fprintf(stderr, "LIBXSMM-AMD: prebuild: %s\n", log.c_str()); } };
+  for (int i = 0; i < nshapes; ++i) {
+    SmmBatch s = shapes[i];
+    s.batch = 1 << 20; s.jit_always = 1; s.sync = SYNC_NONE;
+    if (!smm_jit_eligible(s)) continue;
+    const int flags = s.flags & (LIBXSMM_GEMM_FLAG_BETA_0 | LIBXSMM_GEMM_FLAG_TRANS_B);
+    auto one = [&](int variant) { build(gen_smm_source(s.typesize, s.m, s.n, s.k, flags, variant, s.lda, s.ldb, s.ldc)); };
+    if (s.m > 32 || s.n > 32 || s.k > 64) { one(SMM_JIT_BIG); continue; }
+    // strided batches: the wide flavour with the pack the launcher would choose, and the element-wide flavour for the remainder
+    SmmBatch t = s; t.mode = ADDR_STRIDED; t.sa = (long long)s.m * s.k; t.sb = (long long)s.k * s.n; t.sc = (long long)s.m * s.n;
+    const int pack = smm_jit_pack(t, 0);
+    one(0); if (1 < pack) one(smm_jit_pack_bits(pack));
+    one(SMM_JIT_SCALAR);
+    if (0 == (flags & LIBXSMM_GEMM_FLAG_BETA_0)) { // shared C only matters with beta == 1
+      const bool tight = (s.lda == s.m && s.ldc == s.m && (0 != (flags & LIBXSMM_GEMM_FLAG_TRANS_B) ? (s.ldb == s.n) : (s.ldb == s.k)));
+      const bool wg_fits = (tight && 0 != wg_env && smm_jit_wg_buf(s.typesize, s.m, s.n, s.k, flags) <= 65536
+                         && (2 == wg_env || (size_t)s.typesize * ((size_t)s.m * s.k + (size_t)s.k * s.n) >= 12288));
+      for (int split = 0; split <= SMM_JIT_SPLIT; split += SMM_JIT_SPLIT) {
+        one(SMM_JIT_SCALAR | split | SMM_JIT_RUNS);
+        if (wg_fits) { one(SMM_JIT_SCALAR | split | SMM_JIT_RUNS | SMM_JIT_HASWG); one(SMM_JIT_SCALAR | split | SMM_JIT_WGRUNS); }
+      }
+    }
+  }
+  if (0 != grouped && 1 < nshapes) {
+    for (int relaxed = 0; relaxed < 2; ++relaxed) {
+      std::vector<SmmBatch> g;
+      for (int i = 0; i < nshapes; ++i) {
+        SmmBatch s = shapes[i]; s.mode = ADDR_INDEX; s.batch = 1 << 20; s.sync = SYNC_DEVICE; s.relaxed = relaxed; s.jit_always = 1; s.c_atomics = 1;
+        if (smm_jit_grouped_eligible(s) && s.typesize == shapes[0].typesize) g.push_back(s);
+      }
+      if (1 < g.size()) build(gen_smm_grouped_source_for(g.data(), (int)g.size()));
+    }
+  }
+  if (nullptr != built) *built = done;
+  return failed;
 }
 
 } // namespace xsmm

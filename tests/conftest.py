@@ -11,6 +11,10 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# Tests name the kernel they expect right after the first call of a shape: compile in the calling thread (the product's default
+# is the helper thread, with the pre-compiled kernel serving meanwhile -- tests/test_jit.py::test_jit_never_blocks_a_batch_call)
+os.environ.setdefault("LIBXSMM_AMD_JIT_ASYNC", "0")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

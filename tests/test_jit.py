@@ -504,3 +504,75 @@ def test_jit_leading_dimensions_with_gaps(xs, orc, torch_gpu, dtype, shape):
         torch.cuda.synchronize()
         assert "_jit_shape_runs" in xs.last_kernel(), xs.last_kernel()
         assert np.array_equal(dc.cpu().numpy().view(np.uint8), ref.view(np.uint8))
+
+
+@pytest.mark.gpu
+def test_jit_never_blocks_a_batch_call(xs, orc, torch_gpu, tmp_path):
+    """The compiler works on a helper thread (the product's default, LIBXSMM_AMD_JIT_ASYNC unset): in a cold process with an
+    empty code-object cache no batch call waits for hiprtc -- the first calls of a new shape are served by the pre-compiled
+    kernel (same bits), after libxsmm_amd_jit_wait the specialised kernel takes over (same bits again). Also a grouped call
+    of several new shapes. Run in a child process: environment and caches of this one stay as they are."""
+    import subprocess
+    import sys
+    script = r'''
+import ctypes as C, importlib, os, sys, time
+import numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import torch
+import oracle_binding as orc
+xs = importlib.import_module("libxsmm-1_amd")
+L = xs.lib()
+torch.cuda.set_device(0)
+L.libxsmm_amd_set_mfma(0)
+rng = np.random.default_rng(1)
+def stack(m, n, k, batch):
+    a = rng.uniform(-1, 1, batch * m * k); b = rng.uniform(-1, 1, batch * k * n); c = rng.uniform(-1, 1, (batch // 7 + 1) * m * n)
+    sa = (np.arange(batch) * m * k).astype(np.int32); sb = (np.arange(batch) * k * n).astype(np.int32); sc = ((np.arange(batch) // 7) * m * n).astype(np.int32)
+    ref = c.copy(); assert 0 == orc.gemm_batch_idx(orc.FMA, 0, m, n, k, m, k, m, a, b, ref, 0, sa, sb, sc, batch)
+    return [torch.from_numpy(x).cuda() for x in (a, b, c, sa, sb, sc)] + [ref, c]
+# warm-up of the runtime itself (first kernel launch, pinned rings, verdict slots): a batch too small to be specialised
+w = stack(3, 3, 3, 100)
+xs.gemm_batch(xs.F64, "N", "N", 3, 3, 3, 1.0, w[0], 3, w[1], 3, 1.0, w[2], 3, 0, 4, w[3], w[4], w[5], 100); torch.cuda.synchronize()
+m, n, k, batch = 29, 17, 21, 20000
+d = stack(m, n, k, batch)
+t0 = time.perf_counter()
+xs.gemm_batch(xs.F64, "N", "N", m, n, k, 1.0, d[0], m, d[1], k, 1.0, d[2], m, 0, 4, d[3], d[4], d[5], batch)
+blocked = time.perf_counter() - t0
+first = xs.last_kernel()
+torch.cuda.synchronize()
+assert np.array_equal(d[2].cpu().numpy(), d[6]), "first call"
+L.libxsmm_amd_jit_wait()
+d[2].copy_(torch.from_numpy(d[7]))
+xs.gemm_batch(xs.F64, "N", "N", m, n, k, 1.0, d[0], m, d[1], k, 1.0, d[2], m, 0, 4, d[3], d[4], d[5], batch); torch.cuda.synchronize()
+second = xs.last_kernel()
+assert np.array_equal(d[2].cpu().numpy(), d[6]), "second call"
+# grouped call of three new shapes
+shapes = [(11, 19, 7), (27, 5, 30), (9, 9, 9)]
+g = [stack(mm, nn, kk, 5000) for (mm, nn, kk) in shapes]
+t0 = time.perf_counter()
+assert 0 == xs.gemm_batch_groups(xs.F64, shapes, [q[0] for q in g], [q[1] for q in g], [q[2] for q in g], [q[3] for q in g], [q[4] for q in g], [q[5] for q in g], [5000] * 3)
+gblocked = time.perf_counter() - t0
+gfirst = xs.last_kernel()
+torch.cuda.synchronize()
+for q in g: assert np.array_equal(q[2].cpu().numpy(), q[6]), "grouped, first call"
+L.libxsmm_amd_jit_wait()
+for q in g: q[2].copy_(torch.from_numpy(q[7]))
+assert 0 == xs.gemm_batch_groups(xs.F64, shapes, [q[0] for q in g], [q[1] for q in g], [q[2] for q in g], [q[3] for q in g], [q[4] for q in g], [q[5] for q in g], [5000] * 3)
+torch.cuda.synchronize()
+gsecond = xs.last_kernel()
+for q in g: assert np.array_equal(q[2].cpu().numpy(), q[6]), "grouped, second call"
+print("RESULT", blocked, first, second, gblocked, gfirst, gsecond)
+'''
+    env = dict(os.environ)
+    env.pop("LIBXSMM_AMD_JIT_ASYNC", None)
+    env.pop("LIBXSMM_AMD_JIT_MINBATCH", None)
+    env["LIBXSMM_AMD_CACHE"] = str(tmp_path / "cold_cache")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, "-c", script, root], capture_output=True, text=True, env=env, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    line = [l for l in res.stdout.splitlines() if l.startswith("RESULT")][-1].split()
+    blocked, first, second, gblocked, gfirst, gsecond = float(line[1]), line[2], line[3], float(line[4]), line[5], line[6]
+    assert blocked < 0.05 and gblocked < 0.05, (blocked, gblocked)   # no call waits for the compiler (0.3 s and more per kernel)
+    assert "generic" in first and "generic" in gfirst, (first, gfirst)
+    assert second.endswith("_jit_shape_runs") and gsecond.endswith("_jit_shape_runs_grouped"), (second, gsecond)
+    assert len(os.listdir(str(tmp_path / "cold_cache"))) >= 2     # the compiled code objects were kept for the next process

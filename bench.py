@@ -13,6 +13,15 @@ Output: ONE JSON line (rank 0) with the driver's contract fields plus
   secondary    -- spmdm CSR compute phase (BASELINE config 4 shape), fsspmdm (config 3), CP2K stacks (config 5) and 64^3 batches on this GPU.
 Multi-GPU: one process per GPU (torch.distributed over RCCL); the batch axis shards with no data-path collective
 ("weak" scaling: fixed per-GPU batch). value = work of all ranks / max-over-ranks time.
+
+--config 4 / --config 5 run the two BASELINE configurations that have an exchange step, sharded the same way (readiness
+harness for multi-GPU nodes; at N=1 they are single-GPU runs of the per-GPU shard):
+  4: spmdm fp32 M=K=64 N=48, 50 % zeros, 131072 problems per GPU: createSparseSlice + compute chunk by chunk, chunk i's C
+     all-gathered (RCCL all_gather_into_tensor) while chunk i+1 is computed; `collective_ms` = the gathers alone,
+     `compute_ms` = the kernels alone, `ms_per_step` = both, overlapped.
+  5: CP2K stacks fp64, 27 shapes, 524288 products per GPU in ONE grouped call (libxsmm_amd_gemm_batch_groups). Default
+     partition: every rank owns its C blocks (no exchange); --c5-split measures the fallback for stacks cut across
+     ranks: partial C + one fused all-reduce over all C blocks (`collective_ms`).
 """
 import argparse
 import ctypes as C
@@ -40,6 +49,9 @@ def parse():
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-items", type=int, default=131072, help="bounded CPU-baseline sample (items)")
+    ap.add_argument("--config", type=int, default=2, choices=[2, 4, 5], help="BASELINE configuration (2: the headline)")
+    ap.add_argument("--chunks", type=int, default=4, help="config 4: chunks of the per-GPU shard (gather of chunk i overlaps compute of chunk i+1)")
+    ap.add_argument("--c5-split", action="store_true", help="config 5: stacks cut across ranks: partial C + one fused all-reduce")
     return ap.parse_args()
 
 
@@ -86,6 +98,14 @@ def main():
         raise SystemExit("libxsmm.so sees no HIP device")
     L.libxsmm_amd_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream))  # events and kernels on one stream
     L.libxsmm_amd_set_mfma(args.mfma)
+    if args.config in (4, 5):
+        out = (config4 if 4 == args.config else config5)(args, torch, xs, L, dist, rank, world)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps(out))
+        return
 
     M = N = K = 32
     B = args.batch
@@ -142,11 +162,12 @@ def main():
         # HBM traffic per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, gfx950
         # correction applied) -- counters cannot be collected from inside this process, so the committed summary is used
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_summary.json")))
+            src = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_summary.json"))[-1]  # latest round
+            pmc = json.load(open(os.path.join(ROOT, "profiles", src)))
             entry = pmc.get(kernel_name)
             if entry and B == 1048576:
                 out["roofline"]["traffic"] = entry["traffic_bytes_per_launch"]
-                out["roofline"]["traffic_source"] = "profiles/r1_pmc_summary.json"
+                out["roofline"]["traffic_source"] = "profiles/" + src
         except (OSError, ValueError, KeyError):
             pass
         # measured ceiling for this traffic mix: c += a + b over the same three arrays (3 reads : 1 write, no arithmetic)
@@ -196,6 +217,9 @@ def secondary(torch, xs, L):
     _, t_comp = time_steps(torch, compute, 10, 2, None)
     k_comp = xs.last_kernel()
     nnz = float((a != 0).sum().item()) / B
+    if "|" in k_comp:  # both batch kernels are launched and the one that does not suit the density returns at once (the choice is made
+        # on the device from sampled entry counts, threshold 28 %): name the one that did the work
+        k_comp = "spmdm_compute_mfma" if 100.0 * nnz >= 28.0 * M * K else "spmdm_compute_wg_lds"
     by_create = 4.0 * M * K + 6.0 * nnz + 2.0 * (M + 1)
     by_comp = 6.0 * nnz + 2.0 * (M + 1) + 4.0 * K * N + 4.0 * M * N
     mc, mp = sum(t_create) / len(t_create) * 1e-3, sum(t_comp) / len(t_comp) * 1e-3  # averages, like the headline
@@ -208,7 +232,7 @@ def secondary(torch, xs, L):
     del a, b, c
     # config 3 shape: fsspmdm fp64 M=K=35, ~15% nnz, N=96 per item
     import numpy as np
-    M, K, N, B = 35, 35, 96, 65536
+    M, K, N, B = 35, 35, 96, 262144  # the configuration's own batch (2 x 7.05 GB)
     rng = np.random.default_rng(1)
     palette = np.array([0.25, -0.5, 0.75, 1.0, -1.25, 1.5, -2.0])
     A = np.where(rng.random((M, K)) < 0.15, palette[rng.integers(0, 7, (M, K))], 0.0)
@@ -243,40 +267,33 @@ def secondary(torch, xs, L):
         byt += s_ * 8.0 * (m * k + k * n) + nc * 16.0 * m * n  # the reference's bwsize (cp2k.cpp:156)
         flops += 2.0 * m * n * k * s_
 
-    def stacks():
-        for (m, n, k, s_, a, b, c, ia, ib, ic) in groups:
-            xs.gemm_batch(xs.F64, "N", "N", m, n, k, 1.0, a, m, b, k, 1.0, c, m, 0, 4, ia, ib, ic, s_)
+    shapes27 = [(q[0], q[1], q[2]) for q in groups]
+
+    def stacks(relaxed=False):
+        # ONE call for the 27 shape groups (sums per C block in batch order): one check launch + one fused run-kernel launch
+        assert 0 == xs.gemm_batch_groups(xs.F64, shapes27, [q[4] for q in groups], [q[5] for q in groups], [q[6] for q in groups],
+                                         [q[7] for q in groups], [q[8] for q in groups], [q[9] for q in groups], [q[3] for q in groups], relaxed=relaxed)
+    stacks(); L.libxsmm_amd_jit_wait()  # (the fused kernel comes from lib/jit_cache, or is compiled now: not while timing)
     _, t = time_steps(torch, stacks, 5, 2, None)
     mt = sum(t) / len(t) * 1e-3
-    res["cp2k_stacks_f64_27shapes"] = {"products": 27 * 19418, "kernel": xs.last_kernel(), "streams": 1, "ms": round(mt * 1e3, 4),
-                                       "hbm_gbs": round(byt / mt / 1e9, 1), "frac": round(byt / mt / 1e9 / HBM_PEAK_GBS, 4),
+    res["cp2k_stacks_f64_27shapes"] = {"products": 27 * 19418, "entry": "libxsmm_amd_gemm_batch_groups (one call, batch order)", "kernel": xs.last_kernel(),
+                                       "streams": 1, "ms": round(mt * 1e3, 4), "hbm_gbs": round(byt / mt / 1e9, 1), "frac": round(byt / mt / 1e9 / HBM_PEAK_GBS, 4),
                                        "gflops": round(flops / mt / 1e9, 1)}
-    # the same 27 calls with the shape groups (independent C arrays) spread over 8 caller streams: batch calls make no host
-    # round trip, so the groups overlap on the GPU (each group alone is a set of sequential accumulation chains)
-    main = torch.cuda.current_stream()
-    pool = [torch.cuda.Stream() for _ in range(8)]
 
-    def stacks_streams():
-        fork = torch.cuda.Event(); fork.record(main)
-        for st in pool:
-            st.wait_event(fork)
-        for gi, (m, n, k, s_, a, b, c, ia, ib, ic) in enumerate(groups):
-            L.libxsmm_amd_set_stream(C.c_void_p(pool[gi % len(pool)].cuda_stream))
-            xs.gemm_batch(xs.F64, "N", "N", m, n, k, 1.0, a, m, b, k, 1.0, c, m, 0, 4, ia, ib, ic, s_)
-        L.libxsmm_amd_set_stream(C.c_void_p(main.cuda_stream))
-        for st in pool:
-            ev = torch.cuda.Event(); ev.record(st); main.wait_event(ev)
-    _, t8 = time_steps(torch, stacks_streams, 5, 2, None)
-    m8 = sum(t8) / len(t8) * 1e-3
-    res["cp2k_stacks_f64_27shapes"]["streams8"] = {"ms": round(m8 * 1e3, 4), "hbm_gbs": round(byt / m8 / 1e9, 1), "frac": round(byt / m8 / 1e9 / HBM_PEAK_GBS, 4)}
-    # the multi-threaded entry point (libxsmm_gemm_batch_omp: the reference adds into a shared C under a lock, in no defined
-    # order), one stream: few long runs are cut into segments whose sums join C with floating-point atomics
-    def stacks_omp():
+    # the same stacks as 27 libxsmm_gemm_batch calls, one after the other on one stream (an unchanged CP2K-style caller)
+    def stacks_calls():
         for (m, n, k, s_, a, b, c, ia, ib, ic) in groups:
-            xs.gemm_batch(xs.F64, "N", "N", m, n, k, 1.0, a, m, b, k, 1.0, c, m, 0, 4, ia, ib, ic, s_, omp=True)
-    _, to = time_steps(torch, stacks_omp, 5, 2, None)
+            xs.gemm_batch(xs.F64, "N", "N", m, n, k, 1.0, a, m, b, k, 1.0, c, m, 0, 4, ia, ib, ic, s_)
+    stacks_calls(); L.libxsmm_amd_jit_wait()
+    _, tc = time_steps(torch, stacks_calls, 5, 2, None)
+    mc_ = sum(tc) / len(tc) * 1e-3
+    res["cp2k_stacks_f64_27shapes"]["call_per_shape"] = {"kernel": xs.last_kernel(), "ms": round(mc_ * 1e3, 4), "hbm_gbs": round(byt / mc_ / 1e9, 1), "frac": round(byt / mc_ / 1e9 / HBM_PEAK_GBS, 4)}
+    # order of the sums relaxed (what libxsmm_gemm_batch_omp / ?gemm_batch_omp allow: the reference adds under a lock, in no
+    # defined order): few long runs are cut into segments whose sums join C with floating-point atomics
+    stacks(True); L.libxsmm_amd_jit_wait()
+    _, to = time_steps(torch, lambda: stacks(True), 5, 2, None)
     mo = sum(to) / len(to) * 1e-3
-    res["cp2k_stacks_f64_27shapes"]["omp_entry"] = {"ms": round(mo * 1e3, 4), "hbm_gbs": round(byt / mo / 1e9, 1), "frac": round(byt / mo / 1e9 / HBM_PEAK_GBS, 4)}
+    res["cp2k_stacks_f64_27shapes"]["relaxed_order"] = {"kernel": xs.last_kernel(), "ms": round(mo * 1e3, 4), "hbm_gbs": round(byt / mo / 1e9, 1), "frac": round(byt / mo / 1e9 / HBM_PEAK_GBS, 4)}
     # the upper end of the (M,N,K) <= 64 family: strided batches of 64^3 on the matrix-core work-group kernels
     L.libxsmm_amd_set_mfma(1)
     for (name, dt, prec, ts) in (("smm_f32_64x64x64", torch.float32, xs.F32, 4), ("smm_f64_64x64x64", torch.float64, xs.F64, 8)):
@@ -297,6 +314,137 @@ def secondary(torch, xs, L):
         del a, b, c
     L.libxsmm_amd_set_mfma(old_mfma)
     return res
+
+
+def gather_ranks(value, dist, world):
+    """[value of rank 0, value of rank 1, ...]"""
+    import torch
+    if dist is None:
+        return [float(value)]
+    t = torch.zeros(world, device="cuda", dtype=torch.float64)
+    t[dist.get_rank()] = float(value)
+    dist.all_reduce(t)
+    return [float(x) for x in t.tolist()]
+
+
+def config4(args, torch, xs, L, dist, rank, world):
+    """BASELINE configs[3]: spmdm fp32 M=K=64 N=48, 50 % zeros, beta=0; the problems shard across the GPUs (no exchange while
+    computing), every rank then holds the C of all problems: the per-GPU shard goes chunk by chunk -- createSparseSlice +
+    compute on the chunk, and its C is all-gathered over xGMI while the next chunk is computed."""
+    dist_mod = importlib.import_module("libxsmm-1_amd.dist")
+    M, N, K = 64, 48, 64
+    B = min(args.batch, 131072) if args.batch != 1048576 else 131072  # per GPU: 1 048 576 problems over 8 GPUs
+    nch = max(1, args.chunks)
+    per = B // nch
+    B = per * nch
+    g = torch.Generator(device="cuda"); g.manual_seed(1 + rank)
+    a = torch.rand(B * M * K, device="cuda", generator=g) - 0.5
+    a = torch.where(torch.rand(B * M * K, device="cuda", generator=g) >= 0.5, a, torch.zeros_like(a))
+    b = torch.rand(B * K * N, device="cuda", generator=g) - 0.5
+    c = torch.zeros(B * M * N, device="cuda")
+    gathered = [torch.empty(world * per * M * N, device="cuda") for _ in range(nch)] if dist is not None else None
+    sb = L.libxsmm_amd_spmdm_batch_create(M, N, K, per)
+    assert sb
+    beta = C.c_float(0.0)
+
+    def compute_chunk(i):
+        assert 0 == L.libxsmm_amd_spmdm_batch_create_slices(sb, b"N", xs.dptr(a[i * per * M * K:]))
+        assert 0 == L.libxsmm_amd_spmdm_batch_compute(sb, b"N", xs.dptr(b[i * per * K * N:]), b"N", C.byref(beta), xs.dptr(c[i * per * M * N:]))
+
+    def local_chunk(i):
+        return c[i * per * M * N:(i + 1) * per * M * N]
+
+    def step():
+        dist_mod.gather_chunks_overlapped(nch, compute_chunk, local_chunk, lambda i: gathered[i], dist)
+
+    def compute_only():
+        for i in range(nch):
+            compute_chunk(i)
+
+    def gather_only():
+        dist_mod.gather_chunks_overlapped(nch, lambda i: None, local_chunk, lambda i: gathered[i], dist)
+    wall, per_step = time_steps(torch, step, args.steps, args.warmup, dist)
+    wall_max = dist_mod.max_over_ranks(wall, dist, "cuda")
+    _, t_comp = time_steps(torch, compute_only, max(3, args.steps // 2), 1, dist)
+    t_coll = [0.0]
+    if dist is not None:
+        _, t_coll = time_steps(torch, gather_only, max(3, args.steps // 2), 1, dist)
+    nnz = float((a != 0).sum().item()) / B
+    by_item = (4.0 * M * K + 6.0 * nnz + 2.0 * (M + 1)) + (6.0 * nnz + 2.0 * (M + 1) + 4.0 * K * N + 4.0 * M * N)  # create + compute (SURVEY 8(d))
+    ms = 1e3 * wall_max / args.steps
+    L.libxsmm_amd_spmdm_batch_destroy(sb)
+    return {
+        "metric": "spmdm fp32 64x48x64 nnz50 GFLOP/s (sparse flops, whole job)", "value": round(world * B * 2.0 * nnz * N / (wall_max / args.steps) / 1e9, 1), "unit": "GFLOP/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "configs[3]: spmdm CSR A-sparse fp32 M=K=64 N=48, 50%% zeros, beta=0, %d problems per GPU in %d chunks, createSparseSlice + compute + all-gather of C"
+                   % (B, nch), "batch_per_gpu": B, "parallelism": "batch-shard x%d, chunked all_gather_into_tensor overlapped with compute" % world},
+        "compute_ms": round(sum(t_comp) / len(t_comp), 4), "collective_ms": round(sum(t_coll) / len(t_coll), 4),
+        "ms_per_step_per_rank": [round(1e3 * w / args.steps, 4) for w in gather_ranks(wall, dist, world)],
+        "hbm_gbs_per_gpu": round(B * by_item / (sum(t_comp) / len(t_comp) * 1e-3) / 1e9, 1),
+        "gathered_bytes_per_gpu": (world - 1) * B * M * N * 4 if dist is not None else 0,
+    }
+
+
+def config5(args, torch, xs, L, dist, rank, world):
+    """BASELINE configs[4]: CP2K-style stacks, fp64, 27 shapes (M,N,K) in {13,23,32}^3, 524288 products per GPU (4M over 8), every
+    u consecutive products of a shape accumulate into one C block (samples/cp2k/cp2k.cpp:155,328-360). Every rank owns its
+    C blocks and is handed the products that update them (no exchange); --c5-split: the stacks are cut across the ranks instead
+    -- every rank sums into its own copy of all C blocks, one fused all-reduce joins them."""
+    import math
+    dist_mod = importlib.import_module("libxsmm-1_amd.dist")
+    L.libxsmm_amd_set_mfma(0)
+    products = 524288 if args.batch == 1048576 else args.batch
+    shapes = [(m, n, k) for m in (13, 23, 32) for n in (13, 23, 32) for k in (13, 23, 32)]
+    per = products // len(shapes)
+    g = torch.Generator(device="cuda"); g.manual_seed(1 + rank)
+    groups, byt, flops, csizes = [], 0.0, 0.0, []
+    for (m, n, k) in shapes:
+        s_ = per + (products - per * len(shapes) if (m, n, k) == (32, 32, 32) else 0)
+        u = max(1, math.isqrt(s_ * 160 // 240)); nc = (s_ + u - 1) // u
+        a = torch.rand(s_ * m * k, device="cuda", dtype=torch.float64, generator=g) - 0.5
+        b = torch.rand(s_ * k * n, device="cuda", dtype=torch.float64, generator=g) - 0.5
+        idx = torch.arange(s_, device="cuda", dtype=torch.int64)
+        groups.append([m, n, k, s_, a, b, None, (idx * (m * k)).to(torch.int32), (idx * (k * n)).to(torch.int32), ((idx // u) * (m * n)).to(torch.int32)])
+        csizes.append(nc * m * n)
+        byt += s_ * 8.0 * (m * k + k * n) + nc * 16.0 * m * n  # the reference's bwsize (cp2k.cpp:156)
+        flops += 2.0 * m * n * k * s_
+    # all C blocks of a rank in one array: the split fallback reduces it with ONE collective
+    call = torch.zeros(sum(csizes), device="cuda", dtype=torch.float64)
+    off = 0
+    for q, cs in zip(groups, csizes):
+        q[6] = call[off:off + cs]; off += cs
+
+    def stacks():
+        assert 0 == xs.gemm_batch_groups(xs.F64, shapes, [q[4] for q in groups], [q[5] for q in groups], [q[6] for q in groups],
+                                         [q[7] for q in groups], [q[8] for q in groups], [q[9] for q in groups], [q[3] for q in groups])
+
+    def step():
+        stacks()
+        if args.c5_split:
+            dist_mod.reduce_partial_c(call, dist)
+    stacks(); L.libxsmm_amd_jit_wait()
+    wall, per_step = time_steps(torch, step, args.steps, args.warmup, dist)
+    wall_max = dist_mod.max_over_ranks(wall, dist, "cuda")
+    kernel = xs.last_kernel()
+    _, t_comp = time_steps(torch, stacks, max(3, args.steps // 2), 1, dist)
+    t_coll = [0.0]
+    if dist is not None:
+        _, t_coll = time_steps(torch, lambda: dist_mod.reduce_partial_c(call, dist), max(3, args.steps // 2), 1, dist)
+    ms = 1e3 * wall_max / args.steps
+    return {
+        "metric": "CP2K stacks fp64 27 shapes GFLOP/s (whole job)", "value": round(world * flops / (wall_max / args.steps) / 1e9, 1), "unit": "GFLOP/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "configs[4]: CP2K-style stacks fp64, 27 shapes {13,23,32}^3, %d products per GPU, one grouped call, sums per C block in batch order; %s"
+                   % (products, "stacks cut across ranks: partial C + one fused all-reduce" if args.c5_split else "every rank owns its C blocks (no exchange)"),
+                   "products_per_gpu": products, "parallelism": "batch-shard x%d%s" % (world, ", all-reduce of %d C elements" % call.numel() if args.c5_split else "")},
+        "kernel": kernel, "compute_ms": round(sum(t_comp) / len(t_comp), 4), "collective_ms": round(sum(t_coll) / len(t_coll), 4),
+        "ms_per_step_per_rank": [round(1e3 * w / args.steps, 4) for w in gather_ranks(wall, dist, world)],
+        "hbm_gbs_per_gpu": round(byt / (sum(t_comp) / len(t_comp) * 1e-3) / 1e9, 1),
+        "roofline": {"bound": "hbm", "kernel": kernel, "achieved": round(byt / (sum(t_comp) / len(t_comp) * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(byt / (sum(t_comp) / len(t_comp) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_bytes_per_launch": byt},
+    }
 
 
 def cpu_baseline(M, N, K, items):

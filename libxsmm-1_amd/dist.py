@@ -69,6 +69,27 @@ def allgather_shards(local, n_total, dist):
     return out[:n_total * per_item]
 
 
+def gather_chunks_overlapped(nchunks, compute_chunk, local_chunk, gathered_chunk, dist):
+    """BASELINE config 4 epilogue, overlapped: a rank's shard of C is produced chunk by chunk; while chunk i + 1 is being
+    computed, chunk i is all-gathered (`gathered_chunk(i)`: world x chunk elements, `local_chunk(i)`: this rank's chunk; equal
+    chunk sizes on all ranks). With the nccl (= RCCL) backend the collective runs on RCCL's own stream behind an event of the
+    compute stream, so the xGMI transfer of one chunk hides behind the kernels of the next; per-link bound (7 x ~153 GB/s per
+    GPU), hence few large chunks. Returns when every chunk has arrived (the compute stream waits for the collectives)."""
+    works = []
+    for i in range(nchunks):
+        compute_chunk(i)
+        if dist is not None:
+            works.append(dist.all_gather_into_tensor(gathered_chunk(i), local_chunk(i), async_op=True))
+    for w in works:
+        w.wait()
+
+
+def owned_c_blocks(n_blocks, rank, world):
+    """BASELINE config 5, preferred partition: rank r owns the contiguous share shard_range(n_blocks, r, world) of the C blocks
+    of every shape group and is handed exactly the products that update them -- no exchange at all."""
+    return shard_range(n_blocks, rank, world)
+
+
 def reduce_partial_c(partial, dist):
     """Sum partial C blocks over ranks (one fused all-reduce over the concatenated block array)."""
     if dist is not None:

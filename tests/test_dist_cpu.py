@@ -57,6 +57,29 @@ def _worker(rank, world, port, tmpdir):
         orc.gemm_batch_idx(orc.FMA, 0, m, n, k, m, k, m, a, b, own, 0, sa[mine_idx], sb[mine_idx], sc[mine_idx], len(mine_idx))
     for blk in set(int(x) for x in cid[mine_idx]):
         assert np.array_equal(own[blk * m * n:(blk + 1) * m * n], ref[blk * m * n:(blk + 1) * m * n])  # bit-exact: order kept
+    # ---- config-4 epilogue as bench.py --config 4 runs it: the shard chunk by chunk, chunk i gathered while chunk i+1 is computed ----
+    nch, per_chunk = 3, 8  # equal chunks on every rank (weak scaling: every rank has its own problems)
+    rr = np.random.default_rng(100 + rank)
+    la = rr.uniform(-1, 1, nch * per_chunk * m * k); lb = rr.uniform(-1, 1, nch * per_chunk * k * n)
+    lc = torch.zeros(nch * per_chunk * m * n, dtype=torch.float64)
+    gathered = [torch.empty(world * per_chunk * m * n, dtype=torch.float64) for _ in range(nch)]
+    computed = []
+
+    def compute_chunk(i):
+        out = lc.numpy()[i * per_chunk * m * n:(i + 1) * per_chunk * m * n]
+        orc.gemm_batch_strided(orc.FMA, 16, m, n, k, m, k, m, la[i * per_chunk * m * k:], lb[i * per_chunk * k * n:], out, m * k, k * n, m * n, per_chunk)
+        computed.append(i)
+    dist_mod.gather_chunks_overlapped(nch, compute_chunk, lambda i: lc[i * per_chunk * m * n:(i + 1) * per_chunk * m * n], lambda i: gathered[i], dist)
+    assert computed == list(range(nch))
+    for i in range(nch):
+        for r2 in range(world):  # every rank's chunk i, recomputed here from that rank's seed
+            r3 = np.random.default_rng(100 + r2)
+            xa = r3.uniform(-1, 1, nch * per_chunk * m * k); xb = r3.uniform(-1, 1, nch * per_chunk * k * n)
+            want = np.zeros(per_chunk * m * n)
+            orc.gemm_batch_strided(orc.FMA, 16, m, n, k, m, k, m, xa[i * per_chunk * m * k:], xb[i * per_chunk * k * n:], want, m * k, k * n, m * n, per_chunk)
+            assert np.array_equal(gathered[i].numpy()[r2 * per_chunk * m * n:(r2 + 1) * per_chunk * m * n], want), (i, r2)
+    b0o, b1o = dist_mod.owned_c_blocks(nc, rank, world)
+    assert (b0o, b1o) == dist_mod.shard_range(nc, rank, world)
     t = dist_mod.max_over_ranks(1.0 + rank, dist)
     assert t == float(world)
     dist.barrier()

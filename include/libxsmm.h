@@ -10,7 +10,9 @@
  * Differences a caller can observe (all documented in DESIGN.md / INTEGRATION.md):
  *  - operands may be device (hipMalloc) or host pointers; device operands are processed in place and
  *    asynchronously on the engine's HIP stream (see libxsmm_amd.h), host operands are staged over PCIe.
- *  - "JIT" = selection of a pre-compiled gfx950 kernel variant; kernel pointers are host thunks.
+ *  - "JIT": hand-written gfx950 kernels for the headline shapes, and kernels generated as HIP text per descriptor and compiled
+ *    with hiprtc (on a helper thread, code objects kept on disk) for everything else up to 64 x 64 x K; a pre-compiled
+ *    kernel for any descriptor serves until then. Kernel pointers are host thunks (callable like the reference's).
  */
 #ifndef LIBXSMM_H
 #define LIBXSMM_H

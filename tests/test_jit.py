@@ -576,3 +576,34 @@ print("RESULT", blocked, first, second, gblocked, gfirst, gsecond)
     assert "generic" in first and "generic" in gfirst, (first, gfirst)
     assert second.endswith("_jit_shape_runs") and gsecond.endswith("_jit_shape_runs_grouped"), (second, gsecond)
     assert len(os.listdir(str(tmp_path / "cold_cache"))) >= 2     # the compiled code objects were kept for the next process
+
+
+@pytest.mark.gpu
+def test_process_may_exit_while_the_compiler_thread_is_busy(xs, torch_gpu, tmp_path):
+    """A short-lived process that has just handed a kernel to the compiler thread exits cleanly (the helper thread is not left
+    inside hiprtc / the HIP runtime while their static objects are torn down), and the code object it was building is on disk."""
+    import subprocess
+    import sys
+    script = r'''
+import importlib, os, sys
+sys.path.insert(0, sys.argv[1])
+import torch
+xs = importlib.import_module("libxsmm-1_amd")
+L = xs.lib()
+torch.cuda.set_device(0)
+m, n, k, batch = 19, 27, 14, 4096
+a = torch.rand(batch * m * k, device="cuda", dtype=torch.float64); b = torch.rand(batch * k * n, device="cuda", dtype=torch.float64)
+c = torch.zeros(batch * m * n, device="cuda", dtype=torch.float64)
+blob, desc = xs.descriptor(xs.F64, m, n, k)
+assert 0 == L.libxsmm_amd_gemm_batch_strided(desc, xs.dptr(a), xs.dptr(b), xs.dptr(c), m * k, k * n, m * n, batch)
+torch.cuda.synchronize()
+print("KERNEL", xs.last_kernel())
+'''
+    env = dict(os.environ)
+    env.pop("LIBXSMM_AMD_JIT_ASYNC", None)
+    env["LIBXSMM_AMD_CACHE"] = str(tmp_path / "exit_cache")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, "-c", script, root], capture_output=True, text=True, env=env, timeout=300)
+    assert res.returncode == 0, (res.returncode, res.stdout[-500:], res.stderr[-2000:])
+    assert "KERNEL smm_f64_generic" in res.stdout            # served by the pre-compiled kernel, the compiler was still busy
+    assert len(os.listdir(str(tmp_path / "exit_cache"))) >= 1  # ... and finished its job before the process was gone

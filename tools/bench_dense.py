@@ -4,6 +4,7 @@ usage: python3 tools/bench_dense.py [f64|f32|all] [reps]"""
 import importlib
 import os
 import sys
+os.environ.setdefault("LIBXSMM_AMD_JIT_ASYNC", "0")  # measurements: kernels are compiled in the calling thread (no helper-thread compile behind a timed loop)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -27,6 +28,8 @@ def run(dtype, m, n, k, mfma, beta=1.0):
     c = torch.rand(batch * m * n, device="cuda", dtype=dtype, generator=g) - 0.5
     blob, desc = xs.descriptor(xs.F64 if ts == 8 else xs.F32, m, n, k, beta=beta)
     L.libxsmm_amd_set_mfma(mfma)
+    assert 0 == L.libxsmm_amd_gemm_batch_strided(desc, xs.dptr(a), xs.dptr(b), xs.dptr(c), m * k, k * n, m * n, batch)
+    L.libxsmm_amd_jit_wait()  # the specialised kernel is compiled on a helper thread: not while timing
     times = []
     for it in range(reps + 2):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -283,374 +283,7 @@ void smm64_f32_mfma_kernel(DevAddr ad, long long batch)
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// smm_f32_mfma_wg: the same plan for any fp32 shape with 32 < max(M, N) <= 64 and K <= 64, any leading dimensions -- the
-// class the register-tiled work-group kernels serve at about half of the HBM peak. Operands travel as dwords (lanes along
-// a column: whole 128/256-byte rows of every column), both LDS images are k-major:
-//   A: word k*64 + (m ^ 32(k&1));  B (transposed while parking): word k*64 + (n ^ bkey32(k)), see below.
-// K is padded to an even count with A = -0, B = +0: the extra product is -0 and x + (-0) = x for every x, signed zeros
-// included, so the chain stays the reference's. Rows m >= M and columns n >= N of the images hold the same padding; the
-// C elements they would produce are neither loaded nor stored.
-// ---------------------------------------------------------------------------------------------------------------
-// Swizzle keys of the k-major B images: word k*64 + (n ^ key(k)). The transposing writes put 64 (fp32) resp. 64 (fp64)
-// different k of one column into one instruction, the reads the two (fp32) resp. four (fp64) k of an MFMA step with 32 resp.
-// 16 neighbouring n each. The LDS serves a dword instruction in passes of 32 lanes and a qword instruction in passes of 16
-// (measured: keys that were only distinct over the full wave showed SQ_LDS_BANK_CONFLICT), so the low bits of the key
-// follow k itself and one more bit separates the k of a step as well as the two halves of the wave.
-__device__ __forceinline__ int bkey32(int k) { return (k & 31) | ((((k >> 5) ^ k) & 1) << 5); }
-__device__ __forceinline__ int bkey64(int k) { return (k & 15) | ((((k >> 4) ^ k) & 1) << 4); }
-
-// The operands of an item are the same for the whole work-group: with the base in scalar registers a load is "scalar base
-// + one 32-bit lane offset", and the 48 loads of an item share three offset registers instead of holding 48 addresses.
-template<typename T> __device__ __forceinline__ T* wave_uniform(T* p)
-{
-  const unsigned long long v = reinterpret_cast<unsigned long long>(p);
-  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-  return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
-}
-
-template<bool BETA0, bool TIGHT>
-__global__ __launch_bounds__(256, 4)
-void smm_f32_mfma_wg_kernel(DevAddr ad, int M, int N, int K, int lda, int ldb, int ldc, long long batch, int runlen)
-{
-  __shared__ __align__(16) float As[4096];
-  __shared__ __align__(16) float Bs[4096];
-  const int t = threadIdx.x, wave = t >> 6, lane = t & 63, lo = lane & 31, hi = lane >> 5;
-  const int mq = wave & 1, nq = wave >> 1;
-  const int m = 32 * mq + lo, n = 32 * nq + lo;
-  const int ksteps = (K + 1) >> 1;
-  const bool active = (32 * mq < M) && (32 * nq < N); // the wave's quadrant holds part of C
-  // A unit is a run of `runlen` consecutive items with one C block (blocked GEMM: the k blocks of a C block); C stays in the
-  // accumulators across the run. runlen = 1: independent items.
-  const long long nunits = batch / runlen;
-  long long unit = blockIdx.x;
-  int r0 = 0; // position inside the run
-  if (unit >= nunits) return; // the whole work-group
-
-  // TIGHT (lda = M, ldb = K, M*K and K*N multiples of four): A and B of an item are contiguous arrays and travel as 16-byte
-  // chunks (chunk c = 256j + t holds elements 4c..4c+3) -- a few wide loads instead of one dword load per column; the
-  // elements are scattered into the images one by one. Rows k >= K of the images (odd K) are written once, up front.
-  float ra[16], rb[16], rc[16];
-  const int mk = M * K, kn = K * N;
-  const float rcpm = 1.0f / (float)M, rcpk = 1.0f / (float)K;
-  if (TIGHT && 0 != (K & 1)) { As[K * 64 + (t & 63)] = -0.f; Bs[K * 64 + (t & 63)] = 0.f; }
-  const unsigned offa = (unsigned)(wave * lda + lane), offb = (unsigned)(wave * ldb + lane);
-  const unsigned offc = (unsigned)((32 * nq + 4 * hi) * ldc + m);
-  auto load_ab = [&](long long it) {
-    const float* const pa = wave_uniform(addr_a<float>(ad, it));
-    const float* const pb = wave_uniform(addr_b<float>(ad, it));
-    if (TIGHT) {
-      const bool ala = aligned16(pa), alb = aligned16(pb);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int e = 4 * (256 * j + t);
-        if (e < mk) { const f32x4 v = ld4<true, true>(pa + e, ala); ra[4 * j] = v[0]; ra[4 * j + 1] = v[1]; ra[4 * j + 2] = v[2]; ra[4 * j + 3] = v[3]; }
-        if (e < kn) { const f32x4 v = ld4<true, true>(pb + e, alb); rb[4 * j] = v[0]; rb[4 * j + 1] = v[1]; rb[4 * j + 2] = v[2]; rb[4 * j + 3] = v[3]; }
-      }
-      return;
-    }
-#pragma unroll
-    for (int j = 0; j < 16; ++j) { // element (row = lane, column = 4j + wave) of the 64x64 frame
-      const int col = 4 * j + wave;
-      ra[j] = (lane < M && col < K) ? ld1<true, true>(pa + (size_t)(4 * j) * lda + offa) : -0.f;
-      rb[j] = (lane < K && col < N) ? ld1<true, true>(pb + (size_t)(4 * j) * ldb + offb) : 0.f;
-    }
-  };
-  auto load_c = [&](const float* pc0) {
-    const float* const pc = wave_uniform(pc0);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int nr = (r & 3) + 8 * (r >> 2);
-      rc[r] = (m < M && 32 * nq + 4 * hi + nr < N) ? ld1<true, true>(pc + (size_t)nr * ldc + offc) : 0.f;
-    }
-  };
-  load_ab(unit * runlen);
-  if (!BETA0 && active) load_c(addr_c<float>(ad, unit * runlen));
-  f32x16 acc;
-  for (;;) {
-    const long long item = unit * runlen + r0;
-    if (TIGHT) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int e = 4 * (256 * j + t) + u;
-          if (e < mk) { const int col = (int)(((float)e + 0.5f) * rcpm), row = e - col * M; As[col * 64 + (row ^ ((col & 1) << 5))] = ra[4 * j + u]; } // A[m = row][k = col]
-          if (e < kn) { const int col = (int)(((float)e + 0.5f) * rcpk), row = e - col * K; Bs[row * 64 + (col ^ bkey32(row))] = rb[4 * j + u]; }       // B[k = row][n = col]
-        }
-      }
-    }
-    else
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const int col = 4 * j + wave;
-      As[col * 64 + (lane ^ ((col & 1) << 5))] = ra[j];                         // A[m = lane][k = col]
-      Bs[lane * 64 + (col ^ bkey32(lane))] = rb[j];                               // B[k = lane][n = col]
-    }
-    if (0 == r0) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = BETA0 ? 0.f : rc[r];
-    }
-    int r1 = r0 + 1; long long unit1 = unit;
-    if (r1 == runlen) { r1 = 0; unit1 += gridDim.x; }
-    const bool more = unit1 < nunits;
-    if (more) {
-      load_ab(unit1 * runlen + r1);
-      if (!BETA0 && active && 0 == r1) load_c(addr_c<float>(ad, unit1 * runlen));
-    }
-    __syncthreads();
-    if (active) {
-      for (int s = 0; s < ksteps; ++s) {
-        const int k = 2 * s + hi;
-        const float av = As[k * 64 + (m ^ (hi << 5))];       // A[m][k]
-        const float bv = Bs[k * 64 + (n ^ bkey32(k))];       // B[k][n]
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bv, av, acc, 0, 0, 0);
-      }
-      if (r0 + 1 == runlen) {
-        float* const pc = wave_uniform(addr_c<float>(ad, item));
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int nr = (r & 3) + 8 * (r >> 2);
-          if (m < M && 32 * nq + 4 * hi + nr < N) st1<true, true>(pc + (size_t)nr * ldc + offc, acc[r]);
-        }
-      }
-    }
-    __syncthreads(); // all reads of the images are done before the next item is parked
-    if (!more) break;
-    unit = unit1; r0 = r1;
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// smm_f64_mfma_wg: the fp64 member: v_mfma_f64_16x16x4_f64 (probed to be the k-ordered fma chain bit for bit,
-// tools/probe/mfma_f64_chain.hip), 2x2 tiles of 16x16 per wave, step s feeds k = 4s + q (q = lane >> 4); B is the first
-// operand, so register r of lane (i, q) is C[n = q + 4r][m = i] of a tile: 128-byte rows. Images k-major, only the
-// 4*ceil(K/4) rows in use are allocated (dynamic LDS: 1 KiB per k), so shorter K leave room for a third work-group per CU:
-//   A: word k*64 + (m ^ 16(k&1));  B: word k*64 + (n ^ bkey64(k))
-// K is padded to a multiple of four with A = -0, B = +0 (see above).
-// ---------------------------------------------------------------------------------------------------------------
-template<bool BETA0>
-__global__ __launch_bounds__(256, 3)
-void smm_f64_mfma_wg_kernel(DevAddr ad, int M, int N, int K, int lda, int ldb, int ldc, long long batch, int runlen)
-{
-  extern __shared__ __align__(16) double lds64[];
-  const int t = threadIdx.x, wave = t >> 6, lane = t & 63, i = lane & 15, q = lane >> 4;
-  const int mq = wave & 1, nq = wave >> 1;
-  const int ksteps = (K + 3) >> 2, kp = 4 * ksteps;
-  double* const As = lds64;
-  double* const Bs = lds64 + kp * 64;
-  const int m0 = 32 * mq + i, n0 = 32 * nq + i;
-  const bool tm1 = (32 * mq + 16 < M), tn1 = (32 * nq + 16 < N);
-  const bool active = (32 * mq < M) && (32 * nq < N); // the wave's quadrant holds part of C
-  // A unit is a run of `runlen` consecutive items with one C block (blocked GEMM: the k blocks of a C block); C stays in the
-  // accumulators across the run. runlen = 1: independent items.
-  const long long nunits = batch / runlen;
-  long long unit = blockIdx.x;
-  int r0 = 0; // position inside the run
-  if (unit >= nunits) return; // the whole work-group
-
-  double ra[16], rb[16], rc[16];
-  const unsigned offa = (unsigned)(wave * lda + lane), offb = (unsigned)(wave * ldb + lane);
-  const unsigned offc = (unsigned)((32 * nq + q) * ldc + m0);
-  typedef const __attribute__((address_space(1))) double* gcptr;
-  typedef __attribute__((address_space(1))) double* gptr;
-  auto load_ab = [&](long long it) {
-    const double* const pa = wave_uniform(addr_a<double>(ad, it));
-    const double* const pb = wave_uniform(addr_b<double>(ad, it));
-#pragma unroll
-    for (int j = 0; j < 16; ++j) { // element (row = lane, column = 4j + wave) of the 64x64 frame
-      const int col = 4 * j + wave;
-      ra[j] = (lane < M && col < K) ? __builtin_nontemporal_load((gcptr)(pa + (size_t)(4 * j) * lda + offa)) : -0.0;
-      rb[j] = (lane < K && col < N) ? __builtin_nontemporal_load((gcptr)(pb + (size_t)(4 * j) * ldb + offb)) : 0.0;
-    }
-  };
-  // C element e = 8 tn + 4 tm + r: n = 32 nq + 16 tn + q + 4r, m = 32 mq + 16 tm + i
-  auto load_c = [&](const double* pc0) {
-    const double* const pc = wave_uniform(pc0);
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int nr = 16 * (e >> 3) + 4 * (e & 3), mr = 16 * ((e >> 2) & 1);
-      rc[e] = (m0 + mr < M && 32 * nq + q + nr < N) ? __builtin_nontemporal_load((gcptr)(pc + (size_t)nr * ldc + mr + offc)) : 0.0;
-    }
-  };
-  load_ab(unit * runlen);
-  if (!BETA0 && active) load_c(addr_c<double>(ad, unit * runlen));
-  f64x4 acc[2][2]; // [tn][tm]
-  for (;;) {
-    const long long item = unit * runlen + r0;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const int col = 4 * j + wave;
-      if (col < kp) As[col * 64 + (lane ^ ((col & 1) << 4))] = ra[j];                                      // A[m = lane][k = col]
-      if (lane < kp) Bs[lane * 64 + (col ^ bkey64(lane))] = rb[j];                                         // B[k = lane][n = col]
-    }
-    if (0 == r0) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[e >> 3][(e >> 2) & 1][e & 3] = BETA0 ? 0.0 : rc[e];
-    }
-    int r1 = r0 + 1; long long unit1 = unit;
-    if (r1 == runlen) { r1 = 0; unit1 += gridDim.x; }
-    const bool more = unit1 < nunits;
-    if (more) {
-      load_ab(unit1 * runlen + r1);
-      if (!BETA0 && active && 0 == r1) load_c(addr_c<double>(ad, unit1 * runlen));
-    }
-    __syncthreads();
-    if (active) {
-      for (int s = 0; s < ksteps; ++s) {
-        const int k = 4 * s + q, sa = (q & 1) << 4, sb = bkey64(k);
-        const double a0 = As[k * 64 + (m0 ^ sa)], b0 = Bs[k * 64 + (n0 ^ sb)];
-        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, a0, acc[0][0], 0, 0, 0);
-        if (tm1) {
-          const double a1 = As[k * 64 + ((m0 + 16) ^ sa)];
-          acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, a1, acc[0][1], 0, 0, 0);
-          if (tn1) {
-            const double b1 = Bs[k * 64 + ((n0 + 16) ^ sb)];
-            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a1, acc[1][1], 0, 0, 0);
-          }
-        }
-        else if (tn1) {
-          const double b1 = Bs[k * 64 + ((n0 + 16) ^ sb)];
-          acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a0, acc[1][0], 0, 0, 0);
-        }
-      }
-      if (r0 + 1 == runlen) {
-        double* const pc = wave_uniform(addr_c<double>(ad, item));
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int nr = 16 * (e >> 3) + 4 * (e & 3), mr = 16 * ((e >> 2) & 1);
-          if (m0 + mr < M && 32 * nq + q + nr < N) __builtin_nontemporal_store(acc[e >> 3][(e >> 2) & 1][e & 3], (gptr)(pc + (size_t)nr * ldc + mr + offc));
-        }
-      }
-    }
-    __syncthreads(); // all reads of the images are done before the next item is parked
-    if (!more) break;
-    unit = unit1; r0 = r1;
-  }
-}
-
-// Two-stage form for K > 32: the images hold 32 k at a time (32 KiB per work-group, so three work-groups fit a CU where the
-// one-stage form has room for two); the halves of A and B are parked and consumed one after the other, and the registers of a
-// half are refilled with the next item's as soon as they are parked. B is loaded k-fastest (32 consecutive k of a column per
-// half wave) so that a register belongs to one half.
-template<bool BETA0>
-__global__ __launch_bounds__(256, 3)
-void smm_f64_mfma_wg2_kernel(DevAddr ad, int M, int N, int K, int lda, int ldb, int ldc, long long batch, int runlen)
-{
-  extern __shared__ __align__(16) double lds64[];
-  const int t = threadIdx.x, wave = t >> 6, lane = t & 63, i = lane & 15, q = lane >> 4;
-  const int mq = wave & 1, nq = wave >> 1;
-  const int ksteps = (K + 3) >> 2, kp = 4 * ksteps;
-  double* const As = lds64;
-  double* const Bs = lds64 + 32 * 64;
-  const int m0 = 32 * mq + i, n0 = 32 * nq + i;
-  const bool tm1 = (32 * mq + 16 < M), tn1 = (32 * nq + 16 < N);
-  const bool active = (32 * mq < M) && (32 * nq < N); // the wave's quadrant holds part of C
-  // A unit is a run of `runlen` consecutive items with one C block (blocked GEMM: the k blocks of a C block); C stays in the
-  // accumulators across the run. runlen = 1: independent items.
-  const long long nunits = batch / runlen;
-  long long unit = blockIdx.x;
-  int r0 = 0; // position inside the run
-  if (unit >= nunits) return; // the whole work-group
-
-  double ra[16], rb[16], rc[16];
-  const int kk = t & 31, nb = t >> 5; // B: row within a half, first column
-  const unsigned offa = (unsigned)(wave * lda + lane), offb = (unsigned)(nb * ldb + kk);
-  const unsigned offc = (unsigned)((32 * nq + q) * ldc + m0);
-  typedef const __attribute__((address_space(1))) double* gcptr;
-  typedef __attribute__((address_space(1))) double* gptr;
-  auto load_half = [&](long long it, int h) {
-    const double* const pa = wave_uniform(addr_a<double>(ad, it));
-    const double* const pb = wave_uniform(addr_b<double>(ad, it));
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int col = 32 * h + 4 * j + wave; // A[m = lane][k = col]
-      const double va = (lane < M && col < K) ? __builtin_nontemporal_load((gcptr)(pa + (size_t)(32 * h + 4 * j) * lda + offa)) : -0.0;
-      const int n = nb + 8 * j;              // B[k = 32h + kk][n]
-      const double vb = (32 * h + kk < K && n < N) ? __builtin_nontemporal_load((gcptr)(pb + (size_t)(8 * j) * ldb + 32 * h + offb)) : 0.0;
-      if (0 == h) { ra[j] = va; rb[j] = vb; } else { ra[8 + j] = va; rb[8 + j] = vb; }
-    }
-  };
-  auto park_half = [&](int h) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int col = 4 * j + wave, k = 32 * h + kk; // local row of A, global k of B
-      if (32 * h + col < kp) As[col * 64 + (lane ^ ((col & 1) << 4))] = (0 == h) ? ra[j] : ra[8 + j];
-      if (k < kp) Bs[kk * 64 + ((nb + 8 * j) ^ bkey64(k))] = (0 == h) ? rb[j] : rb[8 + j];
-    }
-  };
-  auto compute_half = [&](int h, f64x4 (&acc)[2][2]) {
-    const int s1 = (ksteps < 8 * h + 8) ? ksteps : 8 * h + 8;
-    for (int s = 8 * h; s < s1; ++s) {
-      const int k = 4 * s + q, kl = k - 32 * h, sa = (q & 1) << 4, sb = bkey64(k);
-      const double a0 = As[kl * 64 + (m0 ^ sa)], b0 = Bs[kl * 64 + (n0 ^ sb)];
-      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, a0, acc[0][0], 0, 0, 0);
-      if (tm1) {
-        const double a1 = As[kl * 64 + ((m0 + 16) ^ sa)];
-        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, a1, acc[0][1], 0, 0, 0);
-        if (tn1) {
-          const double b1 = Bs[kl * 64 + ((n0 + 16) ^ sb)];
-          acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a0, acc[1][0], 0, 0, 0);
-          acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a1, acc[1][1], 0, 0, 0);
-        }
-      }
-      else if (tn1) {
-        const double b1 = Bs[kl * 64 + ((n0 + 16) ^ sb)];
-        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a0, acc[1][0], 0, 0, 0);
-      }
-    }
-  };
-  // C element e = 8 tn + 4 tm + r: n = 32 nq + 16 tn + q + 4r, m = 32 mq + 16 tm + i
-  auto load_c = [&](const double* pc0) {
-    const double* const pc = wave_uniform(pc0);
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int nr = 16 * (e >> 3) + 4 * (e & 3), mr = 16 * ((e >> 2) & 1);
-      rc[e] = (m0 + mr < M && 32 * nq + q + nr < N) ? __builtin_nontemporal_load((gcptr)(pc + (size_t)nr * ldc + mr + offc)) : 0.0;
-    }
-  };
-  load_half(unit * runlen, 0);
-  load_half(unit * runlen, 1);
-  if (!BETA0 && active) load_c(addr_c<double>(ad, unit * runlen));
-  f64x4 acc[2][2]; // [tn][tm]
-  for (;;) {
-    const long long item = unit * runlen + r0;
-    int r1 = r0 + 1; long long unit1 = unit;
-    if (r1 == runlen) { r1 = 0; unit1 += gridDim.x; }
-    const bool more = unit1 < nunits;
-    const long long next = unit1 * runlen + r1;
-    park_half(0);
-    if (0 == r0) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[e >> 3][(e >> 2) & 1][e & 3] = BETA0 ? 0.0 : rc[e];
-    }
-    if (more) load_half(next, 0);
-    __syncthreads();
-    if (active) compute_half(0, acc);
-    __syncthreads(); // the first half has been read
-    park_half(1);
-    if (more) {
-      load_half(next, 1);
-      if (!BETA0 && active && 0 == r1) load_c(addr_c<double>(ad, unit1 * runlen));
-    }
-    __syncthreads();
-    if (active) {
-      compute_half(1, acc);
-      if (r0 + 1 == runlen) {
-        double* const pc = wave_uniform(addr_c<double>(ad, item));
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int nr = 16 * (e >> 3) + 4 * (e & 3), mr = 16 * ((e >> 2) & 1);
-          if (m0 + mr < M && 32 * nq + q + nr < N) __builtin_nontemporal_store(acc[e >> 3][(e >> 2) & 1][e & 3], (gptr)(pc + (size_t)nr * ldc + mr + offc));
-        }
-      }
-    }
-    __syncthreads(); // all reads of the images are done before the next item is parked
-    if (!more) break;
-    unit = unit1; r0 = r1;
-  }
-}
+#include "smm_mfma_wg.inc"
 
 // c[i] = a[i] + b[i] + c[i] in whole 4 KiB items per wave with the same prefetch structure as the SMM kernels: the
 // traffic mix of a beta=1 SMM batch (3 reads : 1 write) without arithmetic or LDS -- the measured ceiling the SMM
@@ -778,7 +411,9 @@ int launch_smm_special(const SmmBatch& s, void* stream, const char** name)
   if (4 == s.typesize && (32 < s.m || 32 < s.n) && s.m <= 64 && s.n <= 64 && 0 < s.k && s.k <= 64 && s.lda >= s.m && s.ldb >= s.k && s.ldc >= s.m
     && 0 == (s.flags & LIBXSMM_GEMM_FLAG_TRANS_B) && mfma_wg_units(s) > 0 && 0 == s.general && 0 != s.use_mfma && 0 != env_int("XSMM_SMM64_MFMA", 1))
   {
-    const int bpc = env_int("XSMM_SMM64_BPC", 4);
+    // C as a contiguous array through LDS when its columns are not whole 128-byte lines (see kernels/smm_mfma_wg.inc)
+    const bool tightc = s.ldc == s.m && 0 == ((s.m * s.n) & 3) && 0 != (s.m & 31) && 0 != env_int("XSMM_SMM64_TIGHTC", 1);
+    const int bpc = env_int("XSMM_SMM64_BPC", tightc ? 3 : 4); // (48 KiB of LDS with the C image)
     long long blocks = mfma_wg_units(s);
     const long long resident = 256LL * (bpc > 0 ? bpc : 4);
     if (blocks > resident) blocks = resident;
@@ -788,14 +423,10 @@ int launch_smm_special(const SmmBatch& s, void* stream, const char** name)
     *name = (1 == runlen) ? "smm_f32_mfma_wg" : "smm_f32_mfma_wg_runs";
     const bool beta0 = 0 != (s.flags & LIBXSMM_GEMM_FLAG_BETA_0);
     const bool tight = s.lda == s.m && s.ldb == s.k && 0 == ((s.m * s.k) & 3) && 0 == ((s.k * s.n) & 3) && 0 != env_int("XSMM_SMM64_WIDE", 1);
-    if (tight) {
-      if (beta0) hipLaunchKernelGGL((smm_f32_mfma_wg_kernel<true, true>), dim3((unsigned)blocks), dim3(256), 0, st, ad, s.m, s.n, s.k, s.lda, s.ldb, s.ldc, s.batch, runlen);
-      else hipLaunchKernelGGL((smm_f32_mfma_wg_kernel<false, true>), dim3((unsigned)blocks), dim3(256), 0, st, ad, s.m, s.n, s.k, s.lda, s.ldb, s.ldc, s.batch, runlen);
-    }
-    else {
-      if (beta0) hipLaunchKernelGGL((smm_f32_mfma_wg_kernel<true, false>), dim3((unsigned)blocks), dim3(256), 0, st, ad, s.m, s.n, s.k, s.lda, s.ldb, s.ldc, s.batch, runlen);
-      else hipLaunchKernelGGL((smm_f32_mfma_wg_kernel<false, false>), dim3((unsigned)blocks), dim3(256), 0, st, ad, s.m, s.n, s.k, s.lda, s.ldb, s.ldc, s.batch, runlen);
-    }
+#define XSMM_MW(B0, TI, TC) hipLaunchKernelGGL((smm_f32_mfma_wg_kernel<B0, TI, TC>), dim3((unsigned)blocks), dim3(256), 0, st, ad, s.m, s.n, s.k, s.lda, s.ldb, s.ldc, s.batch, runlen)
+    if (tightc) { if (tight) { if (beta0) XSMM_MW(true, true, true); else XSMM_MW(false, true, true); } else { if (beta0) XSMM_MW(true, false, true); else XSMM_MW(false, false, true); } }
+    else { if (tight) { if (beta0) XSMM_MW(true, true, false); else XSMM_MW(false, true, false); } else { if (beta0) XSMM_MW(true, false, false); else XSMM_MW(false, false, false); } }
+#undef XSMM_MW
     return (int)hipGetLastError();
   }
   if (8 == s.typesize && (32 < s.m || 32 < s.n) && s.m <= 64 && s.n <= 64 && 0 < s.k && s.k <= 64 && s.lda >= s.m && s.ldb >= s.k && s.ldc >= s.m

@@ -28,7 +28,8 @@ int run_smm(const SmmBatch& s)
 {
   const char* name = "";
   int e = -1;
-  if (0 == s.general) e = launch_smm_special(s, device().stream, &name);            // hand-tuned shapes
+  if (0 == s.general && (32 < s.m || 32 < s.n)) e = launch_smm_jit_mfma(s, device().stream, &name); // matrix-core work-group kernel of this very descriptor
+  if (e < 0 && 0 == s.general) e = launch_smm_special(s, device().stream, &name);  // hand-tuned shapes; the same kernels for any descriptor
   if (e < 0 && smm_jit_eligible(s)) {                                               // shape-specialised via hiprtc
     e = launch_smm_jit(s, device().stream, &name); // (SYNC_DEVICE: whatever the verdict on the device, one of its kernels works)
   }
@@ -980,7 +981,7 @@ LIBXSMM_API int libxsmm_amd_smm_kernel_source(const libxsmm_gemm_descriptor* des
   const libxsmm_gemm_descriptor& d = *descriptor;
   const int ip = LIBXSMM_GETENUM_INP(d.datatype);
   if (LIBXSMM_GEMM_PRECISION_F64 != ip && LIBXSMM_GEMM_PRECISION_F32 != ip) return -1;
-  const std::string src = gen_smm_source(LIBXSMM_GEMM_PRECISION_F64 == ip ? 8 : 4, (int)d.m, (int)d.n, (int)d.k, d.flags, variant & 0x1F3F, (int)d.lda, (int)d.ldb, (int)d.ldc);
+  const std::string src = gen_smm_source(LIBXSMM_GEMM_PRECISION_F64 == ip ? 8 : 4, (int)d.m, (int)d.n, (int)d.k, d.flags, variant & 0x3FFF, (int)d.lda, (int)d.ldb, (int)d.ldc);
   if (nullptr != buffer && 0 < buffer_size) {
     const size_t n = (src.size() < buffer_size - 1 ? src.size() : buffer_size - 1);
     memcpy(buffer, src.data(), n); buffer[n] = 0;

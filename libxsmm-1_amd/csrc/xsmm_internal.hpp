@@ -112,10 +112,12 @@ int jit_blocks_per_cu(JitKernel* k, int threads); // occupancy of a generated ke
 int jit_launch_args(JitKernel* k, unsigned blocks, unsigned threads, void** args, void* stream);
 int jit_launch_raw(JitKernel* k, unsigned blocks, unsigned threads, void* arg0, size_t arg0_size, void* arg1, void* stream);
 // dense SMM kernels specialised per shape (xsmm_jit_smm.cpp)
-enum { SMM_JIT_SCALAR = 1, SMM_JIT_RUNS = 2, SMM_JIT_WGRUNS = 4, SMM_JIT_HASWG = 8, SMM_JIT_BIG = 16, SMM_JIT_SPLIT = 32 }; // variant bits of the generated dense kernel
+enum { SMM_JIT_SCALAR = 1, SMM_JIT_RUNS = 2, SMM_JIT_WGRUNS = 4, SMM_JIT_HASWG = 8, SMM_JIT_BIG = 16, SMM_JIT_SPLIT = 32,
+       SMM_JIT_MFMA = 64 /* matrix-core work-group kernel (kernels/smm_mfma_wg.inc) with the shape baked in; + 128: tight fp32 operands as 16-byte chunks */, SMM_JIT_MFMA_TIGHT = 128, SMM_JIT_MFMA_TIGHTC = 8192 /* fp32: C as a contiguous array through LDS */ }; // variant bits of the generated dense kernel
 std::string gen_smm_source(int typesize, int m, int n, int k, int flags, int variant, int lda = 0, int ldb = 0, int ldc = 0); // (0: tight)
 bool smm_jit_eligible(const SmmBatch& s);
 int launch_smm_jit(const SmmBatch& s, void* stream, const char** name); // -1: not available
+int launch_smm_jit_mfma(const SmmBatch& s, void* stream, const char** name); // matrix-core work-group kernels specialised per descriptor; -1: not available
 int launch_smm_jit_lowp(const SmmBatch& s, void* stream, const char** name); // 16-bit inputs on the specialised streaming form; -1: not applicable
 bool smm_jit_grouped_eligible(const SmmBatch& s);
 int smm_jit_prebuild(const SmmBatch* shapes, int nshapes, int grouped, int* built); // code objects into the cache on disk; returns failures

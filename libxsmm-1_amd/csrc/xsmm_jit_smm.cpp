@@ -20,6 +20,8 @@
 
 namespace xsmm {
 
+extern const char* const SMM_MFMA_WG_SOURCE; // kernels/smm_mfma_wg.inc as text (Makefile)
+
 namespace {
 
 const char* const SMM_JIT_PRELUDE = R"XSMM(
@@ -947,6 +949,16 @@ std::string gen_smm_source(int typesize, int m, int n, int k, int flags, int var
   s += "#define XM " + std::to_string(m) + "\n#define XN " + std::to_string(n) + "\n#define XK " + std::to_string(k) + "\n";
   s += std::string("#define XBETA0 ") + ((flags & LIBXSMM_GEMM_FLAG_BETA_0) ? "1" : "0") + "\n";
   s += std::string("#define XTRANSB ") + ((flags & LIBXSMM_GEMM_FLAG_TRANS_B) ? "1" : "0") + "\n";
+  if (0 != (variant & SMM_JIT_MFMA)) { // matrix-core work-group kernel, shape and leading dimensions baked in
+    s += "#define XFLAT 0\n#define XMW_JIT 1\n";
+    s += "#define XLDA " + std::to_string(lda) + "\n#define XLDB " + std::to_string(ldb) + "\n#define XLDC " + std::to_string(ldc) + "\n";
+    s += std::string("#define XTIGHT ") + ((variant & SMM_JIT_MFMA_TIGHT) ? "1" : "0") + "\n";
+    s += std::string("#define XTIGHTC ") + ((variant & SMM_JIT_MFMA_TIGHTC) ? "1" : "0") + "\n";
+    s += "#define XMW_FORM " + std::to_string(8 == typesize ? (k > 32 ? 2 : 1) : 0) + "\n";
+    s += SMM_JIT_PRELUDE;
+    s += SMM_MFMA_WG_SOURCE;
+    return s;
+  }
   if (0 != (variant & SMM_JIT_BIG)) { // work-group per item, K chunked
     s += "#define XKC " + std::to_string(smm_jit_big_kc(typesize, m, n, k, flags)) + "\n";
     s += SMM_JIT_BIG_BODY;
@@ -1309,6 +1321,49 @@ int launch_smm_jit_grouped(const SmmBatch* groups, int ngroups, void* stream, co
   int nentries = (int)tab.size();
   void* args[] = { (void*)&d_tab, &nentries };
   return jit_launch_dyn(kern, total, (unsigned)plan.key.threads, (unsigned)plan.lds_max, args, stream);
+}
+
+// Matrix-core work-group kernels (32 < max(M, N) <= 64, K <= 64; independent items, or runs of a uniform length) with the
+// descriptor baked in. -1: not applicable / not ready (the pre-compiled kernel of the same plan serves: launch_smm_special).
+int launch_smm_jit_mfma(const SmmBatch& s, void* stream, const char** name)
+{
+  const char* const env_jit = getenv("LIBXSMM_AMD_JIT");
+  if (nullptr != env_jit && 0 == atoi(env_jit)) return -1;
+  static const int on = []() { const char* e = getenv("XSMM_SMMJIT_MFMA"); return (nullptr != e && 0 != *e) ? atoi(e) : 1; }(); // developer knob
+  if (0 == on || 0 == s.use_mfma || 0 != s.general || 0 != s.lowp) return -1;
+  if (!((32 < s.m || 32 < s.n) && s.m <= 64 && s.n <= 64 && 0 < s.k && s.k <= 64 && s.lda >= s.m && s.ldb >= s.k && s.ldc >= s.m)) return -1;
+  if (0 != (s.flags & LIBXSMM_GEMM_FLAG_TRANS_B)) return -1;
+  if (4 == s.typesize && 64 == s.m && 64 == s.n && 64 == s.k && 64 == s.lda && 64 == s.ldb && 64 == s.ldc && SYNC_NONE == s.sync) return -1; // the hand-tuned tight 64^3 kernel
+  long long units = 0; int runlen = 1;
+  if (SYNC_NONE == s.sync) units = s.batch;
+  else if (SYNC_RUNS == s.sync && 0 < s.uniform_run && 0 == s.batch % s.uniform_run) { units = s.batch / s.uniform_run; runlen = (int)s.uniform_run; }
+  if (units < 1) return -1;
+  const char* const env_min = getenv("LIBXSMM_AMD_JIT_MINBATCH");
+  if (s.batch < ((nullptr != env_min && 0 != *env_min) ? atoll(env_min) : 1024LL) && 0 == s.jit_always) return -1;
+  const bool f64 = (8 == s.typesize);
+  const bool tight = !f64 && s.lda == s.m && s.ldb == s.k && 0 == ((s.m * s.k) & 3) && 0 == ((s.k * s.n) & 3);
+  static const int tightc_on = []() { const char* e = getenv("XSMM_SMM64_TIGHTC"); return (nullptr != e && 0 != *e) ? atoi(e) : 1; }();
+  const bool tightc = !f64 && s.ldc == s.m && 0 == ((s.m * s.n) & 3) && 0 != (s.m & 31) && 0 != tightc_on;
+  const int variant = SMM_JIT_MFMA | (tight ? SMM_JIT_MFMA_TIGHT : 0) | (tightc ? SMM_JIT_MFMA_TIGHTC : 0);
+  const SmmKey key = { s.typesize, s.m, s.n, s.k, s.flags & LIBXSMM_GEMM_FLAG_BETA_0, variant, s.lda, s.ldb, s.ldc };
+  JitKernel* const k = smm_jit_get(key);
+  if (nullptr == k) return -1;
+  struct { const char* a; const char* b; char* c; const char* ia; const char* ib; const char* ic; long long sa, sb, sc; int index_base, index_stride, mode; const int* flags; } ad;
+  ad.a = (const char*)s.a; ad.b = (const char*)s.b; ad.c = (char*)s.c; ad.ia = (const char*)s.ia; ad.ib = (const char*)s.ib; ad.ic = (const char*)s.ic;
+  ad.sa = s.sa; ad.sb = s.sb; ad.sc = s.sc; ad.index_base = s.index_base; ad.index_stride = s.index_stride; ad.mode = s.mode; ad.flags = nullptr;
+  long long batch = s.batch;
+  size_t lds = 0; int fit = (tightc ? 3 : 4); // (48 KiB of LDS with the C image: three work-groups per CU)
+  if (f64) { // (the sizes of the pre-compiled launch, kernels/smm_special.hip)
+    lds = (s.k > 32) ? (size_t)2 * 32 * 64 * sizeof(double) : (size_t)2 * (4 * ((s.k + 3) / 4)) * 64 * sizeof(double);
+    fit = (int)((160u * 1024u) / lds); if (fit > 3) fit = 3; if (fit < 1) fit = 1;
+  }
+  static const int bpc_env = []() { const char* e = getenv("XSMM_SMM64_BPC"); return (nullptr != e && 0 != *e) ? atoi(e) : 0; }();
+  long long blocks = units;
+  const long long resident = 256LL * (0 < bpc_env ? bpc_env : fit);
+  if (blocks > resident) blocks = resident;
+  void* args[] = { &ad, &batch, &runlen };
+  *name = f64 ? (1 == runlen ? "smm_f64_mfma_wg_jit" : "smm_f64_mfma_wg_runs_jit") : (1 == runlen ? "smm_f32_mfma_wg_jit" : "smm_f32_mfma_wg_runs_jit");
+  return jit_launch_dyn(k, (unsigned)blocks, 256u, (unsigned)lds, args, stream);
 }
 
 // 16-bit inputs (args.lowp 1: i16 -> i32, 3: bf16 -> f32): strided batches of tightly packed items with independent C go through

@@ -143,7 +143,7 @@ def test_smm64_mfma(xs, orc, torch_gpu, dtype, beta, mode):
         out = dc.cpu().numpy()
     finally:
         xs.lib().libxsmm_amd_set_mfma(old)
-    assert xs.last_kernel() == ("smm_f64_mfma_wg" if dtype == np.float64 else "smm_f32_64x64x64_mfma"), xs.last_kernel()
+    assert xs.last_kernel() in (("smm_f64_mfma_wg", "smm_f64_mfma_wg_jit") if dtype == np.float64 else ("smm_f32_64x64x64_mfma",)), xs.last_kernel()
     assert np.array_equal(out, ref)
 
 
@@ -156,10 +156,15 @@ MFMA_WG_SHAPES = [  # 32 < max(M, N) <= 64, K <= 64: tight and with gaps, odd K 
 @pytest.mark.parametrize("shape", MFMA_WG_SHAPES)
 @pytest.mark.parametrize("beta", [1.0, 0.0])
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
-def test_smm_mfma_wg(xs, orc, torch_gpu, dtype, shape, beta):
+@pytest.mark.parametrize("specialised", [False, True])
+def test_smm_mfma_wg(xs, orc, torch_gpu, dtype, shape, beta, specialised):
     """The general matrix-core kernel (work-group per item) against the oracle's fma chain, bit for bit -- including the sign of
-    zeros: a batch of all-zero A with C = -0 (the padded k step of an odd K must not turn -0 into +0)."""
+    zeros: a batch of all-zero A with C = -0 (the padded k step of an odd K must not turn -0 into +0). Both builds of the one
+    source (kernels/smm_mfma_wg.inc): pre-compiled with the shape as kernel arguments, and compiled by hiprtc with the
+    descriptor baked in."""
     torch = torch_gpu
+    old_jit = os.environ.get("LIBXSMM_AMD_JIT")
+    os.environ["LIBXSMM_AMD_JIT"] = "1" if specialised else "0"
     m, n, k, lda, ldb, ldc = shape
     batch = 1100
     rng = np.random.default_rng(99 + m + 64 * n + k)
@@ -183,7 +188,11 @@ def test_smm_mfma_wg(xs, orc, torch_gpu, dtype, shape, beta):
         out = dc.cpu().numpy()
     finally:
         xs.lib().libxsmm_amd_set_mfma(old)
-    assert xs.last_kernel() == ("smm_f64_mfma_wg" if dtype == np.float64 else "smm_f32_mfma_wg"), xs.last_kernel()
+        if old_jit is None:
+            del os.environ["LIBXSMM_AMD_JIT"]
+        else:
+            os.environ["LIBXSMM_AMD_JIT"] = old_jit
+    assert xs.last_kernel() == ("smm_f64_mfma_wg" if dtype == np.float64 else "smm_f32_mfma_wg") + ("_jit" if specialised else ""), xs.last_kernel()
     bits = np.uint64 if dtype == np.float64 else np.uint32
     assert np.array_equal(out.view(bits), ref.view(bits))
 

@@ -21,6 +21,15 @@ LIBXSMM_API int libxsmm_amd_device_count(void);
  *  on different streams, by one thread switching streams between calls or by several threads. */
 LIBXSMM_API void libxsmm_amd_set_stream(void* hip_stream);
 LIBXSMM_API void* libxsmm_amd_get_stream(void);
+/** Calls of a dispatched kernel on device memory, kernel(a, b, c) once per product (samples/smm/specialized.cpp:172-190), do
+ *  not cost a launch each: consecutive calls form a burst whose work is queued on the stream with the first call (a gate
+ *  kernel that waits for the burst to be complete and the batch kernel behind it) while the following calls only append
+ *  their operands to a ring in pinned memory. A burst is completed by the next entry point of the library called on the
+ *  thread, by a call that may not run beside the recorded ones, or by a helper thread a few dozen microseconds after the
+ *  last call -- so whatever the caller queues or waits for afterwards (its own kernels, hipMemcpy, hipStreamSynchronize,
+ *  hipDeviceSynchronize) is ordered behind the calls as behind any asynchronous launch. libxsmm_amd_flush completes the
+ *  calling thread's burst at once (a latency hint, never needed for correctness). LIBXSMM_AMD_DEFER=0: a launch per call. */
+LIBXSMM_API void libxsmm_amd_flush(void);
 /** Block until all work enqueued by this library on its stream has completed. Returns EXIT_SUCCESS/FAILURE. */
 LIBXSMM_API int libxsmm_amd_synchronize(void);
 /** Device memory (hipMalloc/hipFree) -- what libxsmm_malloc returns when a device is present is host-pinned

@@ -39,8 +39,12 @@ template<int G> __device__ __forceinline__ void unit_sync()
 template<typename T, int TM, int TN, int TGM, int TGN, bool GENERAL>
 __global__ __launch_bounds__(256)
 void smm_generic_kernel(DevAddr ad, int M, int N, int K, int lda, int ldb, int ldc, int flags, int sync_arg,
-                        long long batch_arg, int KC, int kshift, T alpha, T beta, int tiles_m, int tiles_n, int hw_atomics)
+                        long long batch_arg, int KC, int kshift, T alpha, T beta, int tiles_m, int tiles_n, int hw_atomics,
+                        const unsigned long long* batch_ptr)
 {
+  // (deferred per-call kernels: the number of items was not known when this launch was queued -- the gate kernel in front of
+  // it on the stream has left it in *batch_ptr)
+  if (nullptr != batch_ptr) batch_arg = (long long)(*batch_ptr);
   // tiles_m * tiles_n > 1 (independent C only): a unit is one MP x NP tile of one item -- a single large product
   // (libxsmm_?gemm, a relinked BLAS caller) spreads over the chip instead of running on one work-group
   const int tiles = tiles_m * tiles_n;
@@ -270,7 +274,7 @@ int launch_generic_t(const SmmBatch& s, hipStream_t stream)
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL((smm_generic_kernel<T, TM, TM, TGM, TGM, GENERAL>), dim3((unsigned)blocks), dim3(256), smem, stream,
     make_addr(s), s.m, s.n, s.k, s.lda, s.ldb, s.ldc, s.flags, s.sync, s.batch, KC, kshift, (T)s.alpha, (T)s.beta, tiles_m, tiles_n,
-    (SYNC_DEVICE == s.sync || SYNC_ATOMIC == s.sync) ? s.c_atomics : 1);
+    (SYNC_DEVICE == s.sync || SYNC_ATOMIC == s.sync) ? s.c_atomics : 1, s.batch_ptr);
   return (int)hipGetLastError();
 }
 
@@ -312,6 +316,31 @@ int launch_c_order_check(const SmmBatch& s, int* d_out, void* stream)
   if (blocks < 1) blocks = 1;
   if (8 == s.typesize) hipLaunchKernelGGL((c_order_kernel<double>), dim3((unsigned)blocks), dim3(256), 0, st, make_addr(s), s.batch, d_out);
   else hipLaunchKernelGGL((c_order_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, st, make_addr(s), s.batch, d_out);
+  return (int)hipGetLastError();
+}
+
+// Gate of a burst of deferred per-call kernels: one lane waits until the host has sealed the burst (bit 63 of *word, which
+// lives in host memory the GPU reads directly) and leaves the number of recorded calls for the batch kernel that is queued
+// right behind it. The wait is bounded: the host's helper thread seals a burst a few dozen microseconds after the last call;
+// should that never happen, the gate gives up after `limit_ticks` of the 100 MHz wall clock and flags it.
+__global__ __launch_bounds__(64) void defer_gate_kernel(const unsigned long long* word, unsigned long long* count_out, unsigned long long limit_ticks)
+{
+  if (0 != threadIdx.x) return;
+  const unsigned long long t0 = wall_clock64();
+  unsigned long long w;
+  for (;;) {
+    w = __hip_atomic_load(word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (0 != (w >> 63)) break;
+    if (wall_clock64() - t0 > limit_ticks) { w |= (1ULL << 62); break; } // gave up: whatever has been recorded so far
+    __builtin_amdgcn_s_sleep(32);
+  }
+  count_out[0] = w & 0xFFFFFFFFULL;
+  count_out[1] = (w >> 62) & 1ULL;
+}
+
+int launch_defer_gate(const unsigned long long* word, unsigned long long* count_out, void* stream)
+{
+  hipLaunchKernelGGL(defer_gate_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, word, count_out, 200000000ULL /* 2 s */);
   return (int)hipGetLastError();
 }
 

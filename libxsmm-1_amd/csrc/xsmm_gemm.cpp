@@ -491,6 +491,7 @@ void call_kernel(Kernel* k, const void* a, const void* b, void* c, const void* x
   }
   if (KC_DENSE == k->kclass) {
     if (try_record(k->desc, a, b, c)) return;
+    if (defer_call(k, a, b, c)) return; // device operands: recorded, runs in stream order without a launch of its own (xsmm_defer.cpp)
     (void)single_execute(from_descriptor(k->desc), a, b, c);
   }
   else if (KC_REDUCE == k->kclass) { // xbm(const void** a, const void** b, void* c, const unsigned long long* count)

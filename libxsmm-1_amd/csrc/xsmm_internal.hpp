@@ -66,6 +66,7 @@ struct SmmBatch {
   int jit_always;           // != 0: specialise with hiprtc whatever the batch size (batch-reduce kernels: short batches, called over and over)
   int relaxed;              // != 0: sums into a shared C may be formed in any order (the caller's reference path is multi-threaded)
   int use_mfma;             // policy bit (0: scalar FMA only)
+  const unsigned long long* batch_ptr; // != NULL: the number of items is read from here by the kernel (deferred per-call kernels); `batch` is the capacity
   // general form used by the BLAS-like fallback (libxsmm_?gemm with alpha/beta/trans outside the SMM domain)
   double alpha, beta; int general;              // general != 0: C = alpha*op(A)*op(B) + beta*C, flags may hold TRANS_A
 };
@@ -78,6 +79,13 @@ constexpr int FLAG_SLOT_BLOCKS = 512; // work-groups of the C ordering check (ea
 // detects how C operands alias across the batch: out[0] = number of i with c_i == c_{i-1},
 // out[1] = number of i with c_i < c_{i-1}. d_out is a slot of flag_slot().
 int launch_c_order_check(const SmmBatch& args, int* d_out, void* stream);
+int launch_defer_gate(const unsigned long long* word, unsigned long long* count_out, void* stream); // see xsmm_defer.cpp
+int launch_smm_generic(const SmmBatch& s, void* stream, const char** name);
+// deferred per-call kernels (xsmm_defer.cpp)
+struct Kernel;
+bool defer_call(Kernel* k, const void* a, const void* b, void* c);  // true: recorded (runs later, in stream order)
+void defer_flush();                                                  // seal the calling thread's open burst
+extern thread_local bool tl_defer_open;
 
 // CSR "register" kernel family (fsspmdm sparse path, libxsmm_create_?csr_reg): row-major
 // C[m*ldc+n] = (beta? C:0) + sum_p val[p]*B[col[p]*ldb+n], rows without nnz untouched.
@@ -149,6 +157,7 @@ struct Device {
   void* stream = nullptr;   // hipStream_t
 };
 Device& device();
+Device& device_raw();                     // the same without sealing an open burst of deferred calls
 bool device_ready();                      // probes once; false if no HIP device
 void fail_no_device(const char* what);    // prints a loud error (always) -- the product has no CPU compute path
 bool is_device_ptr(const void* p);

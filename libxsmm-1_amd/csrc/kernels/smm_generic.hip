@@ -322,8 +322,9 @@ int launch_c_order_check(const SmmBatch& s, int* d_out, void* stream)
 // Gate of a burst of deferred per-call kernels: one lane waits until the host has sealed the burst (bit 63 of *word, which
 // lives in host memory the GPU reads directly) and leaves the number of recorded calls for the batch kernel that is queued
 // right behind it. The wait is bounded: the host's helper thread seals a burst a few dozen microseconds after the last call;
-// should that never happen, the gate gives up after `limit_ticks` of the 100 MHz wall clock and flags it.
-__global__ __launch_bounds__(64) void defer_gate_kernel(const unsigned long long* word, unsigned long long* count_out, unsigned long long limit_ticks)
+// should that not happen (the process was stopped), the gate seals the burst itself after `limit_ticks` of the 100 MHz wall
+// clock -- atomically, like the helper would: the caller's next call finds the seal and starts a new burst, nothing is lost.
+__global__ __launch_bounds__(64) void defer_gate_kernel(unsigned long long* word, unsigned long long* count_out, unsigned long long limit_ticks)
 {
   if (0 != threadIdx.x) return;
   const unsigned long long t0 = wall_clock64();
@@ -331,14 +332,17 @@ __global__ __launch_bounds__(64) void defer_gate_kernel(const unsigned long long
   for (;;) {
     w = __hip_atomic_load(word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
     if (0 != (w >> 63)) break;
-    if (wall_clock64() - t0 > limit_ticks) { w |= (1ULL << 62); break; } // gave up: whatever has been recorded so far
+    if (wall_clock64() - t0 > limit_ticks) {
+      w = __hip_atomic_fetch_or(word, 1ULL << 63, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_SYSTEM) | (1ULL << 62);
+      break;
+    }
     __builtin_amdgcn_s_sleep(32);
   }
   count_out[0] = w & 0xFFFFFFFFULL;
   count_out[1] = (w >> 62) & 1ULL;
 }
 
-int launch_defer_gate(const unsigned long long* word, unsigned long long* count_out, void* stream)
+int launch_defer_gate(unsigned long long* word, unsigned long long* count_out, void* stream)
 {
   hipLaunchKernelGGL(defer_gate_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, word, count_out, 200000000ULL /* 2 s */);
   return (int)hipGetLastError();

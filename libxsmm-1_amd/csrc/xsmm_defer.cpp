@@ -196,7 +196,7 @@ bool open_burst(Ring& r, Kernel* k)
   b.a = &sl.entries[0].a; b.b = &sl.entries[0].b; b.c = &sl.entries[0].c; b.sa = b.sb = b.sc = (long long)sizeof(Entry);
   b.batch = DEFER_CAP; b.batch_ptr = sl.count;
   b.sync = (0 != (b.flags & LIBXSMM_GEMM_FLAG_BETA_0)) ? SYNC_NONE : SYNC_RUNS; // consecutive calls with one C: a run, in call order
-  if (0 != launch_defer_gate(reinterpret_cast<const unsigned long long*>(sl.word), sl.count, dev.stream)) return false;
+  if (0 != launch_defer_gate(reinterpret_cast<unsigned long long*>(sl.word), sl.count, dev.stream)) return false;
   const char* name = "";
   const int e = launch_smm_generic(b, dev.stream, &name);
   if (0 != e) { // (the gate is queued already: let it through with nothing recorded)

@@ -116,14 +116,14 @@ template<int V, int NL, int E> __device__ __forceinline__ void load_flat(const T
   const XGLOBAL T* const g = (const XGLOBAL T*)p;
 #pragma unroll
   for (int j = 0; j < NL; ++j) {
-    const int e = (UT * j + lane) * V;
-    if (e < E) {
-      if constexpr (1 == V) r[j][0] = __builtin_nontemporal_load(g + e);
-      else {
-        const typename Vec<V>::type v = __builtin_nontemporal_load(reinterpret_cast<const XGLOBAL typename Vec<V>::type*>(g + e));
+    // lanes past the end fetch the last piece again (never used): no divergent control flow around the loads, so the
+    // compiler's count of what is in flight at a wait stays exact instead of falling back to "everything"
+    const int e0 = (UT * j + lane) * V, e = (e0 < E - V) ? e0 : (E - V);
+    if constexpr (1 == V) r[j][0] = __builtin_nontemporal_load(g + e);
+    else {
+      const typename Vec<V>::type v = __builtin_nontemporal_load(reinterpret_cast<const XGLOBAL typename Vec<V>::type*>(g + e));
 #pragma unroll
-        for (int q = 0; q < V; ++q) r[j][q] = v[q];
-      }
+      for (int q = 0; q < V; ++q) r[j][q] = v[q];
     }
   }
 }
@@ -359,6 +359,33 @@ __device__ __forceinline__ void store_c(T* Cs, T* pc, int lane, int tx, int ty, 
     }
   }
   wave_lds_sync();
+}
+
+// The streaming form defers the stores of an item to the top of the next iteration, in front of that iteration's loads:
+// vmcnt retires loads and stores in the order of issue, so stores issued right behind the arithmetic -- younger than the
+// prefetched operands -- made the wait for the operands a wait for the previous item's C to reach memory as well (measured
+// on tools/probe/mfma_wave.hip: 7.3 -> 2.2 us per item and wave).
+__device__ __forceinline__ void c_to_lds(T* Ci, int tx, int ty, const T (&acc)[TM][TN])
+{
+  wave_lds_sync();
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) { const int m = tx * TM + i, n = ty * TN + j; if (m < M && n < N) Ci[n * M + m] = acc[i][j]; }
+  }
+  wave_lds_sync();
+}
+__device__ __forceinline__ void lds_to_mem(const T* Cs, T* pc, int lane)
+{
+#pragma unroll
+  for (int j = 0; j < NLC; ++j) {
+    if constexpr (!TIGHT_C) { const int e = 64 * j + lane; if (e < CE) { const int n = e / LDC, m = e - n * LDC; if (m < M) __builtin_nontemporal_store(Cs[n * M + m], (XGLOBAL T*)pc + e); } } // (VC == 1)
+    else { // (lanes past the end repeat the last piece: same data to the same place)
+      const int e0 = (64 * j + lane) * VC, e = (e0 < CE - VC) ? e0 : (CE - VC);
+      if constexpr (1 == VC) __builtin_nontemporal_store(Cs[e], (XGLOBAL T*)pc + e);
+      else __builtin_nontemporal_store(*reinterpret_cast<const typename Vec<VC>::type*>(Cs + e), reinterpret_cast<XGLOBAL typename Vec<VC>::type*>((XGLOBAL T*)pc + e));
+    }
+  }
 }
 
 #if XRUNS
@@ -661,11 +688,18 @@ extern "C" __global__ __launch_bounds__(64 * XWAVES) void xsmm_smm_op(DevAddr ad
 #else
   if (!XBETA0) load_flat<VC, NLC, CE>(resolve<const T>(ad.c, ad.ic, ad.sc, ad, w), lane, rc);
 #endif
+#if (2 != XLOWP)
+  T* pend = nullptr; // C block whose result waits in the LDS image
+#endif
   for (long long item = w; item < batch; item += W) {
 #if (2 == XLOWP)
     unsigned* const pc = resolve<unsigned>(ad.c, ad.ic, ad.sc, ad, item);
 #else
     T* const pc = resolve<T>(ad.c, ad.ic, ad.sc, ad, item);
+    if (XDEFER) {
+      __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): this item's operands; the only other instructions in flight are older stores
+      if (nullptr != pend) { lds_to_mem(Cs, pend, lane); wave_lds_sync(); }
+    }
 #endif
 #if XLOWP
     park_pairs(As, Bs, lane, ra, rb);
@@ -700,13 +734,180 @@ extern "C" __global__ __launch_bounds__(64 * XWAVES) void xsmm_smm_op(DevAddr ad
 #if (2 == XLOWP)
     store_c_pairs(Cs, pc, lane, tx, ty, acc);
 #else
-    store_c(Cs, pc, lane, tx, ty, acc, Cs + grp * CT1);
+    if (XDEFER) { c_to_lds(Cs + grp * CT1, tx, ty, acc); pend = pc; }
+    else store_c(Cs, pc, lane, tx, ty, acc, Cs + grp * CT1);
 #endif
   }
+#if (2 != XLOWP)
+  if (XDEFER && nullptr != pend) lds_to_mem(Cs, pend, lane);
+#endif
 #endif
 }
 #endif
 )XSMM";
+
+// ---- 32 < max(M, N) <= 64 on the matrix cores with ONE WAVE PER ITEM (tight operands, M and K multiples of four) --------
+// The work-group-per-item kernels (kernels/smm_mfma_wg.inc) synchronise four waves twice per item and keep few items in
+// flight per CU; below 64^3 they are latency-bound (40^3: 46 % of the HBM peak). Here a wave owns an item: C, A and B
+// arrive as whole 16-byte chunks of the contiguous arrays (lanes past the end of an array repeat its last chunk: no
+// divergent control flow around memory instructions, so the compiler's wait counts stay exact), C is redistributed through
+// LDS into the tile layout of the accumulators, A and B are parked as LDS images that the operand fetches of
+// v_mfma_{f32,f64}_16x16x4 read conflict-free (A: [k][MS], rows of 16 lanes at a stride that spreads the four k of a fetch
+// over the banks; B: [n][KSD] with KSD/VEC odd), the result goes back through LDS and leaves as whole lines. Both
+// instructions are k-ordered fma chains (tools/probe/mfma_f64_chain.hip; kernels/sparse.hip uses the fp32 one): C equals
+// the reference's per-element chain bit for bit. The stores of item i are issued at the top of iteration i + 1, before
+// the loads of item i + 2: vmcnt retires in the order of issue, so whenever the wave waits for its operands nothing younger
+// is in flight and it never waits for a store to reach memory (tools/probe/mfma_wave.hip: 7.3 -> 2.2 us per item and wave).
+const char* const SMM_JIT_MFMA_WAVE_BODY = R"XSMM(
+constexpr int M = XM, N = XN, K = XK;
+constexpr int TS = (int)sizeof(T);
+constexpr int VEC = 16 / TS;
+typedef T V __attribute__((ext_vector_type(VEC)));
+typedef T ACC __attribute__((ext_vector_type(4)));
+typedef float ACC32 __attribute__((ext_vector_type(4)));
+typedef double ACC64 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ ACC32 xmfma(float a, float b, ACC32 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ ACC64 xmfma(double a, double b, ACC64 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+constexpr bool F64 = (8 == TS);
+constexpr int MI = (M + 15) / 16, NI = (N + 15) / 16, KS = K / 4;
+constexpr int MS = (M <= 16) ? 16 : (M <= 48 ? 48 : 64);
+constexpr bool ASWZ = (64 == MS);
+constexpr int kstride() { int s = ((K + VEC - 1) / VEC); if (0 == (s & 1)) ++s; return s * VEC; }
+constexpr int KSD = kstride();
+// image of C: column stride such that the four column groups of a tile access fall into different banks
+constexpr int cstride() { int s = M; for (;; s += VEC) { if (F64 ? (16 == s % 32) : (4 == s % 16 || 12 == s % 16)) break; } return s; }
+constexpr int CSD = cstride();
+constexpr int C_ELEMS = N * CSD;
+constexpr int A_ELEMS = (C_ELEMS > K * MS) ? C_ELEMS : K * MS, B_ELEMS = N * KSD;
+constexpr int CA = (M * K / VEC + 63) / 64, CB = (K * N / VEC + 63) / 64, CC = (M * N / VEC + 63) / 64;
+static_assert(0 == M % VEC && 0 == K % 4, "shape");
+__device__ __forceinline__ int clampi(int v, int hi) { return v < hi ? v : hi; }
+// row of C a lane's accumulator register r belongs to (the fp32 and fp64 instructions differ)
+#define XNROW(r) (F64 ? (lq + 4 * (r)) : (4 * lq + (r)))
+
+extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(XWPE))) void xsmm_smm_op(DevAddr ad, long long batch, int runlen)
+{
+  extern __shared__ __align__(16) unsigned char smem[];
+  T* const As = reinterpret_cast<T*>(smem);
+  T* const Bs = As + A_ELEMS;
+  T* const Cs = As;                      // the image of C shares the place of A's (never alive together)
+  T* const dummy = Bs + B_ELEMS;         // a word per lane for the writes of lanes outside C
+  const int lane = threadIdx.x, l16 = lane & 15, lq = lane >> 4;
+  (void)runlen;
+  V ra[CA], rb[CB], rc[CC];
+  auto load_ab = [&](long long item) {
+    const XGLOBAL V* const pa = (const XGLOBAL V*)resolve<const T>(ad.a, ad.ia, ad.sa, ad, item);
+    const XGLOBAL V* const pb = (const XGLOBAL V*)resolve<const T>(ad.b, ad.ib, ad.sb, ad, item);
+#pragma unroll
+    for (int j = 0; j < CA; ++j) ra[j] = __builtin_nontemporal_load(pa + clampi(64 * j + lane, M * K / VEC - 1));
+#pragma unroll
+    for (int j = 0; j < CB; ++j) rb[j] = __builtin_nontemporal_load(pb + clampi(64 * j + lane, K * N / VEC - 1));
+  };
+  auto load_c = [&](long long item) {
+    const XGLOBAL V* const pc = (const XGLOBAL V*)resolve<const T>(ad.c, ad.ic, ad.sc, ad, item);
+#pragma unroll
+    for (int j = 0; j < CC; ++j) rc[j] = __builtin_nontemporal_load(pc + clampi(64 * j + lane, M * N / VEC - 1));
+  };
+  auto store_c = [&](long long item) { // the image of C -> memory, whole lines
+    XGLOBAL V* const pc = (XGLOBAL V*)resolve<T>(ad.c, ad.ic, ad.sc, ad, item);
+#pragma unroll
+    for (int j = 0; j < CC; ++j) {
+      const int ch = clampi(64 * j + lane, M * N / VEC - 1), e = ch * VEC, n = e / M, m = e % M;
+      __builtin_nontemporal_store(*reinterpret_cast<const V*>(Cs + n * CSD + m), pc + ch);
+    }
+  };
+  long long item = blockIdx.x, prev = -1;
+  if (item >= batch) return;
+  load_ab(item);
+  if (!XBETA0) load_c(item);
+  for (;;) {
+    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): this item's operands (the only other instructions in flight are older stores)
+    if (0 <= prev) { store_c(prev); wave_lds_sync(); }
+    ACC acc[NI][MI];
+    if (!XBETA0) {
+#pragma unroll
+      for (int j = 0; j < CC; ++j) {
+        const int ch = clampi(64 * j + lane, M * N / VEC - 1), e = ch * VEC, n = e / M, m = e % M;
+        *reinterpret_cast<V*>(Cs + n * CSD + m) = rc[j];
+      }
+      wave_lds_sync();
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int n = clampi(16 * ni + XNROW(r), N - 1), m = clampi(16 * mi + l16, M - 1);
+            acc[ni][mi][r] = Cs[n * CSD + m];
+          }
+      wave_lds_sync();
+    }
+    else {
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = ACC{ 0, 0, 0, 0 };
+    }
+#pragma unroll
+    for (int j = 0; j < CA; ++j) {
+      const int ch = clampi(64 * j + lane, M * K / VEC - 1), e = ch * VEC, k = e / M, m = e % M;
+      *reinterpret_cast<V*>(As + k * MS + (ASWZ ? (m ^ ((k & 3) << 4)) : m)) = ra[j];
+    }
+#pragma unroll
+    for (int j = 0; j < CB; ++j) {
+      const int ch = clampi(64 * j + lane, K * N / VEC - 1), e = ch * VEC, n = e / K, k = e % K;
+      *reinterpret_cast<V*>(Bs + n * KSD + k) = rb[j];
+    }
+    const long long next = item + gridDim.x;
+    if (next < batch) { load_ab(next); if (!XBETA0) load_c(next); }
+    wave_lds_sync();
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      T af[MI], bf[NI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) { const int m = 16 * mi + l16; af[mi] = As[(4 * ks + lq) * MS + (ASWZ ? (m ^ (lq << 4)) : m)]; }
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) { const int n = clampi(16 * ni + l16, N - 1); bf[ni] = Bs[n * KSD + 4 * ks + lq]; }
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = xmfma(bf[ni], af[mi], acc[ni][mi]);
+    }
+    wave_lds_sync(); // (the images are dead now)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int n = 16 * ni + XNROW(r), m = 16 * mi + l16;
+          const bool inside = (16 * ni + 15 < N || n < N) && (16 * mi + 15 < M || m < M);
+          T* const dst = inside ? Cs + n * CSD + m : dummy + lane;
+          *dst = acc[ni][mi][r];
+        }
+    wave_lds_sync();
+    prev = item;
+    if (next >= batch) break;
+    item = next;
+  }
+  store_c(prev);
+}
+)XSMM";
+
+// LDS bytes of a wave of that kernel (mirrors the constexpr arithmetic of the source); 0: the shape is not served
+static size_t smm_mfma_wave_lds(int typesize, int m, int n, int k)
+{
+  const int vec = 16 / typesize;
+  if (0 != m % vec || 0 != k % 4 || m > 64 || n > 64 || k > 64 || k < 4) return 0;
+  const int ms = (m <= 16) ? 16 : (m <= 48 ? 48 : 64);
+  int ksd = (k + vec - 1) / vec; if (0 == (ksd & 1)) ++ksd; ksd *= vec;
+  int csd = m; for (;; csd += vec) { if (8 == typesize ? (16 == csd % 32) : (4 == csd % 16 || 12 == csd % 16)) break; }
+  const int a_elems = (n * csd > k * ms) ? n * csd : k * ms;
+  return (size_t)(a_elems + n * ksd + 64) * typesize;
+}
+// waves per SIMD the kernel is compiled for: two where LDS leaves room for eight waves per CU, else one (the register file
+// then holds an item's operands, the next item's and the accumulators without spilling)
+static int smm_mfma_wave_wpe(size_t lds) { return (8 * lds <= 160u * 1024u) ? 2 : 1; }
 
 // ---- shapes with 32 < M or N <= 64: one work-group (256 threads, 16 x 16) per item, K in chunks of KC through LDS ------
 const char* const SMM_JIT_BIG_BODY = R"XSMM(
@@ -949,6 +1150,12 @@ std::string gen_smm_source(int typesize, int m, int n, int k, int flags, int var
   s += "#define XM " + std::to_string(m) + "\n#define XN " + std::to_string(n) + "\n#define XK " + std::to_string(k) + "\n";
   s += std::string("#define XBETA0 ") + ((flags & LIBXSMM_GEMM_FLAG_BETA_0) ? "1" : "0") + "\n";
   s += std::string("#define XTRANSB ") + ((flags & LIBXSMM_GEMM_FLAG_TRANS_B) ? "1" : "0") + "\n";
+  if (0 != (variant & SMM_JIT_MFMA_WAVE)) { // matrix-core kernel, one wave per item
+    s += "#define XFLAT 0\n#define XWPE " + std::to_string(smm_mfma_wave_wpe(smm_mfma_wave_lds(typesize, m, n, k))) + "\n";
+    s += SMM_JIT_PRELUDE;
+    s += SMM_JIT_MFMA_WAVE_BODY;
+    return s;
+  }
   if (0 != (variant & SMM_JIT_MFMA)) { // matrix-core work-group kernel, shape and leading dimensions baked in
     s += "#define XFLAT 0\n#define XMW_JIT 1\n";
     s += "#define XLDA " + std::to_string(lda) + "\n#define XLDB " + std::to_string(ldb) + "\n#define XLDC " + std::to_string(ldc) + "\n";
@@ -974,13 +1181,19 @@ std::string gen_smm_source(int typesize, int m, int n, int k, int flags, int var
   { // address space of the operand accesses: global for the run forms; the streaming (one wave per item) form measured
     // faster with generic pointers, i.e. FLAT instructions (f64 13^3: 60.7 vs 55.3 %, the fp32 32^3 kernels 72.5 vs 69 %)
     static const int flat_env = []() { const char* e = getenv("XSMM_SMMJIT_FLAT"); return (nullptr != e && 0 != *e) ? atoi(e) : -1; }();
-    const int flat = (0 <= flat_env) ? flat_env : ((variant & (SMM_JIT_RUNS | SMM_JIT_WGRUNS)) ? 0 : 1);
+    static const int defer_env0 = []() { const char* e = getenv("XSMM_SMMJIT_DEFER"); return (nullptr != e && 0 != *e) ? atoi(e) : 1; }();
+    // (with the stores deferred the global form is the faster one: tools/sweep_defer.sh, profiles/r2_sweep_defer.txt)
+    const int flat = (0 <= flat_env) ? flat_env : ((0 != (variant & (SMM_JIT_RUNS | SMM_JIT_WGRUNS)) || 0 != defer_env0) ? 0 : 1);
     s += std::string("#define XFLAT ") + (flat ? "1" : "0") + "\n";
   }
   s += "#define XDEPTH " + std::to_string(smm_jit_depth(typesize, m, n, k, variant)) + "\n";  // register stages of the run forms
   s += std::string("#define XSPLIT ") + ((variant & SMM_JIT_SPLIT) ? "1" : "0") + "\n";  // relaxed order: few long runs are cut into segments (atomics)
   s += std::string("#define XHASWG ") + ((variant & SMM_JIT_HASWG) ? "1" : "0") + "\n";   // wave form: leave long runs to the work-group form
   s += "#define XGROUPED 0\n";
+  { // deferred stores of the streaming form (developer knob)
+    static const int defer_env = []() { const char* e = getenv("XSMM_SMMJIT_DEFER"); return (nullptr != e && 0 != *e) ? atoi(e) : 1; }();
+    s += std::string("#define XDEFER ") + (defer_env ? "1" : "0") + "\n";
+  }
   s += SMM_JIT_PRELUDE;
   s += SMM_JIT_SHAPE;
   return s;
@@ -1341,6 +1554,32 @@ int launch_smm_jit_mfma(const SmmBatch& s, void* stream, const char** name)
   const char* const env_min = getenv("LIBXSMM_AMD_JIT_MINBATCH");
   if (s.batch < ((nullptr != env_min && 0 != *env_min) ? atoll(env_min) : 1024LL) && 0 == s.jit_always) return -1;
   const bool f64 = (8 == s.typesize);
+  { // one wave per item: independent items of a strided batch, tight and 16-byte aligned operands, at least four waves per CU
+    static const int wave_on = []() { const char* e = getenv("XSMM_SMMJIT_MFMA_WAVE"); return (nullptr != e && 0 != *e) ? atoi(e) : 1; }(); // developer knob
+    const size_t wlds = smm_mfma_wave_lds(s.typesize, s.m, s.n, s.k);
+    const uintptr_t bits = reinterpret_cast<uintptr_t>(s.a) | reinterpret_cast<uintptr_t>(s.b) | reinterpret_cast<uintptr_t>(s.c)
+                         | (uintptr_t)(s.sa * s.typesize) | (uintptr_t)(s.sb * s.typesize) | (uintptr_t)(s.sc * s.typesize);
+    if (0 != wave_on && 0 != wlds && 4 * wlds <= 160u * 1024u && SYNC_NONE == s.sync && ADDR_STRIDED == s.mode && 0 == (bits & 15)
+      && s.lda == s.m && s.ldb == s.k && s.ldc == s.m)
+    {
+      const SmmKey wkey = { s.typesize, s.m, s.n, s.k, s.flags & LIBXSMM_GEMM_FLAG_BETA_0, SMM_JIT_MFMA_WAVE, s.lda, s.ldb, s.ldc };
+      JitKernel* const wk = smm_jit_get(wkey);
+      if (nullptr != wk) {
+        struct { const char* a; const char* b; char* c; const char* ia; const char* ib; const char* ic; long long sa, sb, sc; int index_base, index_stride, mode; const int* flags; } wad;
+        wad.a = (const char*)s.a; wad.b = (const char*)s.b; wad.c = (char*)s.c; wad.ia = wad.ib = wad.ic = nullptr;
+        wad.sa = s.sa; wad.sb = s.sb; wad.sc = s.sc; wad.index_base = 0; wad.index_stride = 0; wad.mode = 0; wad.flags = nullptr;
+        long long wbatch = s.batch; int one = 1;
+        int per_cu = (int)((160u * 1024u) / wlds);
+        const int by_regs = 4 * smm_mfma_wave_wpe(wlds);
+        if (per_cu > by_regs) per_cu = by_regs;
+        long long wblocks = 256LL * per_cu;
+        if (wblocks > s.batch) wblocks = s.batch;
+        void* wargs[] = { &wad, &wbatch, &one };
+        *name = f64 ? "smm_f64_mfma_wave_jit" : "smm_f32_mfma_wave_jit";
+        return jit_launch_dyn(wk, (unsigned)wblocks, 64u, (unsigned)wlds, wargs, stream);
+      }
+    }
+  }
   const bool tight = !f64 && s.lda == s.m && s.ldb == s.k && 0 == ((s.m * s.k) & 3) && 0 == ((s.k * s.n) & 3);
   static const int tightc_on = []() { const char* e = getenv("XSMM_SMM64_TIGHTC"); return (nullptr != e && 0 != *e) ? atoi(e) : 1; }();
   const bool tightc = !f64 && s.ldc == s.m && 0 == ((s.m * s.n) & 3) && 0 != (s.m & 31) && 0 != tightc_on;

@@ -39,6 +39,13 @@ def test_generated_sources_compile_for_gfx950(xs):
                     src = buf.value.decode()
                     assert "#define XM %d" % m in src and "xsmm_smm_op" in src
                     assert "#define XRUNS %d" % (2 if variant & 4 else (variant >> 1) & 1) in src
+    # matrix-core kernel with one wave per item (variant bit 16384): tight shapes beyond 32 with M and K multiples of four
+    for prec, shapes in ((xs.F32, [(40, 40, 40), (48, 48, 48), (56, 56, 56), (36, 64, 8), (64, 20, 12)]), (xs.F64, [(40, 40, 40), (48, 48, 48), (34, 40, 4)])):
+        for (m, n, k) in shapes:
+            for beta in (1.0, 0.0):
+                blob, d = xs.descriptor(prec, m, n, k, beta=beta)
+                assert 0 == L.libxsmm_amd_smm_kernel_source(d, 16384, buf, len(buf), 1), (prec, m, n, k, beta)
+                assert "xmfma" in buf.value.decode() and "#define XWPE" in buf.value.decode()
     # several consecutive items per wave (variant bits 8..10 = log2 of the count): small and oddly sized shapes of tight strided batches
     for prec in (xs.F64, xs.F32):
         for (m, n, k), packs in (((5, 5, 5), (1, 2, 3, 4)), ((8, 8, 8), (1, 2)), ((13, 13, 13), (1, 2)), ((23, 23, 23), (1,)), ((5, 7, 3), (3,))):

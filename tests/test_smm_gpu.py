@@ -153,6 +153,23 @@ MFMA_WG_SHAPES = [  # 32 < max(M, N) <= 64, K <= 64: tight and with gaps, odd K 
 ]
 
 
+def mfma_wave_serves(dtype, m, n, k, lda, ldb, ldc):
+    """mirror of smm_mfma_wave_lds / the eligibility rule in csrc/xsmm_jit_smm.cpp: the one-wave-per-item matrix-core kernel takes
+    tight operands with M a multiple of a 16-byte chunk and K a multiple of four whose LDS images leave room for four waves per CU"""
+    ts = np.dtype(dtype).itemsize
+    vec = 16 // ts
+    if (lda, ldb, ldc) != (m, k, m) or m % vec or k % 4 or max(m, n) <= 32:
+        return False
+    ms = 16 if m <= 16 else (48 if m <= 48 else 64)
+    ksd = (k + vec - 1) // vec
+    ksd = (ksd + 1 if ksd % 2 == 0 else ksd) * vec
+    csd = m
+    while not ((csd % 32 == 16) if ts == 8 else (csd % 16 in (4, 12))):
+        csd += vec
+    lds = (max(n * csd, k * ms) + n * ksd + 64) * ts
+    return 4 * lds <= 160 * 1024
+
+
 @pytest.mark.parametrize("shape", MFMA_WG_SHAPES)
 @pytest.mark.parametrize("beta", [1.0, 0.0])
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
@@ -192,9 +209,56 @@ def test_smm_mfma_wg(xs, orc, torch_gpu, dtype, shape, beta, specialised):
             del os.environ["LIBXSMM_AMD_JIT"]
         else:
             os.environ["LIBXSMM_AMD_JIT"] = old_jit
-    assert xs.last_kernel() == ("smm_f64_mfma_wg" if dtype == np.float64 else "smm_f32_mfma_wg") + ("_jit" if specialised else ""), xs.last_kernel()
+    form = "wave" if (specialised and mfma_wave_serves(dtype, *shape)) else "wg"
+    assert xs.last_kernel() == ("smm_f64_mfma_" if dtype == np.float64 else "smm_f32_mfma_") + form + ("_jit" if specialised else ""), xs.last_kernel()
     bits = np.uint64 if dtype == np.float64 else np.uint32
     assert np.array_equal(out.view(bits), ref.view(bits))
+
+
+MFMA_WAVE_SHAPES = [(40, 40, 40), (48, 48, 48), (56, 56, 56), (36, 64, 8), (64, 20, 12), (44, 52, 36), (64, 64, 60), (16, 48, 64), (34, 40, 4)]
+
+
+@pytest.mark.parametrize("shape", MFMA_WAVE_SHAPES)
+@pytest.mark.parametrize("beta", [1.0, 0.0])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_smm_mfma_wave(xs, orc, torch_gpu, dtype, shape, beta):
+    """One wave per item on the matrix cores (csrc/xsmm_jit_smm.cpp, SMM_JIT_MFMA_WAVE_BODY: 16x16x4 tiles, operands and C as
+    whole lines through LDS, stores deferred behind the next item's wait): the oracle's fma chain bit for bit, for batches
+    smaller than, equal to and larger than the resident grid (every wave then walks several items) and with C = -0 / A = 0."""
+    torch = torch_gpu
+    m, n, k = shape
+    if not mfma_wave_serves(dtype, m, n, k, m, k, m):
+        pytest.skip("shape is left to the work-group kernel")
+    old_jit = os.environ.get("LIBXSMM_AMD_JIT")
+    os.environ["LIBXSMM_AMD_JIT"] = "1"
+    flags = xs.FLAG_BETA_0 if beta == 0.0 else 0
+    old = xs.lib().libxsmm_amd_set_mfma(1)
+    try:
+        for batch in (1, 7, 1024, 5003):
+            rng = np.random.default_rng(7 * batch + m + 64 * n + k)
+            a, b, c, asz, bsz, csz = make_inputs(rng, dtype, batch, m, n, k, m, k, m, False, False, orc)
+            a[:asz] = 0.0
+            c[:csz] = -0.0
+            if beta == 0.0:
+                c[:] = np.nan
+            ref = c.copy()
+            orc.gemm_batch_strided(orc.FMA, flags, m, n, k, m, k, m, a, b, ref, asz, bsz, csz, batch, 8)
+            da, db, dc = (torch.from_numpy(x).cuda() for x in (a, b, c))
+            blob, desc = xs.descriptor(xs.F64 if dtype == np.float64 else xs.F32, m, n, k, m, k, m, 1.0, beta)
+            # (batches below the threshold of the specialised kernels: the descriptor asks for them explicitly)
+            os.environ["LIBXSMM_AMD_JIT_MINBATCH"] = "1"
+            assert 0 == xs.lib().libxsmm_amd_gemm_batch_strided(desc, xs.dptr(da), xs.dptr(db), xs.dptr(dc), asz, bsz, csz, batch)
+            torch.cuda.synchronize()
+            assert xs.last_kernel() == ("smm_f64_mfma_wave_jit" if dtype == np.float64 else "smm_f32_mfma_wave_jit"), (batch, xs.last_kernel())
+            bits = np.uint64 if dtype == np.float64 else np.uint32
+            assert np.array_equal(dc.cpu().numpy().view(bits), ref.view(bits)), batch
+    finally:
+        xs.lib().libxsmm_amd_set_mfma(old)
+        os.environ.pop("LIBXSMM_AMD_JIT_MINBATCH", None)
+        if old_jit is None:
+            del os.environ["LIBXSMM_AMD_JIT"]
+        else:
+            os.environ["LIBXSMM_AMD_JIT"] = old_jit
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])

@@ -1355,11 +1355,14 @@ static int smm_jit_pack(const SmmBatch& s, int width)
     // many as make up 16 KB -- f64 5^3: 22 -> 69 % of the HBM peak, 8^3: 43 -> 72 %, 13^3: 61 -> 67 %; f32 5^3: 13 -> 58 %, 8^3: 25 -> 72 %
     const size_t item = ((size_t)s.m * s.k + (size_t)s.k * s.n + (size_t)s.m * s.n) * s.typesize;
     if (item < 6000) while (pack < 16 && 2 * pack * item <= 16384) pack *= 2;
+    // items up to ~13 KB that do not end on a 128-byte line: two at a time, so that a line is not fetched by two waves (with
+    // deferred stores, profiles/r2_sweep_pack.txt: f32 23^3 62.1 -> 63.4 %, f32 13x23x32 61.2 -> 63.6 %, f64 13x23x32 65.1 -> 66.5 %)
+    else if (item < 14000 && 0 != item % 128) pack = 2;
   }
   if (pack > 16) pack = 16;
   while (0 != (pack & (pack - 1))) --pack; // power of two
   // operands of `pack` items in flight per lane (registers) and in LDS
-  while (1 < pack && ((size_t)pack * ((size_t)s.m * s.k + (size_t)s.k * s.n + (size_t)s.m * s.n) * s.typesize > 24576
+  while (1 < pack && ((size_t)pack * ((size_t)s.m * s.k + (size_t)s.k * s.n + (size_t)s.m * s.n) * s.typesize > 28672
                    || 0 == smm_jit_waves(s.typesize, s.m, s.n, s.k, s.flags, pack))) pack /= 2;
   return pack;
 }

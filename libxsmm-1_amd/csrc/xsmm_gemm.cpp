@@ -447,6 +447,7 @@ SmmBatch lowp_from_descriptor(const libxsmm_gemm_descriptor& d, float scf)
   s.scf = scf; s.typesize = 2;
   s.m = (int)d.m; s.n = (int)d.n; s.k = (int)d.k; s.lda = (int)d.lda; s.ldb = (int)d.ldb; s.ldc = (int)d.ldc;
   s.flags = d.flags & LIBXSMM_GEMM_FLAG_BETA_0;
+  s.use_mfma = libxsmm_amd_get_mfma();
   return s;
 }
 

@@ -779,8 +779,29 @@ constexpr int cstride() { int s = M; for (;; s += VEC) { if (F64 ? (16 == s % 32
 constexpr int CSD = cstride();
 constexpr int C_ELEMS = N * CSD;
 constexpr int A_ELEMS = (C_ELEMS > K * MS) ? C_ELEMS : K * MS, B_ELEMS = N * KSD;
-constexpr int CA = (M * K / VEC + 63) / 64, CB = (K * N / VEC + 63) / 64, CC = (M * N / VEC + 63) / 64;
+#if XLOWP
+// bf16 inputs (XLOWP 3: fp32 result, 2: bf16 result) as the reference's low-precision kernels store them: A in pairs of k
+// (a[(k/2)*M*2 + m*2 + k%2]), B column-major -- both sequences of 32-bit k pairs. A 16-byte chunk is four pairs (A: four
+// rows m of one pair of k; B: eight consecutive k of one column); the halves are widened on the way into the same fp32 LDS
+// images (a bf16 product is exact in fp32, so fma(a, b, acc) is the gold loop's product-then-add, samples/xgemm/kernel.c).
+typedef unsigned UV __attribute__((ext_vector_type(4)));
+constexpr int NCA = M * K / 8, NCB = K * N / 8;                    // chunks per operand
+constexpr int NCC = (2 == XLOWP) ? (M * N / 8) : (M * N / 4);
+static_assert(0 == M % 4 && 0 == K % 8 && (2 != XLOWP || 0 == M % 8), "shape");
+__device__ __forceinline__ V widen_lo(UV p) { return V{ __uint_as_float(p[0] << 16), __uint_as_float(p[1] << 16), __uint_as_float(p[2] << 16), __uint_as_float(p[3] << 16) }; }
+__device__ __forceinline__ V widen_hi(UV p) { return V{ __uint_as_float(p[0] & 0xFFFF0000u), __uint_as_float(p[1] & 0xFFFF0000u), __uint_as_float(p[2] & 0xFFFF0000u), __uint_as_float(p[3] & 0xFFFF0000u) }; }
+// eight consecutive bf16 (four pairs) as two vectors of four floats in memory order
+__device__ __forceinline__ void widen8(UV p, V& v0, V& v1)
+{
+  v0 = V{ __uint_as_float(p[0] << 16), __uint_as_float(p[0] & 0xFFFF0000u), __uint_as_float(p[1] << 16), __uint_as_float(p[1] & 0xFFFF0000u) };
+  v1 = V{ __uint_as_float(p[2] << 16), __uint_as_float(p[2] & 0xFFFF0000u), __uint_as_float(p[3] << 16), __uint_as_float(p[3] & 0xFFFF0000u) };
+}
+#else
+constexpr int NCA = M * K / VEC, NCB = K * N / VEC, NCC = M * N / VEC;
+typedef V UV;
 static_assert(0 == M % VEC && 0 == K % 4, "shape");
+#endif
+constexpr int CA = (NCA + 63) / 64, CB = (NCB + 63) / 64, CC = (NCC + 63) / 64;
 __device__ __forceinline__ int clampi(int v, int hi) { return v < hi ? v : hi; }
 // row of C a lane's accumulator register r belongs to (the fp32 and fp64 instructions differ)
 #define XNROW(r) (F64 ? (lq + 4 * (r)) : (4 * lq + (r)))
@@ -794,26 +815,35 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(X
   T* const dummy = Bs + B_ELEMS;         // a word per lane for the writes of lanes outside C
   const int lane = threadIdx.x, l16 = lane & 15, lq = lane >> 4;
   (void)runlen;
-  V ra[CA], rb[CB], rc[CC];
+  UV ra[CA], rb[CB], rc[CC]; // (strides of the batch are in 32-bit words: the host halves those of 16-bit operands)
   auto load_ab = [&](long long item) {
-    const XGLOBAL V* const pa = (const XGLOBAL V*)resolve<const T>(ad.a, ad.ia, ad.sa, ad, item);
-    const XGLOBAL V* const pb = (const XGLOBAL V*)resolve<const T>(ad.b, ad.ib, ad.sb, ad, item);
+    const XGLOBAL UV* const pa = (const XGLOBAL UV*)resolve<const T>(ad.a, ad.ia, ad.sa, ad, item);
+    const XGLOBAL UV* const pb = (const XGLOBAL UV*)resolve<const T>(ad.b, ad.ib, ad.sb, ad, item);
 #pragma unroll
-    for (int j = 0; j < CA; ++j) ra[j] = __builtin_nontemporal_load(pa + clampi(64 * j + lane, M * K / VEC - 1));
+    for (int j = 0; j < CA; ++j) ra[j] = __builtin_nontemporal_load(pa + clampi(64 * j + lane, NCA - 1));
 #pragma unroll
-    for (int j = 0; j < CB; ++j) rb[j] = __builtin_nontemporal_load(pb + clampi(64 * j + lane, K * N / VEC - 1));
+    for (int j = 0; j < CB; ++j) rb[j] = __builtin_nontemporal_load(pb + clampi(64 * j + lane, NCB - 1));
   };
   auto load_c = [&](long long item) {
-    const XGLOBAL V* const pc = (const XGLOBAL V*)resolve<const T>(ad.c, ad.ic, ad.sc, ad, item);
+    const XGLOBAL UV* const pc = (const XGLOBAL UV*)resolve<const T>(ad.c, ad.ic, ad.sc, ad, item);
 #pragma unroll
-    for (int j = 0; j < CC; ++j) rc[j] = __builtin_nontemporal_load(pc + clampi(64 * j + lane, M * N / VEC - 1));
+    for (int j = 0; j < CC; ++j) rc[j] = __builtin_nontemporal_load(pc + clampi(64 * j + lane, NCC - 1));
   };
   auto store_c = [&](long long item) { // the image of C -> memory, whole lines
-    XGLOBAL V* const pc = (XGLOBAL V*)resolve<T>(ad.c, ad.ic, ad.sc, ad, item);
+    XGLOBAL UV* const pc = (XGLOBAL UV*)resolve<T>(ad.c, ad.ic, ad.sc, ad, item);
 #pragma unroll
     for (int j = 0; j < CC; ++j) {
-      const int ch = clampi(64 * j + lane, M * N / VEC - 1), e = ch * VEC, n = e / M, m = e % M;
-      __builtin_nontemporal_store(*reinterpret_cast<const V*>(Cs + n * CSD + m), pc + ch);
+      const int ch = clampi(64 * j + lane, NCC - 1);
+#if (2 == XLOWP)
+      const int e = ch * 8, n = e / M, m = e % M; // a bf16 result is the upper half of the float sum (truncation, as the harness does)
+      const V v0 = *reinterpret_cast<const V*>(Cs + n * CSD + m), v1 = *reinterpret_cast<const V*>(Cs + n * CSD + m + 4);
+      const UV w = UV{ (__float_as_uint(v0[0]) >> 16) | (__float_as_uint(v0[1]) & 0xFFFF0000u), (__float_as_uint(v0[2]) >> 16) | (__float_as_uint(v0[3]) & 0xFFFF0000u),
+                       (__float_as_uint(v1[0]) >> 16) | (__float_as_uint(v1[1]) & 0xFFFF0000u), (__float_as_uint(v1[2]) >> 16) | (__float_as_uint(v1[3]) & 0xFFFF0000u) };
+      __builtin_nontemporal_store(w, pc + ch);
+#else
+      const int e = ch * VEC, n = e / M, m = e % M;
+      __builtin_nontemporal_store(*reinterpret_cast<const UV*>(Cs + n * CSD + m), pc + ch);
+#endif
     }
   };
   long long item = blockIdx.x, prev = -1;
@@ -827,8 +857,15 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(X
     if (!XBETA0) {
 #pragma unroll
       for (int j = 0; j < CC; ++j) {
-        const int ch = clampi(64 * j + lane, M * N / VEC - 1), e = ch * VEC, n = e / M, m = e % M;
-        *reinterpret_cast<V*>(Cs + n * CSD + m) = rc[j];
+        const int ch = clampi(64 * j + lane, NCC - 1);
+#if (2 == XLOWP)
+        const int e = ch * 8, n = e / M, m = e % M;
+        V v0, v1; widen8(rc[j], v0, v1);
+        *reinterpret_cast<V*>(Cs + n * CSD + m) = v0; *reinterpret_cast<V*>(Cs + n * CSD + m + 4) = v1;
+#else
+        const int e = ch * VEC, n = e / M, m = e % M;
+        *reinterpret_cast<UV*>(Cs + n * CSD + m) = rc[j];
+#endif
       }
       wave_lds_sync();
 #pragma unroll
@@ -850,13 +887,27 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(X
     }
 #pragma unroll
     for (int j = 0; j < CA; ++j) {
-      const int ch = clampi(64 * j + lane, M * K / VEC - 1), e = ch * VEC, k = e / M, m = e % M;
+      const int ch = clampi(64 * j + lane, NCA - 1);
+#if XLOWP
+      const int w = ch * 4, sp = w / M, m = w % M, k0 = 2 * sp, k1 = 2 * sp + 1; // four rows of the k pair (2 sp, 2 sp + 1)
+      *reinterpret_cast<V*>(As + k0 * MS + (ASWZ ? (m ^ ((k0 & 3) << 4)) : m)) = widen_lo(ra[j]);
+      *reinterpret_cast<V*>(As + k1 * MS + (ASWZ ? (m ^ ((k1 & 3) << 4)) : m)) = widen_hi(ra[j]);
+#else
+      const int e = ch * VEC, k = e / M, m = e % M;
       *reinterpret_cast<V*>(As + k * MS + (ASWZ ? (m ^ ((k & 3) << 4)) : m)) = ra[j];
+#endif
     }
 #pragma unroll
     for (int j = 0; j < CB; ++j) {
-      const int ch = clampi(64 * j + lane, K * N / VEC - 1), e = ch * VEC, n = e / K, k = e % K;
+      const int ch = clampi(64 * j + lane, NCB - 1);
+#if XLOWP
+      const int e = ch * 8, n = e / K, k = e % K; // eight consecutive k of column n
+      V v0, v1; widen8(rb[j], v0, v1);
+      *reinterpret_cast<V*>(Bs + n * KSD + k) = v0; *reinterpret_cast<V*>(Bs + n * KSD + k + 4) = v1;
+#else
+      const int e = ch * VEC, n = e / K, k = e % K;
       *reinterpret_cast<V*>(Bs + n * KSD + k) = rb[j];
+#endif
     }
     const long long next = item + gridDim.x;
     if (next < batch) { load_ab(next); if (!XBETA0) load_c(next); }
@@ -1616,6 +1667,37 @@ int launch_smm_jit_lowp(const SmmBatch& s, void* stream, const char** name)
   if (nullptr != env_jit && 0 == atoi(env_jit)) return -1;
   if ((1 != s.lowp && 3 != s.lowp && 4 != s.lowp) || ADDR_STRIDED != s.mode || 0 != (s.flags & LIBXSMM_GEMM_FLAG_TRANS_B)) return -1;
   if (4 == s.lowp && 0 != (s.m & 1)) return -1;
+  { // bf16 inputs beyond 32: the one-wave-per-item matrix-core kernel (fp32 instruction on the widened operands: the gold
+    // loop's product-then-add bit for bit)
+    static const int wave_on = []() { const char* e = getenv("XSMM_SMMJIT_MFMA_WAVE"); return (nullptr != e && 0 != *e) ? atoi(e) : 1; }();
+    static const int wave_min = []() { const char* e = getenv("XSMM_SMMJIT_LOWP_WAVE_MIN"); return (nullptr != e && 0 != *e) ? atoi(e) : 31; }(); // developer knob (32^3: 73.8 vs 67.9 % for the fp32 result, 67.9 vs 49.5 % for bf16; 16^3 is better off on the streaming form)
+    const size_t wlds = smm_mfma_wave_lds(4, s.m, s.n, s.k);
+    const uintptr_t bits = reinterpret_cast<uintptr_t>(s.a) | reinterpret_cast<uintptr_t>(s.b) | reinterpret_cast<uintptr_t>(s.c)
+                         | (uintptr_t)(s.sa * 2) | (uintptr_t)(s.sb * 2) | (uintptr_t)(s.sc * (4 == s.lowp ? 2 : 4));
+    const char* const env_min = getenv("LIBXSMM_AMD_JIT_MINBATCH");
+    if (0 != wave_on && 0 != s.use_mfma && (3 == s.lowp || 4 == s.lowp) && (wave_min < s.m || wave_min < s.n) && 0 != wlds && 4 * wlds <= 160u * 1024u
+      && 0 == (s.k & 7) && (3 == s.lowp || 0 == (s.m & 7)) && 0 == (bits & 15) && s.lda == s.m && s.ldb == s.k && s.ldc == s.m
+      && s.batch >= ((nullptr != env_min && 0 != *env_min) ? atoll(env_min) : 1024LL))
+    {
+      const SmmKey wkey = { 4, s.m, s.n, s.k, s.flags & LIBXSMM_GEMM_FLAG_BETA_0, SMM_JIT_MFMA_WAVE | ((4 == s.lowp ? 2 : 3) << 11), s.lda, s.ldb, s.ldc };
+      JitKernel* const wk = smm_jit_get(wkey);
+      if (nullptr != wk) {
+        struct { const char* a; const char* b; char* c; const char* ia; const char* ib; const char* ic; long long sa, sb, sc; int index_base, index_stride, mode; const int* flags; } wad;
+        wad.a = (const char*)s.a; wad.b = (const char*)s.b; wad.c = (char*)s.c; wad.ia = wad.ib = wad.ic = nullptr;
+        wad.sa = s.sa / 2; wad.sb = s.sb / 2; wad.sc = (4 == s.lowp ? s.sc / 2 : s.sc); // in 32-bit words
+        wad.index_base = 0; wad.index_stride = 0; wad.mode = 0; wad.flags = nullptr;
+        long long wbatch = s.batch; int one = 1;
+        int per_cu = (int)((160u * 1024u) / wlds);
+        const int by_regs = 4 * smm_mfma_wave_wpe(wlds);
+        if (per_cu > by_regs) per_cu = by_regs;
+        long long wblocks = 256LL * per_cu;
+        if (wblocks > s.batch) wblocks = s.batch;
+        void* wargs[] = { &wad, &wbatch, &one };
+        *name = (4 == s.lowp) ? "smm_bf16_mfma_wave_jit_lowp" : "smm_bf16f32_mfma_wave_jit_lowp";
+        return jit_launch_dyn(wk, (unsigned)wblocks, 64u, (unsigned)wlds, wargs, stream);
+      }
+    }
+  }
   if (s.m > 32 || s.n > 32 || s.k > 64 || 0 != (s.k & 1) || s.lda != s.m || s.ldb != s.k || s.ldc != s.m) return -1;
   if (s.sa != (long long)s.m * s.k || s.sb != (long long)s.k * s.n || s.sc != (long long)s.m * s.n) return -1;
   const char* const env_min = getenv("LIBXSMM_AMD_JIT_MINBATCH");

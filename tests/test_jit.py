@@ -46,6 +46,13 @@ def test_generated_sources_compile_for_gfx950(xs):
                 blob, d = xs.descriptor(prec, m, n, k, beta=beta)
                 assert 0 == L.libxsmm_amd_smm_kernel_source(d, 16384, buf, len(buf), 1), (prec, m, n, k, beta)
                 assert "xmfma" in buf.value.decode() and "#define XWPE" in buf.value.decode()
+    # ... and its bf16-input forms (variant bits 11..12: 2 = bf16 result, 3 = fp32 result)
+    for (m, n, k) in [(48, 48, 48), (64, 40, 56), (16, 64, 8)]:
+        for beta in (1.0, 0.0):
+            blob, d = xs.descriptor(xs.F32, m, n, k, beta=beta)
+            for lowp in (2, 3):
+                assert 0 == L.libxsmm_amd_smm_kernel_source(d, 16384 | (lowp << 11), buf, len(buf), 1), (m, n, k, beta, lowp)
+                assert "#define XLOWP %d\n" % lowp in buf.value.decode() and "widen8" in buf.value.decode()
     # several consecutive items per wave (variant bits 8..10 = log2 of the count): small and oddly sized shapes of tight strided batches
     for prec in (xs.F64, xs.F32):
         for (m, n, k), packs in (((5, 5, 5), (1, 2, 3, 4)), ((8, 8, 8), (1, 2)), ((13, 13, 13), (1, 2)), ((23, 23, 23), (1,)), ((5, 7, 3), (3,))):

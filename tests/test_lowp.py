@@ -218,3 +218,53 @@ def test_low_precision_batches(xs, orc, torch_gpu, kind):
     assert xs.last_kernel().endswith("_lowp")
     got = dc.cpu().numpy(); got = got.view(np.uint16) if kind == 3 else got
     assert np.array_equal(got.view(np.uint8), ref2.view(np.uint8))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", [2, 3])
+@pytest.mark.parametrize("shape", [(48, 48, 48), (64, 40, 56), (64, 64, 64), (16, 64, 8), (40, 33, 16)])
+def test_low_precision_wave_kernel(xs, orc, torch_gpu, kind, shape):
+    """bf16 inputs beyond 32 on the one-wave-per-item matrix-core kernel (csrc/xsmm_jit_smm.cpp, SMM_JIT_MFMA_WAVE_BODY with
+    XLOWP): the fp32 instruction on the widened operands is the gold loop's product-then-add (samples/xgemm/kernel.c:1104-1123,
+    1207-1229) bit for bit; a bf16 result is truncated once. Strided batches smaller and larger than the resident grid."""
+    import os
+    torch = torch_gpu
+    L = xs.lib()
+    m, n, k = shape
+    if kind == 3 and m % 16:
+        pytest.skip("a bf16 result needs m % 16 == 0 (reference rule)")
+    blob = xs.DescriptorBlob()
+    L.libxsmm_gemm_descriptor_dinit2.restype = C.c_void_p
+    L.libxsmm_gemm_descriptor_dinit2.argtypes = [C.c_void_p] + [C.c_int] * 8 + [C.c_double, C.c_double, C.c_int, C.c_int]
+    ip, op = {2: (xs.BF16, xs.F32), 3: (xs.BF16, xs.BF16)}[kind]
+    old_env = os.environ.get("LIBXSMM_AMD_JIT_MINBATCH")
+    os.environ["LIBXSMM_AMD_JIT_MINBATCH"] = "1"
+    old_mfma = L.libxsmm_amd_set_mfma(1)
+    try:
+        for beta0 in (0, 1):
+            desc = L.libxsmm_gemm_descriptor_dinit2(C.byref(blob), ip, op, m, n, k, m, k, m, 1.0, 0.0 if beta0 else 1.0, 0, 0)
+            assert desc
+            for batch in (1, 5, 2500):
+                rng = np.random.default_rng(11 * batch + m + k + kind)
+                a = _bf16(rng.uniform(-1, 1, batch * m * k)); b = _bf16(rng.uniform(-1, 1, batch * k * n))
+                c = rng.uniform(-1, 1, batch * m * n).astype(np.float32) if kind == 2 else _bf16(rng.uniform(-1, 1, batch * m * n))
+                ref = c.copy()
+                for i in range(batch):
+                    assert 0 == orc.gemm_lowp(kind, beta0, m, n, k, m, k, m, a[i * m * k:(i + 1) * m * k], b[i * k * n:(i + 1) * k * n], ref[i * m * n:(i + 1) * m * n], 1.0)
+                if beta0 and kind == 2:
+                    c[:] = np.nan
+                da, db = (torch.from_numpy(x.view(np.int16)).cuda() for x in (a, b))
+                dc = torch.from_numpy(c.view(np.int16) if kind == 3 else c).cuda()
+                assert 0 == L.libxsmm_amd_gemm_batch_strided(C.c_void_p(desc), da.data_ptr(), db.data_ptr(), dc.data_ptr(), m * k, k * n, m * n, batch)
+                torch.cuda.synchronize()
+                wave = (max(m, n) > 32 and k % 8 == 0 and m % (8 if kind == 3 else 4) == 0)
+                assert xs.last_kernel() == (("smm_bf16_mfma_wave_jit_lowp" if kind == 3 else "smm_bf16f32_mfma_wave_jit_lowp") if wave else xs.last_kernel()), xs.last_kernel()
+                assert xs.last_kernel().endswith("_lowp")
+                got = dc.cpu().numpy(); got = got.view(np.uint16) if kind == 3 else got
+                assert np.array_equal(got.view(np.uint8), ref.view(np.uint8)), (beta0, batch)
+    finally:
+        L.libxsmm_amd_set_mfma(old_mfma)
+        if old_env is None:
+            os.environ.pop("LIBXSMM_AMD_JIT_MINBATCH", None)
+        else:
+            os.environ["LIBXSMM_AMD_JIT_MINBATCH"] = old_env

@@ -76,7 +76,7 @@ def run_lowp(kind, m, n, k):
 
 if which == "lowp":
     for kind in ("bf16f32", "i16i32", "bf16"):
-        for (m, n, k) in ((32, 32, 32), (16, 16, 16), (64, 64, 64)):
+        for (m, n, k) in ((32, 32, 32), (16, 16, 16), (48, 48, 48), (64, 64, 64)):
             run_lowp(kind, m, n, k)
     sys.exit(0)
 

@@ -82,7 +82,8 @@ def build(verbose=False):
 
 # shapes whose code objects build() leaves in lib/jit_cache (they travel with the library): the BASELINE configurations
 PREBUILD_F64 = [(m, n, k) for m in (13, 23, 32) for n in (13, 23, 32) for k in (13, 23, 32)]  # config 1 and 5 (CP2K stacks: also grouped)
-PREBUILD_F32 = [(32, 32, 32), (23, 23, 23), (13, 13, 13)]
+PREBUILD_F64 += [(40, 40, 40), (48, 48, 48), (56, 56, 56), (64, 64, 64)]  # shapes beyond 32: matrix-core forms
+PREBUILD_F32 = [(32, 32, 32), (23, 23, 23), (13, 13, 13), (40, 40, 40), (48, 48, 48), (56, 56, 56), (64, 64, 32)]
 
 
 def prebuild_kernels(verbose=False):

@@ -95,7 +95,8 @@ constexpr int VA = XSCALAR ? 1 : vw(AE), VB = XSCALAR ? 1 : vw(BE), VC = (XSCALA
 constexpr int NLA = (AE + UT * VA - 1) / (UT * VA), NLB = (BE + UT * VB - 1) / (UT * VB), NLC = (CE + UT * VC - 1) / (UT * VC);
 // LDS strides: A as [k][M] (lanes with equal ty read the same words, lanes with different tx adjacent ones);
 // B as [n][KP] (TRANS_B: [k][N]) with KP chosen so that the column groups of one instruction fall into different banks
-constexpr int pick_kp() { int kp = K; while (0 == (TN * kp * (TS / 4)) % 16) ++kp; return kp; }
+// (TN * TS / 4 a multiple of 16 -- fp64, eight columns per lane -- has no such stride: an odd one then)
+constexpr int pick_kp() { if (0 == (TN * (TS / 4)) % 16) return K | 1; int kp = K; while (0 == (TN * kp * (TS / 4)) % 16) ++kp; return kp; }
 constexpr int KP = pick_kp();
 constexpr int AS1 = ((K * M + TGM * TM + 3) / 4) * 4;                 // per item
 constexpr int BS1 = XTRANSB ? (((K * N + NPAD + 3) / 4) * 4) : ((NPAD * KP + 3) / 4) * 4;
@@ -1255,7 +1256,7 @@ static size_t smm_jit_wave_lds(int typesize, int m, int n, int k, int flags, int
 {
   const int tgm = (pack >= 4) ? ((pack >= 16) ? 2 : 4) : 8, tgn = 64 / (pack * tgm);
   const int tm = (m + tgm - 1) / tgm, tn = (n + tgn - 1) / tgn;
-  int kp = k; while (0 == (tn * kp * (typesize / 4)) % 16) ++kp;
+  int kp = k; if (0 == (tn * (typesize / 4)) % 16) kp = k | 1; else while (0 == (tn * kp * (typesize / 4)) % 16) ++kp;
   const size_t as = ((size_t)(k * m + tgm * tm + 3) / 4) * 4;
   const size_t bs = (flags & LIBXSMM_GEMM_FLAG_TRANS_B) ? (((size_t)(k * n + tgn * tn + 3) / 4) * 4) : ((((size_t)tgn * tn) * kp + 3) / 4) * 4;
   const size_t cs = ((size_t)(pack * m * n + 3) / 4) * 4;
@@ -1305,7 +1306,7 @@ bool smm_jit_eligible(const SmmBatch& s)
 static size_t smm_jit_wg_buf(int typesize, int m, int n, int k, int flags)
 {
   const int nq = (n + 3) / 4, tm = (m + 15) / 16, tn = (nq + 3) / 4, npad = 3 * nq + 4 * tn;
-  int kp = k; while (0 == (tn * kp * (typesize / 4)) % 16) ++kp;
+  int kp = k; if (0 == (tn * (typesize / 4)) % 16) kp = k | 1; else while (0 == (tn * kp * (typesize / 4)) % 16) ++kp;
   const size_t as = ((size_t)(k * m + 16 * tm + 3) / 4) * 4;
   const size_t bs = (flags & LIBXSMM_GEMM_FLAG_TRANS_B) ? (((size_t)(k * n + npad + 3) / 4) * 4) : (((size_t)npad * kp + 3) / 4) * 4;
   return (as + bs) * typesize;
@@ -1782,7 +1783,20 @@ int smm_jit_prebuild(const SmmBatch* shapes, int nshapes, int grouped, int* buil
     if (!smm_jit_eligible(s)) continue;
     const int flags = s.flags & (LIBXSMM_GEMM_FLAG_BETA_0 | LIBXSMM_GEMM_FLAG_TRANS_B);
     auto one = [&](int variant) { build(gen_smm_source(s.typesize, s.m, s.n, s.k, flags, variant, s.lda, s.ldb, s.ldc)); };
-    if (s.m > 32 || s.n > 32 || s.k > 64) { one(SMM_JIT_BIG); continue; }
+    if (s.m > 32 || s.n > 32 || s.k > 64) {
+      one(SMM_JIT_BIG);
+      if (s.m <= 64 && s.n <= 64 && s.k <= 64 && 0 == (flags & LIBXSMM_GEMM_FLAG_TRANS_B)) { // the matrix-core forms launch_smm_jit_mfma would pick
+        const size_t wlds = smm_mfma_wave_lds(s.typesize, s.m, s.n, s.k);
+        const bool f64 = (8 == s.typesize);
+        if (0 != wlds && 4 * wlds <= 160u * 1024u && s.lda == s.m && s.ldb == s.k && s.ldc == s.m) one(SMM_JIT_MFMA_WAVE);
+        else if (!(!f64 && 64 == s.m && 64 == s.n && 64 == s.k && 64 == s.lda && 64 == s.ldb && 64 == s.ldc)) {
+          const bool tight = !f64 && s.lda == s.m && s.ldb == s.k && 0 == ((s.m * s.k) & 3) && 0 == ((s.k * s.n) & 3);
+          const bool tightc = !f64 && s.ldc == s.m && 0 == ((s.m * s.n) & 3) && 0 != (s.m & 31);
+          one(SMM_JIT_MFMA | (tight ? SMM_JIT_MFMA_TIGHT : 0) | (tightc ? SMM_JIT_MFMA_TIGHTC : 0));
+        }
+      }
+      continue;
+    }
     // strided batches: the wide flavour with the pack the launcher would choose, and the element-wide flavour for the remainder
     SmmBatch t = s; t.mode = ADDR_STRIDED; t.sa = (long long)s.m * s.k; t.sb = (long long)s.k * s.n; t.sc = (long long)s.m * s.n;
     const int pack = smm_jit_pack(t, 0);

@@ -55,7 +55,8 @@ def test_generated_sources_compile_for_gfx950(xs):
                 assert "#define XLOWP %d\n" % lowp in buf.value.decode() and "widen8" in buf.value.decode()
     # several consecutive items per wave (variant bits 8..10 = log2 of the count): small and oddly sized shapes of tight strided batches
     for prec in (xs.F64, xs.F32):
-        for (m, n, k), packs in (((5, 5, 5), (1, 2, 3, 4)), ((8, 8, 8), (1, 2)), ((13, 13, 13), (1, 2)), ((23, 23, 23), (1,)), ((5, 7, 3), (3,))):
+        for (m, n, k), packs in (((5, 5, 5), (1, 2, 3, 4)), ((8, 8, 8), (1, 2)), ((13, 13, 13), (1, 2)), ((23, 23, 23), (1,)), ((5, 7, 3), (3,)),
+                                ((13, 32, 13), (1, 2)), ((23, 32, 13), (1,))):  # (fp64, eight columns per lane: the stride search for B's image must end)
             for beta, flags in ((1.0, 0), (0.0, xs.FLAG_TRANS_B)):
                 blob, d = xs.descriptor(prec, m, n, k, beta=beta, flags=flags)
                 for lg in packs:

@@ -297,9 +297,11 @@ def secondary(torch, xs, L):
     res["cp2k_stacks_f64_27shapes"]["relaxed_order"] = {"kernel": xs.last_kernel(), "ms": round(mo * 1e3, 4), "hbm_gbs": round(byt / mo / 1e9, 1), "frac": round(byt / mo / 1e9 / HBM_PEAK_GBS, 4)}
     # the upper end of the (M,N,K) <= 64 family: strided batches of 64^3 on the matrix-core work-group kernels
     L.libxsmm_amd_set_mfma(1)
-    for (name, dt, prec, ts) in (("smm_f32_64x64x64", torch.float32, xs.F32, 4), ("smm_f64_64x64x64", torch.float64, xs.F64, 8)):
-        m = n = k = 64
-        B64 = 65536 if ts == 4 else 32768
+    # ... and, between 32 and 64, the one-wave-per-item matrix-core kernel (48^3)
+    for (name, dt, prec, ts, mnk) in (("smm_f32_64x64x64", torch.float32, xs.F32, 4, 64), ("smm_f64_64x64x64", torch.float64, xs.F64, 8, 64),
+                                      ("smm_f32_48x48x48", torch.float32, xs.F32, 4, 48), ("smm_f64_48x48x48", torch.float64, xs.F64, 8, 48)):
+        m = n = k = mnk
+        B64 = (65536 if ts == 4 else 32768) * (64 // mnk) ** 2
         a = torch.rand(B64 * m * k, device="cuda", dtype=dt, generator=g) - 0.5
         b = torch.rand(B64 * k * n, device="cuda", dtype=dt, generator=g) - 0.5
         c = torch.zeros(B64 * m * n, device="cuda", dtype=dt)
@@ -307,6 +309,7 @@ def secondary(torch, xs, L):
 
         def dense64():
             assert 0 == L.libxsmm_amd_gemm_batch_strided(desc, xs.dptr(a), xs.dptr(b), xs.dptr(c), m * k, k * n, m * n, B64)
+        dense64(); L.libxsmm_amd_jit_wait()
         _, td = time_steps(torch, dense64, 5, 2, None)
         md = sum(td) / len(td) * 1e-3
         byt64 = B64 * float(ts) * (m * k + k * n + 2 * m * n)

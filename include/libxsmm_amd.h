@@ -153,6 +153,12 @@ LIBXSMM_API int libxsmm_amd_smm_grouped_kernel_source(const libxsmm_gemm_descrip
  *  fused kernel of libxsmm_amd_gemm_batch_groups over all of them) into the cache directory (LIBXSMM_AMD_CACHE, default
  *  jit_cache/ next to the library); returns the number of code objects now present, or -(number of failures). */
 LIBXSMM_API void libxsmm_amd_jit_wait(void);
+/** Drops the compile jobs that have not started and waits for the one that is running. A process must not reach exit() while
+ *  the helper thread is inside the compiler: the compiler's static objects, first constructed during that very job, are
+ *  destroyed ahead of any exit handler this library could have registered earlier. libxsmm_finalize() calls it (the
+ *  reference's callers end with libxsmm_finalize), the Python binding calls it from Python's own atexit; an exit handler of
+ *  the library remains as the last line of defence. */
+LIBXSMM_API void libxsmm_amd_jit_drain(void);
 LIBXSMM_API int libxsmm_amd_jit_prebuild(const libxsmm_gemm_descriptor* const descriptors[], int ndescriptors, int grouped);
 
 /** Executable form of the sparse text kernels (libxsmm_generator_spgemm_{csr,csc}_kernel): the pattern is compiled into

@@ -123,6 +123,8 @@ def lib():
         L = C.CDLL(LIB_PATH)
         _declare(L)
         _lib = L
+        import atexit
+        atexit.register(L.libxsmm_amd_jit_drain)  # before the interpreter goes: see include/libxsmm_amd.h
     return _lib
 
 
@@ -264,6 +266,7 @@ def _declare(L):
     sig("libxsmm_amd_smm_grouped_kernel_source", i, C.POINTER(vp), i, vp, C.c_size_t, i)
     sig("libxsmm_amd_jit_prebuild", i, C.POINTER(vp), i, i)
     sig("libxsmm_amd_jit_wait", None)
+    sig("libxsmm_amd_jit_drain", None)
     sig("libxsmm_amd_gemm_batch_groups", i, i, i, i, C.c_char_p, C.c_char_p, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p, vp, vp,
         C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i, i, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), c_int_p, i)
 

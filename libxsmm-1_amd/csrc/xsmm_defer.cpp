@@ -228,6 +228,9 @@ void defer_flush()
 bool defer_call(Kernel* k, const void* a, const void* b, void* c)
 {
   if (!defer_enabled() || nullptr == k || KC_DENSE != k->kclass) return false;
+  // small products only (the reference's own JIT domain, LIBXSMM_MAX_MNK = 64^3): a large product is a launch -- or a library
+  // GEMM -- of its own that spreads over the chip
+  if ((long long)k->desc.m * k->desc.n * k->desc.k > 64LL * 64 * 64 || k->desc.m > 128 || k->desc.n > 128) return false;
   Ring* const rp = my_ring();
   if (nullptr == rp) return false;
   Ring& r = *rp;

@@ -1042,6 +1042,7 @@ LIBXSMM_API int libxsmm_amd_jit_prebuild(const libxsmm_gemm_descriptor* const de
 }
 
 LIBXSMM_API void libxsmm_amd_jit_wait(void) { jit_async_wait(); }
+LIBXSMM_API void libxsmm_amd_jit_drain(void) { jit_async_drain(); }
 
 // ---- measurement aid -----------------------------------------------------------------------------------------------
 namespace xsmm { int launch_stream_abc(const void* a, const void* b, void* c, long long bytes, void* stream); }

@@ -112,7 +112,8 @@ JitKernel* jit_from_cache(const std::string& src, const char* fname); // only if
 int jit_build_offline(const std::string& src, std::string* log);      // compile into the cache on disk (no device needed); 0: there
 bool jit_async_enabled();                                             // LIBXSMM_AMD_JIT_ASYNC (default on)
 void jit_async(std::function<void()> job);                            // run on the compiler thread
-void jit_async_wait();                                                // until the compiler thread has nothing left to do
+void jit_async_wait();
+void jit_async_drain(); // drop queued compile jobs, wait for the running one                                                // until the compiler thread has nothing left to do
 int jit_check_source(const std::string& src, std::string* log);
 void jit_release(JitKernel* k);
 int jit_launch_panels(JitKernel* k, const void* B, void* C, long long ncols, long long ldb, long long ldc, int vec, void* stream);

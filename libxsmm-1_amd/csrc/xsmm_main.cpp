@@ -227,6 +227,7 @@ LIBXSMM_API void libxsmm_finalize(void)
 { // kernels stay valid until process exit in this implementation (the reference releases the registry);
   // finalize only drains the stream so that results are complete.
   if (device_ready()) (void)stream_sync();
+  jit_async_drain(); // (a process on its way out must not leave the helper thread inside the compiler, see libxsmm_amd_jit_drain)
 }
 
 __attribute__((constructor)) static void xsmm_ctor(void) { libxsmm_init(); } // LIBXSMM_ATTRIBUTE_CTOR (src/libxsmm_main.c:708)

@@ -1,0 +1,12 @@
+#!/bin/bash
+# Round-2 additions to the evidence: PMC passes of the dense matrix-core kernels and of the reference-API spmdm path,
+# per-call bursts, and the callers either side of the hot path (re-run).
+cd "$GRAFT_REPO_ROOT" || exit 1
+export TMPDIR=/tmp
+timeout -k 10 500 bash tools/pmc_dense_mfma.sh > /dev/null 2>&1
+timeout -k 10 300 bash tools/pmc_spmdm_api.sh > /dev/null 2>&1
+gcc -O2 -I include tools/bench_calls.c -o /tmp/bench_calls -L libxsmm-1_amd/lib -lxsmm -Wl,-rpath,$PWD/libxsmm-1_amd/lib &&
+ (timeout -k 10 120 /tmp/bench_calls; echo "--- LIBXSMM_AMD_DEFER=0 (a launch per call) ---"; LIBXSMM_AMD_DEFER=0 timeout -k 10 120 /tmp/bench_calls) > gpurun_out/bench_calls.txt 2>&1
+(timeout -k 10 200 python3 tools/bench_gemm_single.py 256 1024 2048 4096; LIBXSMM_AMD_BLAS=0 timeout -k 10 200 python3 tools/bench_gemm_single.py 2048) 2>&1 | grep -v amdgpu.ids > gpurun_out/gemm_single.txt
+timeout -k 10 300 python bench.py --steps 10 --warmup 2 > gpurun_out/bench_n1.json 2> gpurun_out/bench_n1.err
+tail -n 6 gpurun_out/dense_mfma_pmc.txt; cat gpurun_out/gemm_single.txt gpurun_out/bench_calls.txt

@@ -90,6 +90,36 @@ __global__ __launch_bounds__(256) void smm_lowp_kernel(DevAddr ad, int m, int n,
   }
 }
 
+// Batch-reduce form of the bf16 kernels (libxsmm_bsmmdispatch_reducebatch / libxsmm_bmmdispatch_reducebatch,
+// src/libxsmm_main.c:2290-2315): C (+)= sum_i A_i * B_i over `count` products given as arrays of pointers. A thread owns one
+// element of C and walks the products in batch order, k ascending inside a product, every add rounded to fp32 -- the chain of
+// `count` consecutive calls of the plain bf16 -> f32 kernel; a bf16 C is widened once at the start and truncated once at the end
+// (the reference's kernel keeps the sums in fp32 registers across the batch).
+template<int KIND>
+__global__ __launch_bounds__(256) void smm_lowp_reduce_kernel(DevAddr ad, int m, int n, int k, int lda, int ldb, int ldc, int beta0, long long count)
+{
+  typedef typename LowpOut<KIND>::type TC;
+  const int kh = k >> 1;
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long long)m * n) return;
+  const int j = (int)(e / m), i = (int)(e - (long long)j * m);
+  TC* const pc = reinterpret_cast<TC*>(ad.c) + (size_t)j * ldc + i;
+  float facc = 0.f;
+  if (0 == beta0) facc = (4 == KIND) ? bf16_to_f32(*reinterpret_cast<const unsigned short*>(pc)) : *reinterpret_cast<const float*>(pc);
+  for (long long item = 0; item < count; ++item) {
+    const unsigned short* const a = addr_a<unsigned short>(ad, item);
+    const unsigned short* const b = addr_b<unsigned short>(ad, item);
+    for (int s = 0; s < kh; ++s) {
+      const unsigned short* const qa = a + ((size_t)s * lda + i) * 2;
+      const unsigned short* const qb = b + (size_t)j * ldb + 2 * s;
+      facc = __fadd_rn(facc, __fmul_rn(bf16_to_f32(qa[0]), bf16_to_f32(qb[0])));
+      facc = __fadd_rn(facc, __fmul_rn(bf16_to_f32(qa[1]), bf16_to_f32(qb[1])));
+    }
+  }
+  if (4 == KIND) *reinterpret_cast<unsigned short*>(pc) = (unsigned short)(__float_as_uint(facc) >> 16);
+  else *reinterpret_cast<float*>(pc) = facc;
+}
+
 template<int KIND>
 int launch_kind(const SmmBatch& s, hipStream_t st)
 {
@@ -110,6 +140,19 @@ int launch_kind(const SmmBatch& s, hipStream_t st)
 }
 
 } // namespace
+
+int launch_smm_lowp_reduce(const SmmBatch& s, void* stream, const char** name)
+{ // s.a / s.b: device arrays of pointers (stride s.sa / s.sb bytes), s.c: the one C, s.batch: number of products
+  hipStream_t st = (hipStream_t)stream;
+  if (0 != (s.k & 1) || s.m <= 0 || s.n <= 0 || s.k <= 0 || (3 != s.lowp && 4 != s.lowp) || ADDR_POINTER != s.mode) return (int)hipErrorInvalidValue;
+  DevAddr ad = make_addr(s);
+  ad.c = static_cast<char*>(const_cast<void*>(static_cast<const void*>(s.c)));
+  const unsigned blocks = (unsigned)(((long long)s.m * s.n + 255) / 256);
+  const int beta0 = (0 != (s.flags & LIBXSMM_GEMM_FLAG_BETA_0)) ? 1 : 0;
+  if (3 == s.lowp) { *name = "smm_bf16f32_reduce_lowp"; hipLaunchKernelGGL((smm_lowp_reduce_kernel<3>), dim3(blocks), dim3(256), 0, st, ad, s.m, s.n, s.k, s.lda, s.ldb, s.ldc, beta0, s.batch); }
+  else { *name = "smm_bf16_reduce_lowp"; hipLaunchKernelGGL((smm_lowp_reduce_kernel<4>), dim3(blocks), dim3(256), 0, st, ad, s.m, s.n, s.k, s.lda, s.ldb, s.ldc, beta0, s.batch); }
+  return (int)hipGetLastError();
+}
 
 int launch_smm_lowp(const SmmBatch& s, void* stream, const char** name)
 {

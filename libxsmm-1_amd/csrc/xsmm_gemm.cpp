@@ -484,6 +484,32 @@ int lowp_single_execute(SmmBatch s, const void* a, const void* b, void* c)
 void call_kernel(Kernel* k, const void* a, const void* b, void* c, const void* x3, const void* x6)
 {
   if (nullptr == k) return;
+  if (KC_LOWP == k->kclass && 0 != (k->desc.flags & LIBXSMM_GEMM_FLAG_BATCH_REDUCE)) { // kernel(a[], b[], c, &count): bf16 batch-reduce
+    if (nullptr == x3 || nullptr == a || nullptr == b || nullptr == c) return;
+    const unsigned long long count = *static_cast<const unsigned long long*>(x3);
+    if (0 == count) return;
+    if (!device_ready()) { fail_no_device("a low-precision batch-reduce kernel"); return; }
+    SmmBatch s = lowp_from_descriptor(k->desc, 1.f);
+    s.mode = ADDR_POINTER; s.sa = s.sb = (long long)sizeof(void*); s.sc = 0; s.batch = (long long)count; s.sync = SYNC_NONE; s.c = c;
+    bool ok = is_device_ptr(c);
+    if (ok && is_device_ptr(a) && is_device_ptr(b)) { s.a = a; s.b = b; } // pointer arrays the GPU reaches
+    else if (ok) { // host arrays of pointers to device matrices: the arrays travel through the pinned ring
+      const void* const a0 = *static_cast<const void* const*>(a); const void* const b0 = *static_cast<const void* const*>(b);
+      ok = is_device_ptr(a0) && is_device_ptr(b0);
+      if (ok) { s.a = index_upload(a, (size_t)count * sizeof(void*)); s.b = index_upload(b, (size_t)count * sizeof(void*)); ok = (nullptr != s.a && nullptr != s.b); }
+    }
+    if (!ok) {
+      index_upload_commit();
+      fprintf(stderr, "LIBXSMM-AMD ERROR: low-precision batch-reduce kernels need matrices the GPU can reach (libxsmm_malloc or device memory)\n");
+      return;
+    }
+    const char* name = "";
+    const int e = launch_smm_lowp_reduce(s, device().stream, &name); note_launch(name);
+    index_upload_commit();
+    if (0 != e) fprintf(stderr, "LIBXSMM-AMD ERROR: kernel launch failed (%s, hip error %d)\n", name, e);
+    else settle(c);
+    return;
+  }
   if (KC_LOWP == k->kclass) { // i16 -> f32 kernels are called as kernel(a, b, c, pa, pb, pc, &scf) (samples/xgemm/kernel.c:262)
     const bool scaled = (LIBXSMM_GEMM_PRECISION_I16 == LIBXSMM_GETENUM_INP(k->desc.datatype) && LIBXSMM_GEMM_PRECISION_F32 == LIBXSMM_GETENUM_OUT(k->desc.datatype));
     if (scaled && nullptr == x6) return;
@@ -566,6 +592,7 @@ LIBXSMM_API int libxsmm_mmbatch_kernel(libxsmm_xmmfunction kernel, libxsmm_blasi
   const long long tasksize = (size + ntasks - 1) / ntasks;
   const long long begin = (long long)tid * tasksize, span = begin + tasksize, end = (span < size ? span : size);
   if (KC_LOWP == k->kclass) { // batches of low-precision products: independent C operands, everything device-reachable
+    if (0 != (k->desc.flags & LIBXSMM_GEMM_FLAG_BATCH_REDUCE)) return EXIT_FAILURE; // (a batch-reduce kernel is called with its own argument list)
     if (!device_ready()) { fail_no_device("libxsmm_mmbatch_kernel"); return EXIT_FAILURE; }
     if (end <= begin) return EXIT_SUCCESS;
     if (LIBXSMM_GEMM_PRECISION_I16 == LIBXSMM_GETENUM_INP(k->desc.datatype) && LIBXSMM_GEMM_PRECISION_F32 == LIBXSMM_GETENUM_OUT(k->desc.datatype)) return EXIT_FAILURE; // no way to pass the scaling factor
@@ -813,6 +840,7 @@ LIBXSMM_API int libxsmm_amd_gemm_batch_strided(const libxsmm_gemm_descriptor* de
   const Kernel* const k = kernel_from_pointer(reinterpret_cast<const void*>(kernel.xmm));
   if (nullptr != k && KC_LOWP == k->kclass) { // i16 / bf16 inputs: independent C operands (strides in elements of the respective type)
     if (0 == stride_c && 1 < batchsize) return EXIT_FAILURE;
+    if (0 != (k->desc.flags & LIBXSMM_GEMM_FLAG_BATCH_REDUCE)) return EXIT_FAILURE;
     if (LIBXSMM_GEMM_PRECISION_I16 == LIBXSMM_GETENUM_INP(k->desc.datatype) && LIBXSMM_GEMM_PRECISION_F32 == LIBXSMM_GETENUM_OUT(k->desc.datatype)) return EXIT_FAILURE; // no way to pass the scaling factor
     SmmBatch s = lowp_from_descriptor(k->desc, 1.f);
     s.mode = ADDR_STRIDED; s.a = a; s.b = b; s.c = c; s.sa = stride_a; s.sb = stride_b; s.sc = stride_c; s.batch = batchsize; s.sync = SYNC_NONE;

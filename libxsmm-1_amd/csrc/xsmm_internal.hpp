@@ -74,6 +74,7 @@ struct SmmBatch {
 // returns hipError_t as int (0 == success); *name receives a static string naming the kernel variant
 int launch_smm_batch(const SmmBatch& args, void* stream, const char** name);
 int launch_smm_lowp(const SmmBatch& args, void* stream, const char** name);  // args.lowp != 0; independent C operands
+int launch_smm_lowp_reduce(const SmmBatch& args, void* stream, const char** name); // bf16 batch-reduce: one C, pointer arrays of A and B
 
 constexpr int FLAG_SLOT_BLOCKS = 512; // work-groups of the C ordering check (each leaves a pair of counts in the flag slot)
 // detects how C operands alias across the batch: out[0] = number of i with c_i == c_{i-1},

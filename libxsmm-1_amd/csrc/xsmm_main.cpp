@@ -383,7 +383,8 @@ bool desc_buildable(const libxsmm_gemm_descriptor& d)
 {
   const int ip = LIBXSMM_GETENUM_INP(d.datatype), op = LIBXSMM_GETENUM_OUT(d.datatype);
   if (0 != lowp_kind(d)) { // constraints of the reference's generator (src/generator_gemm.c:121-147,236-243)
-    if (0 != (d.k % 2) || 0 != (d.flags & (LIBXSMM_GEMM_FLAG_TRANS_B | LIBXSMM_GEMM_FLAG_BATCH_REDUCE))) return false;
+    if (0 != (d.k % 2) || 0 != (d.flags & LIBXSMM_GEMM_FLAG_TRANS_B)) return false;
+    if (0 != (d.flags & LIBXSMM_GEMM_FLAG_BATCH_REDUCE) && LIBXSMM_GEMM_PRECISION_BF16 != ip) return false; // batch-reduce: bf16 inputs only (src/libxsmm_main.c:2290-2315)
     if (LIBXSMM_GEMM_PRECISION_BF16 == op && 0 != (d.m % 16)) return false;
   }
   else if (!((LIBXSMM_GEMM_PRECISION_F64 == ip && LIBXSMM_GEMM_PRECISION_F64 == op) ||
@@ -501,6 +502,15 @@ LIBXSMM_API libxsmm_bmmfunction libxsmm_bmmdispatch(libxsmm_blasint m, libxsmm_b
   const libxsmm_blasint* lda, const libxsmm_blasint* ldb, const libxsmm_blasint* ldc,
   const float* alpha, const float* beta, const int* flags, const int* prefetch)
 { XSMM_DISPATCH_BODY(libxsmm_bgemm_descriptor_init, float, 0, bmm); }
+// batch-reduce twins (src/libxsmm_main.c:2290-2315): kernel(a[], b[], c, &count)
+LIBXSMM_API libxsmm_bsmmfunction_reducebatch libxsmm_bsmmdispatch_reducebatch(libxsmm_blasint m, libxsmm_blasint n, libxsmm_blasint k,
+  const libxsmm_blasint* lda, const libxsmm_blasint* ldb, const libxsmm_blasint* ldc,
+  const float* alpha, const float* beta, const int* flags, const int* prefetch)
+{ XSMM_DISPATCH_BODY(libxsmm_bsgemm_descriptor_init, float, LIBXSMM_GEMM_FLAG_BATCH_REDUCE, bsmr); }
+LIBXSMM_API libxsmm_bmmfunction_reducebatch libxsmm_bmmdispatch_reducebatch(libxsmm_blasint m, libxsmm_blasint n, libxsmm_blasint k,
+  const libxsmm_blasint* lda, const libxsmm_blasint* ldb, const libxsmm_blasint* ldc,
+  const float* alpha, const float* beta, const int* flags, const int* prefetch)
+{ XSMM_DISPATCH_BODY(libxsmm_bgemm_descriptor_init, float, LIBXSMM_GEMM_FLAG_BATCH_REDUCE, bmr); }
 
 // ---- caller-owned sparse kernels (src/libxsmm_main.c:2523-2582) ----------------------------------------------
 namespace {

@@ -268,3 +268,51 @@ def test_low_precision_wave_kernel(xs, orc, torch_gpu, kind, shape):
             os.environ.pop("LIBXSMM_AMD_JIT_MINBATCH", None)
         else:
             os.environ["LIBXSMM_AMD_JIT_MINBATCH"] = old_env
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", [2, 3])
+@pytest.mark.parametrize("shape", [(32, 32, 32), (16, 12, 24), (64, 48, 64)])
+def test_low_precision_batch_reduce(xs, orc, torch_gpu, kind, shape):
+    """libxsmm_bsmmdispatch_reducebatch / libxsmm_bmmdispatch_reducebatch (src/libxsmm_main.c:2290-2315): kernel(a[], b[], c, &count),
+    C (+)= sum_i A_i B_i with the sums kept in fp32 across the batch -- the chain of `count` calls of the bf16 -> f32 gold loop
+    (samples/xgemm/kernel.c:1104-1123); a bf16 C is widened once and truncated once. No reference-held vector covers these
+    kernels (they serve the RNN module): parity unpinned beyond that chain. Pointer arrays on the host and on the device."""
+    torch = torch_gpu
+    L = xs.lib()
+    m, n, k = shape
+    for name in ("libxsmm_bsmmdispatch_reducebatch", "libxsmm_bmmdispatch_reducebatch"):
+        f = getattr(L, name); f.restype = C.c_void_p
+        f.argtypes = [C.c_int] * 3 + [C.c_void_p] * 7
+    disp = L.libxsmm_bsmmdispatch_reducebatch if kind == 2 else L.libxsmm_bmmdispatch_reducebatch
+    rng = np.random.default_rng(3 * kind + m)
+    for beta0, cnt in ((0, 1), (0, 7), (1, 5)):
+        beta = C.c_float(0.0 if beta0 else 1.0)
+        fn = disp(m, n, k, None, None, None, None, C.addressof(beta), None, None)
+        assert fn
+        As = [_bf16(rng.uniform(-1, 1, m * k)) for _ in range(cnt)]; Bs = [_bf16(rng.uniform(-1, 1, k * n)) for _ in range(cnt)]
+        c = rng.uniform(-1, 1, m * n).astype(np.float32) if kind == 2 else _bf16(rng.uniform(-1, 1, m * n))
+        chain = (np.zeros(m * n, dtype=np.float32) if beta0 else (c.copy() if kind == 2 else _f32(c)))  # fp32 sums across the batch
+        for i in range(cnt):
+            assert 0 == orc.gemm_lowp(2, 0, m, n, k, m, k, m, As[i], Bs[i], chain, 1.0)
+        ref = chain if kind == 2 else _bf16(chain)
+        if beta0 and kind == 2:
+            c[:] = np.nan
+        dA = [torch.from_numpy(x.view(np.int16)).cuda() for x in As]; dB = [torch.from_numpy(x.view(np.int16)).cuda() for x in Bs]
+        pa = np.array([t.data_ptr() for t in dA], dtype=np.uint64); pb = np.array([t.data_ptr() for t in dB], dtype=np.uint64)
+        count = np.array([cnt], dtype=np.uint64)
+        for where in ("host", "device"):
+            dc = torch.from_numpy(c.view(np.int16) if kind == 3 else c).cuda()
+            if where == "host":
+                xs.call_kernel(fn, pa, pb, dc, count)
+            else:
+                qa = torch.from_numpy(pa.view(np.int64)).cuda(); qb = torch.from_numpy(pb.view(np.int64)).cuda()
+                xs.call_kernel(fn, qa, qb, dc, count)
+            torch.cuda.synchronize()
+            assert xs.last_kernel() == ("smm_bf16f32_reduce_lowp" if kind == 2 else "smm_bf16_reduce_lowp")
+            got = dc.cpu().numpy(); got = got.view(np.uint16) if kind == 3 else got
+            assert np.array_equal(got.view(np.uint8), ref.view(np.uint8)), (beta0, cnt, where)
+    # the reference's rules still hold: odd k and (for a bf16 result) m % 16 != 0 give NULL; int16 inputs have no batch-reduce form
+    assert not disp(m, n, 7, None, None, None, None, None, None, None)
+    if kind == 3:
+        assert not disp(m + 4, n, k, None, None, None, None, None, None, None)

@@ -807,6 +807,7 @@ __device__ __forceinline__ int clampi(int v, int hi) { return v < hi ? v : hi; }
 // row of C a lane's accumulator register r belongs to (the fp32 and fp64 instructions differ)
 #define XNROW(r) (F64 ? (lq + 4 * (r)) : (4 * lq + (r)))
 
+#if (2 != XNSPLIT)
 extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(XWPE))) void xsmm_smm_op(DevAddr ad, long long batch, int runlen)
 {
   extern __shared__ __align__(16) unsigned char smem[];
@@ -944,6 +945,133 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(X
   }
   store_c(prev);
 }
+#else
+// XNSPLIT 2: the columns of C are worked on in two halves against one image of A (items whose images would not leave room
+// for four waves per CU: fp64 56^3 needs 55 KB). Per half: its C and B columns arrive, C goes through the place of B's half
+// image into the accumulators, B is parked there, after the arithmetic the result waits there for the deferred stores. The
+// operands of the next half -- or the next item's A and first half -- are in flight meanwhile. A's image is tight (stride M:
+// two-way bank conflicts on its fetches, irrelevant next to 64-cycle fp64 matrix instructions).
+constexpr int AMS = M;
+constexpr int NH = N / 2, NIH = (NH + 15) / 16;
+constexpr int CSH = M;
+constexpr int BH_ELEMS = (NH * KSD > NH * CSH) ? NH * KSD : NH * CSH;
+constexpr int CBH = (K * NH / VEC + 63) / 64, CCH = (M * NH / VEC + 63) / 64;
+static_assert(0 == N % 2 && 0 == (K * NH) % VEC && 0 == (M * NH) % VEC && 0 == XLOWP, "shape");
+extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(XWPE))) void xsmm_smm_op(DevAddr ad, long long batch, int runlen)
+{
+  extern __shared__ __align__(16) unsigned char smem[];
+  T* const As = reinterpret_cast<T*>(smem);
+  T* const Bs = As + K * AMS;
+  T* const Cs = Bs;                      // the half image of C shares the place of B's half (never alive together)
+  T* const dummy = Bs + BH_ELEMS;
+  const int lane = threadIdx.x, l16 = lane & 15, lq = lane >> 4;
+  (void)runlen;
+  V ra[CA], rb[CBH], rc[CCH];
+  auto load_a = [&](long long item) {
+    const XGLOBAL V* const pa = (const XGLOBAL V*)resolve<const T>(ad.a, ad.ia, ad.sa, ad, item);
+#pragma unroll
+    for (int j = 0; j < CA; ++j) ra[j] = __builtin_nontemporal_load(pa + clampi(64 * j + lane, M * K / VEC - 1));
+  };
+  auto load_bc = [&](long long item, int h) {
+    const XGLOBAL V* const pb = (const XGLOBAL V*)(resolve<const T>(ad.b, ad.ib, ad.sb, ad, item) + h * (K * NH));
+#pragma unroll
+    for (int j = 0; j < CBH; ++j) rb[j] = __builtin_nontemporal_load(pb + clampi(64 * j + lane, K * NH / VEC - 1));
+    if (!XBETA0) {
+      const XGLOBAL V* const pc = (const XGLOBAL V*)(resolve<const T>(ad.c, ad.ic, ad.sc, ad, item) + h * (M * NH));
+#pragma unroll
+      for (int j = 0; j < CCH; ++j) rc[j] = __builtin_nontemporal_load(pc + clampi(64 * j + lane, M * NH / VEC - 1));
+    }
+  };
+  auto store_c = [&](long long item, int h) {
+    XGLOBAL V* const pc = (XGLOBAL V*)(resolve<T>(ad.c, ad.ic, ad.sc, ad, item) + h * (M * NH));
+#pragma unroll
+    for (int j = 0; j < CCH; ++j) {
+      const int ch = clampi(64 * j + lane, M * NH / VEC - 1), e = ch * VEC, n = e / M, m = e % M;
+      __builtin_nontemporal_store(*reinterpret_cast<const V*>(Cs + n * CSH + m), pc + ch);
+    }
+  };
+  long long item = blockIdx.x, prev = -1; int prevh = 0;
+  if (item >= batch) return;
+  load_a(item); load_bc(item, 0);
+  for (;;) {
+    const long long next = item + gridDim.x;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): this half's operands (the only other instructions in flight are older stores)
+      if (0 <= prev) { store_c(prev, prevh); wave_lds_sync(); }
+      ACC acc[NIH][MI];
+      if (!XBETA0) {
+#pragma unroll
+        for (int j = 0; j < CCH; ++j) {
+          const int ch = clampi(64 * j + lane, M * NH / VEC - 1), e = ch * VEC, n = e / M, m = e % M;
+          *reinterpret_cast<V*>(Cs + n * CSH + m) = rc[j];
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int ni = 0; ni < NIH; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int n = clampi(16 * ni + XNROW(r), NH - 1), m = clampi(16 * mi + l16, M - 1);
+              acc[ni][mi][r] = Cs[n * CSH + m];
+            }
+        wave_lds_sync();
+      }
+      else {
+#pragma unroll
+        for (int ni = 0; ni < NIH; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = ACC{ 0, 0, 0, 0 };
+      }
+      if (0 == h) {
+#pragma unroll
+        for (int j = 0; j < CA; ++j) {
+          const int ch = clampi(64 * j + lane, M * K / VEC - 1), e = ch * VEC, k = e / M, m = e % M;
+          *reinterpret_cast<V*>(As + k * AMS + m) = ra[j];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < CBH; ++j) {
+        const int ch = clampi(64 * j + lane, K * NH / VEC - 1), e = ch * VEC, n = e / K, k = e % K;
+        *reinterpret_cast<V*>(Bs + n * KSD + k) = rb[j];
+      }
+      if (0 == h) load_bc(item, 1);
+      else if (next < batch) { load_a(next); load_bc(next, 0); }
+      wave_lds_sync();
+#pragma unroll 2
+      for (int ks = 0; ks < KS; ++ks) { // (limited unrolling: with the whole k loop unrolled the operand fetches are hoisted and the registers spill)
+        T af[MI], bf[NIH];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) { const int m = clampi(16 * mi + l16, M - 1); af[mi] = As[(4 * ks + lq) * AMS + m]; }
+#pragma unroll
+        for (int ni = 0; ni < NIH; ++ni) { const int n = clampi(16 * ni + l16, NH - 1); bf[ni] = Bs[n * KSD + 4 * ks + lq]; }
+#pragma unroll
+        for (int ni = 0; ni < NIH; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = xmfma(bf[ni], af[mi], acc[ni][mi]);
+      }
+      wave_lds_sync();
+#pragma unroll
+      for (int ni = 0; ni < NIH; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int n = 16 * ni + XNROW(r), m = 16 * mi + l16;
+            const bool inside = (16 * ni + 15 < NH || n < NH) && (16 * mi + 15 < M || m < M);
+            T* const dst = inside ? Cs + n * CSH + m : dummy + lane;
+            *dst = acc[ni][mi][r];
+          }
+      wave_lds_sync();
+      prev = item; prevh = h;
+    }
+    if (next >= batch) break;
+    item = next;
+  }
+  store_c(prev, prevh);
+}
+#endif
 )XSMM";
 
 // LDS bytes of a wave of that kernel (mirrors the constexpr arithmetic of the source); 0: the shape is not served
@@ -956,6 +1084,17 @@ static size_t smm_mfma_wave_lds(int typesize, int m, int n, int k)
   int csd = m; for (;; csd += vec) { if (8 == typesize ? (16 == csd % 32) : (4 == csd % 16 || 12 == csd % 16)) break; }
   const int a_elems = (n * csd > k * ms) ? n * csd : k * ms;
   return (size_t)(a_elems + n * ksd + 64) * typesize;
+}
+// ... of the form that works on the columns of C in two halves (0: not served)
+static size_t smm_mfma_wave2_lds(int typesize, int m, int n, int k)
+{
+  const int vec = 16 / typesize;
+  if (0 != m % vec || 0 != k % 4 || m > 64 || n > 64 || k > 64 || k < 4 || 0 != (n & 1)) return 0;
+  const int nh = n / 2;
+  if (0 != (k * nh) % vec || 0 != (m * nh) % vec) return 0;
+  int ksd = (k + vec - 1) / vec; if (0 == (ksd & 1)) ++ksd; ksd *= vec;
+  const int bh = (nh * ksd > nh * m) ? nh * ksd : nh * m;
+  return (size_t)(k * m + bh + 64) * typesize;
 }
 // waves per SIMD the kernel is compiled for: two where LDS leaves room for eight waves per CU, else one (the register file
 // then holds an item's operands, the next item's and the accumulators without spilling)
@@ -1202,7 +1341,14 @@ std::string gen_smm_source(int typesize, int m, int n, int k, int flags, int var
   s += "#define XM " + std::to_string(m) + "\n#define XN " + std::to_string(n) + "\n#define XK " + std::to_string(k) + "\n";
   s += std::string("#define XBETA0 ") + ((flags & LIBXSMM_GEMM_FLAG_BETA_0) ? "1" : "0") + "\n";
   s += std::string("#define XTRANSB ") + ((flags & LIBXSMM_GEMM_FLAG_TRANS_B) ? "1" : "0") + "\n";
+  if (0 != (variant & SMM_JIT_MFMA_WAVE2)) { // ... the columns of C in two halves
+    s += "#define XFLAT 0\n#define XWPE 1\n#define XNSPLIT 2\n";
+    s += SMM_JIT_PRELUDE;
+    s += SMM_JIT_MFMA_WAVE_BODY;
+    return s;
+  }
   if (0 != (variant & SMM_JIT_MFMA_WAVE)) { // matrix-core kernel, one wave per item
+    s += "#define XNSPLIT 1\n";
     s += "#define XFLAT 0\n#define XWPE " + std::to_string(smm_mfma_wave_wpe(smm_mfma_wave_lds(typesize, m, n, k))) + "\n";
     s += SMM_JIT_PRELUDE;
     s += SMM_JIT_MFMA_WAVE_BODY;
@@ -1635,6 +1781,30 @@ int launch_smm_jit_mfma(const SmmBatch& s, void* stream, const char** name)
       }
     }
   }
+  { // fp64 items too large for that: the two-halves form where it leaves room for four waves per CU (56^3: 66 % against 54-58 % on the
+    // work-group form; 64 x 64 x K stays on the work-group form, which is the faster one there -- tools/probe/mfma_wave.hip)
+    static const int wave_on = []() { const char* e = getenv("XSMM_SMMJIT_MFMA_WAVE"); return (nullptr != e && 0 != *e) ? atoi(e) : 1; }();
+    const size_t wlds = f64 ? smm_mfma_wave2_lds(s.typesize, s.m, s.n, s.k) : 0;
+    const uintptr_t bits = reinterpret_cast<uintptr_t>(s.a) | reinterpret_cast<uintptr_t>(s.b) | reinterpret_cast<uintptr_t>(s.c)
+                         | (uintptr_t)(s.sa * s.typesize) | (uintptr_t)(s.sb * s.typesize) | (uintptr_t)(s.sc * s.typesize);
+    if (0 != wave_on && 0 != wlds && 4 * wlds <= 160u * 1024u && !(64 == s.m && 64 == s.n) && SYNC_NONE == s.sync && ADDR_STRIDED == s.mode && 0 == (bits & 15)
+      && s.lda == s.m && s.ldb == s.k && s.ldc == s.m)
+    {
+      const SmmKey wkey = { s.typesize, s.m, s.n, s.k, s.flags & LIBXSMM_GEMM_FLAG_BETA_0, SMM_JIT_MFMA_WAVE2, s.lda, s.ldb, s.ldc };
+      JitKernel* const wk = smm_jit_get(wkey);
+      if (nullptr != wk) {
+        struct { const char* a; const char* b; char* c; const char* ia; const char* ib; const char* ic; long long sa, sb, sc; int index_base, index_stride, mode; const int* flags; } wad;
+        wad.a = (const char*)s.a; wad.b = (const char*)s.b; wad.c = (char*)s.c; wad.ia = wad.ib = wad.ic = nullptr;
+        wad.sa = s.sa; wad.sb = s.sb; wad.sc = s.sc; wad.index_base = 0; wad.index_stride = 0; wad.mode = 0; wad.flags = nullptr;
+        long long wbatch = s.batch; int one = 1;
+        long long wblocks = 256LL * 4;
+        if (wblocks > s.batch) wblocks = s.batch;
+        void* wargs[] = { &wad, &wbatch, &one };
+        *name = "smm_f64_mfma_wave2_jit";
+        return jit_launch_dyn(wk, (unsigned)wblocks, 64u, (unsigned)wlds, wargs, stream);
+      }
+    }
+  }
   const bool tight = !f64 && s.lda == s.m && s.ldb == s.k && 0 == ((s.m * s.k) & 3) && 0 == ((s.k * s.n) & 3);
   static const int tightc_on = []() { const char* e = getenv("XSMM_SMM64_TIGHTC"); return (nullptr != e && 0 != *e) ? atoi(e) : 1; }();
   const bool tightc = !f64 && s.ldc == s.m && 0 == ((s.m * s.n) & 3) && 0 != (s.m & 31) && 0 != tightc_on;
@@ -1788,7 +1958,9 @@ int smm_jit_prebuild(const SmmBatch* shapes, int nshapes, int grouped, int* buil
       if (s.m <= 64 && s.n <= 64 && s.k <= 64 && 0 == (flags & LIBXSMM_GEMM_FLAG_TRANS_B)) { // the matrix-core forms launch_smm_jit_mfma would pick
         const size_t wlds = smm_mfma_wave_lds(s.typesize, s.m, s.n, s.k);
         const bool f64 = (8 == s.typesize);
+        const size_t w2lds = f64 ? smm_mfma_wave2_lds(s.typesize, s.m, s.n, s.k) : 0;
         if (0 != wlds && 4 * wlds <= 160u * 1024u && s.lda == s.m && s.ldb == s.k && s.ldc == s.m) one(SMM_JIT_MFMA_WAVE);
+        else if (0 != w2lds && 4 * w2lds <= 160u * 1024u && !(64 == s.m && 64 == s.n) && s.lda == s.m && s.ldb == s.k && s.ldc == s.m) one(SMM_JIT_MFMA_WAVE2);
         else if (!(!f64 && 64 == s.m && 64 == s.n && 64 == s.k && 64 == s.lda && 64 == s.ldb && 64 == s.ldc)) {
           const bool tight = !f64 && s.lda == s.m && s.ldb == s.k && 0 == ((s.m * s.k) & 3) && 0 == ((s.k * s.n) & 3);
           const bool tightc = !f64 && s.ldc == s.m && 0 == ((s.m * s.n) & 3) && 0 != (s.m & 31);

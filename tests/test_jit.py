@@ -46,6 +46,12 @@ def test_generated_sources_compile_for_gfx950(xs):
                 blob, d = xs.descriptor(prec, m, n, k, beta=beta)
                 assert 0 == L.libxsmm_amd_smm_kernel_source(d, 16384, buf, len(buf), 1), (prec, m, n, k, beta)
                 assert "xmfma" in buf.value.decode() and "#define XWPE" in buf.value.decode()
+    # ... the fp64 form that works on the columns of C in two halves (variant bit 32768)
+    for (m, n, k) in [(56, 56, 56), (16, 64, 64), (64, 56, 56)]:
+        for beta in (1.0, 0.0):
+            blob, d = xs.descriptor(xs.F64, m, n, k, beta=beta)
+            assert 0 == L.libxsmm_amd_smm_kernel_source(d, 32768, buf, len(buf), 1), (m, n, k, beta)
+            assert "#define XNSPLIT 2" in buf.value.decode()
     # ... and its bf16-input forms (variant bits 11..12: 2 = bf16 result, 3 = fp32 result)
     for (m, n, k) in [(48, 48, 48), (64, 40, 56), (16, 64, 8)]:
         for beta in (1.0, 0.0):

@@ -154,12 +154,14 @@ MFMA_WG_SHAPES = [  # 32 < max(M, N) <= 64, K <= 64: tight and with gaps, odd K 
 
 
 def mfma_wave_serves(dtype, m, n, k, lda, ldb, ldc):
-    """mirror of smm_mfma_wave_lds / the eligibility rule in csrc/xsmm_jit_smm.cpp: the one-wave-per-item matrix-core kernel takes
-    tight operands with M a multiple of a 16-byte chunk and K a multiple of four whose LDS images leave room for four waves per CU"""
+    """mirror of smm_mfma_wave_lds / smm_mfma_wave2_lds and the eligibility rules in csrc/xsmm_jit_smm.cpp: the one-wave-per-item
+    matrix-core kernel takes tight operands with M a multiple of a 16-byte chunk and K a multiple of four whose LDS images leave
+    room for four waves per CU ("wave"); fp64 items too large for that are worked on in two halves of C's columns ("wave2",
+    not for 64 x 64 x K). None: the work-group form."""
     ts = np.dtype(dtype).itemsize
     vec = 16 // ts
     if (lda, ldb, ldc) != (m, k, m) or m % vec or k % 4 or max(m, n) <= 32:
-        return False
+        return None
     ms = 16 if m <= 16 else (48 if m <= 48 else 64)
     ksd = (k + vec - 1) // vec
     ksd = (ksd + 1 if ksd % 2 == 0 else ksd) * vec
@@ -167,7 +169,14 @@ def mfma_wave_serves(dtype, m, n, k, lda, ldb, ldc):
     while not ((csd % 32 == 16) if ts == 8 else (csd % 16 in (4, 12))):
         csd += vec
     lds = (max(n * csd, k * ms) + n * ksd + 64) * ts
-    return 4 * lds <= 160 * 1024
+    if 4 * lds <= 160 * 1024:
+        return "wave"
+    nh = n // 2
+    if ts == 8 and n % 2 == 0 and (k * nh) % vec == 0 and (m * nh) % vec == 0 and not (m == 64 and n == 64):
+        lds2 = (k * m + max(nh * ksd, nh * m) + 64) * ts
+        if 4 * lds2 <= 160 * 1024:
+            return "wave2"
+    return None
 
 
 @pytest.mark.parametrize("shape", MFMA_WG_SHAPES)
@@ -209,13 +218,14 @@ def test_smm_mfma_wg(xs, orc, torch_gpu, dtype, shape, beta, specialised):
             del os.environ["LIBXSMM_AMD_JIT"]
         else:
             os.environ["LIBXSMM_AMD_JIT"] = old_jit
-    form = "wave" if (specialised and mfma_wave_serves(dtype, *shape)) else "wg"
+    form = (mfma_wave_serves(dtype, *shape) if specialised else None) or "wg"
     assert xs.last_kernel() == ("smm_f64_mfma_" if dtype == np.float64 else "smm_f32_mfma_") + form + ("_jit" if specialised else ""), xs.last_kernel()
     bits = np.uint64 if dtype == np.float64 else np.uint32
     assert np.array_equal(out.view(bits), ref.view(bits))
 
 
-MFMA_WAVE_SHAPES = [(40, 40, 40), (48, 48, 48), (56, 56, 56), (36, 64, 8), (64, 20, 12), (44, 52, 36), (64, 64, 60), (16, 48, 64), (34, 40, 4)]
+MFMA_WAVE_SHAPES = [(40, 40, 40), (48, 48, 48), (56, 56, 56), (36, 64, 8), (64, 20, 12), (44, 52, 36), (64, 64, 60), (16, 48, 64), (34, 40, 4),
+                    (16, 64, 64), (56, 64, 48), (64, 56, 56)]
 
 
 @pytest.mark.parametrize("shape", MFMA_WAVE_SHAPES)
@@ -227,7 +237,8 @@ def test_smm_mfma_wave(xs, orc, torch_gpu, dtype, shape, beta):
     smaller than, equal to and larger than the resident grid (every wave then walks several items) and with C = -0 / A = 0."""
     torch = torch_gpu
     m, n, k = shape
-    if not mfma_wave_serves(dtype, m, n, k, m, k, m):
+    form = mfma_wave_serves(dtype, m, n, k, m, k, m)
+    if form is None:
         pytest.skip("shape is left to the work-group kernel")
     old_jit = os.environ.get("LIBXSMM_AMD_JIT")
     os.environ["LIBXSMM_AMD_JIT"] = "1"
@@ -249,7 +260,7 @@ def test_smm_mfma_wave(xs, orc, torch_gpu, dtype, shape, beta):
             os.environ["LIBXSMM_AMD_JIT_MINBATCH"] = "1"
             assert 0 == xs.lib().libxsmm_amd_gemm_batch_strided(desc, xs.dptr(da), xs.dptr(db), xs.dptr(dc), asz, bsz, csz, batch)
             torch.cuda.synchronize()
-            assert xs.last_kernel() == ("smm_f64_mfma_wave_jit" if dtype == np.float64 else "smm_f32_mfma_wave_jit"), (batch, xs.last_kernel())
+            assert xs.last_kernel() == ("smm_f64_mfma_%s_jit" % form if dtype == np.float64 else "smm_f32_mfma_wave_jit"), (batch, xs.last_kernel())
             bits = np.uint64 if dtype == np.float64 else np.uint32
             assert np.array_equal(dc.cpu().numpy().view(bits), ref.view(bits)), batch
     finally:

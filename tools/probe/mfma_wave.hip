@@ -5,6 +5,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#ifndef XKUNROLL
+#define XKUNROLL 2
+#endif
 #ifndef XF64
 #define XF64 0
 #endif
@@ -156,6 +159,148 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(XWPE))) void
   store_c(prev);
 }
 
+#if defined(XNSPLIT) && (2 == XNSPLIT)
+// Variant for items whose images do not leave room for four waves per CU (fp64 56^3: 55 KB): the columns of C are worked
+// on in two halves against one image of A. Per half: its C and B columns arrive, C goes through the B region into the
+// accumulators, B is parked there, after the arithmetic the result waits there for the deferred stores. The operands of the
+// next half (or the next item's A and first half) are in flight meanwhile.
+#ifndef XAMS
+#define XAMS MS
+#endif
+constexpr int AMS = XAMS;                                  // row stride of A's image
+constexpr int NH = N / 2, NIH = (NH + 15) / 16;
+constexpr int CSH = M;                                     // column stride of the half C image
+constexpr int BH_ELEMS = (NH * KSD > NH * CSH) ? NH * KSD : NH * CSH;
+constexpr int CBH = (K * NH / VEC + 63) / 64, CCH = (M * NH / VEC + 63) / 64;
+constexpr size_t LDS2_BYTES = (size_t)(K * AMS + BH_ELEMS + 64) * sizeof(T);
+static_assert(0 == N % 2, "shape");
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(XWPE))) void kern2(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ c, long long batch)
+{
+  extern __shared__ __align__(16) unsigned char smem[];
+  T* const As = reinterpret_cast<T*>(smem);
+  T* const Bs = As + K * AMS;
+  T* const Cs = Bs;                      // the half image of C shares the place of B's half (never alive together)
+  T* const dummy = Bs + BH_ELEMS;
+  const int lane = threadIdx.x, l16 = lane & 15, lq = lane >> 4;
+  V ra[CA], rb[CBH], rc[CCH];
+  auto load_a = [&](long long item) {
+    const V* const pa = reinterpret_cast<const V*>(a + item * (M * K));
+#pragma unroll
+    for (int j = 0; j < CA; ++j) ra[j] = __builtin_nontemporal_load(pa + clampi(64 * j + lane, M * K / VEC - 1));
+  };
+  auto load_bc = [&](long long item, int h) {
+    const V* const pb = reinterpret_cast<const V*>(b + item * (K * N) + h * (K * NH));
+#pragma unroll
+    for (int j = 0; j < CBH; ++j) rb[j] = __builtin_nontemporal_load(pb + clampi(64 * j + lane, K * NH / VEC - 1));
+    if (!XBETA0) {
+      const V* const pc = reinterpret_cast<const V*>(c + item * (M * N) + h * (M * NH));
+#pragma unroll
+      for (int j = 0; j < CCH; ++j) rc[j] = __builtin_nontemporal_load(pc + clampi(64 * j + lane, M * NH / VEC - 1));
+    }
+  };
+  auto lds_sync = [&]() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); };
+  auto store_c = [&](long long item, int h) {
+    V* const pc = reinterpret_cast<V*>(c + item * (M * N) + h * (M * NH));
+#pragma unroll
+    for (int j = 0; j < CCH; ++j) {
+      const int ch = clampi(64 * j + lane, M * NH / VEC - 1), e = ch * VEC, n = e / M, m = e % M;
+      __builtin_nontemporal_store(*reinterpret_cast<const V*>(Cs + n * CSH + m), pc + ch);
+    }
+  };
+  long long item = blockIdx.x, prev = -1; int prevh = 0;
+  if (item >= batch) return;
+  load_a(item); load_bc(item, 0);
+  for (;;) {
+    const long long next = item + gridDim.x;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+      if (0 <= prev) { store_c(prev, prevh); lds_sync(); }
+      ACC acc[NIH][MI];
+      if (!XBETA0) {
+#pragma unroll
+        for (int j = 0; j < CCH; ++j) {
+          const int ch = clampi(64 * j + lane, M * NH / VEC - 1), e = ch * VEC, n = e / M, m = e % M;
+          *reinterpret_cast<V*>(Cs + n * CSH + m) = rc[j];
+        }
+        lds_sync();
+#pragma unroll
+        for (int ni = 0; ni < NIH; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int n = clampi(16 * ni + NROW(r), NH - 1), m = clampi(16 * mi + l16, M - 1);
+              acc[ni][mi][r] = Cs[n * CSH + m];
+            }
+        lds_sync();
+      }
+      else {
+#pragma unroll
+        for (int ni = 0; ni < NIH; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = ACC{ 0, 0, 0, 0 };
+      }
+      if (0 == h) {
+#pragma unroll
+        for (int j = 0; j < CA; ++j) {
+          const int ch = clampi(64 * j + lane, M * K / VEC - 1), e = ch * VEC, k = e / M, m = e % M;
+          *reinterpret_cast<V*>(As + k * AMS + m) = ra[j];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < CBH; ++j) {
+        const int ch = clampi(64 * j + lane, K * NH / VEC - 1), e = ch * VEC, n = e / K, k = e % K;
+        *reinterpret_cast<V*>(Bs + n * KSD + k) = rb[j];
+      }
+      if (0 == h) load_bc(item, 1);
+      else if (next < batch) { load_a(next); load_bc(next, 0); }
+      lds_sync();
+#if (1 == XKUNROLL)
+#pragma unroll 1
+#elif (2 == XKUNROLL)
+#pragma unroll 2
+#else
+#pragma unroll
+#endif
+      for (int ks = 0; ks < KS; ++ks) {
+        T af[MI], bf[NIH];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) { const int m = clampi(16 * mi + l16, M - 1); af[mi] = As[(4 * ks + lq) * AMS + m]; }
+#pragma unroll
+        for (int ni = 0; ni < NIH; ++ni) { const int n = clampi(16 * ni + l16, NH - 1); bf[ni] = Bs[n * KSD + 4 * ks + lq]; }
+#pragma unroll
+        for (int ni = 0; ni < NIH; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = MFMA(bf[ni], af[mi], acc[ni][mi]);
+      }
+      lds_sync();
+#pragma unroll
+      for (int ni = 0; ni < NIH; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int n = 16 * ni + NROW(r), m = 16 * mi + l16;
+            const bool inside = (16 * ni + 15 < NH || n < NH) && (16 * mi + 15 < M || m < M);
+            T* const dst = inside ? Cs + n * CSH + m : dummy + lane;
+            *dst = acc[ni][mi][r];
+          }
+      lds_sync();
+      prev = item; prevh = h;
+    }
+    if (next >= batch) break;
+    item = next;
+  }
+  store_c(prev, prevh);
+}
+#define KERN kern2
+#define KLDS LDS2_BYTES
+#else
+#define KERN kern
+#define KLDS LDS_BYTES
+#endif
+
 #define CHECK(x) do { hipError_t e_ = (x); if (hipSuccess != e_) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 int main(int argc, char** argv)
 {
@@ -171,12 +316,12 @@ int main(int argc, char** argv)
   CHECK(hipMalloc(&da, na * sizeof(T))); CHECK(hipMalloc(&db, nb * sizeof(T))); CHECK(hipMalloc(&dc, nc * sizeof(T)));
   CHECK(hipMemcpy(da, ha.data(), na * sizeof(T), hipMemcpyHostToDevice)); CHECK(hipMemcpy(db, hb.data(), nb * sizeof(T), hipMemcpyHostToDevice));
   CHECK(hipMemcpy(dc, hc.data(), nc * sizeof(T), hipMemcpyHostToDevice));
-  CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
-  int occ = 0; CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 64, LDS_BYTES));
+  CHECK(hipFuncSetAttribute((const void*)KERN, hipFuncAttributeMaxDynamicSharedMemorySize, (int)KLDS));
+  int occ = 0; CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, KERN, 64, KLDS));
   if (0 >= bpc) bpc = occ;
   const unsigned blocks = (unsigned)(256 * bpc);
-  printf("M=%d N=%d K=%d %s lds=%zu B/wave occupancy=%d waves/CU, using %d\n", M, N, K, XF64 ? "f64" : "f32", LDS_BYTES, occ, bpc);
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), LDS_BYTES, 0, da, db, dc, batch);
+  printf("M=%d N=%d K=%d %s lds=%zu B/wave occupancy=%d waves/CU, using %d\n", M, N, K, XF64 ? "f64" : "f32", (size_t)KLDS, occ, bpc);
+  hipLaunchKernelGGL(KERN, dim3(blocks), dim3(64), KLDS, 0, da, db, dc, batch);
   CHECK(hipDeviceSynchronize());
   CHECK(hipMemcpy(out.data(), dc, nc * sizeof(T), hipMemcpyDeviceToHost));
   long long bad = 0; // fma chain in ascending k, checked on a sample of items
@@ -195,7 +340,7 @@ int main(int argc, char** argv)
   hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
   const int reps = 10;
   CHECK(hipEventRecord(e0));
-  for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), LDS_BYTES, 0, da, db, dc, batch);
+  for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(KERN, dim3(blocks), dim3(64), KLDS, 0, da, db, dc, batch);
   CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
   float ms = 0; CHECK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
   const double bytes = (double)batch * sizeof(T) * (M * K + K * N + (XBETA0 ? 1 : 2) * M * N);

@@ -25,7 +25,7 @@ LIBXSMM_API void* libxsmm_amd_get_stream(void);
  *  not cost a launch each: consecutive calls form a burst whose work is queued on the stream with the first call (a gate
  *  kernel that waits for the burst to be complete and the batch kernel behind it) while the following calls only append
  *  their operands to a ring in pinned memory. A burst is completed by the next entry point of the library called on the
- *  thread, by a call that may not run beside the recorded ones, or by a helper thread a few dozen microseconds after the
+ *  thread, by a call that may not run beside the recorded ones, or by a helper thread a few microseconds after the
  *  last call -- so whatever the caller queues or waits for afterwards (its own kernels, hipMemcpy, hipStreamSynchronize,
  *  hipDeviceSynchronize) is ordered behind the calls as behind any asynchronous launch. libxsmm_amd_flush completes the
  *  calling thread's burst at once (a latency hint, never needed for correctness). LIBXSMM_AMD_DEFER=0: a launch per call. */

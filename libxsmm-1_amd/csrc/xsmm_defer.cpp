@@ -11,7 +11,7 @@
 //   * the burst is sealed by whatever comes first: another entry point of the library on this thread (it asks for the
 //     stream: device()), a call that must not run beside the recorded ones (other kernel, operands that overlap a C of
 //     the burst, a C that repeats but not consecutively, a full ring), or a helper thread once the calls have stopped
-//     coming for a few dozen microseconds.
+//     coming for a few microseconds.
 // Everything the burst does is already queued on the stream when the first call returns, so whatever the caller queues
 // or waits for afterwards -- its own kernels, hipMemcpy, hipStreamSynchronize, hipDeviceSynchronize -- is ordered behind
 // it like behind any asynchronous call; no later "flush" has to win a race against the caller. Consecutive calls with
@@ -21,6 +21,7 @@
 #include "xsmm_internal.hpp"
 
 #include <hip/hip_runtime_api.h>
+#include <sys/prctl.h>
 
 #include <atomic>
 #include <chrono>
@@ -39,7 +40,7 @@ namespace {
 constexpr unsigned long long SEALED = 1ULL << 63;
 constexpr int DEFER_CAP = 8192;    // calls per burst
 constexpr int DEFER_SLOTS = 8;     // bursts of a thread that may be in flight on the GPU
-constexpr long long IDLE_NS = 20000; // the helper seals a burst that has not grown for this long
+constexpr long long IDLE_NS = 6000;  // the helper seals a burst that has not grown for this long (a loop in C issues a call every 0.05 us)
 
 struct Entry { const void* a; const void* b; void* c; };
 struct Range { uintptr_t lo = 0, hi = 0; bool has(uintptr_t p, size_t bytes) const { return lo <= p && p + bytes <= hi; } };
@@ -75,6 +76,9 @@ long long now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>
 
 void helper_loop()
 {
+  // (sleeps of a few microseconds: the default timer slack of a thread, 50 us, would add that much to the latency of a caller who
+  // issues one call and waits for the device)
+  (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0UL, 0UL, 0UL);
   for (;;) {
     {
       std::unique_lock<std::mutex> guard(g_rings_lock);
@@ -96,7 +100,7 @@ void helper_loop()
           }
         }
       }
-      std::this_thread::sleep_for(std::chrono::microseconds(10));
+      std::this_thread::sleep_for(std::chrono::microseconds(2));
     }
   }
 }

@@ -1322,6 +1322,8 @@ static int smm_jit_depth(int typesize, int m, int n, int k, int variant)
   (void)typesize; (void)m; (void)n; (void)k;
   if (0 == (variant & (SMM_JIT_RUNS | SMM_JIT_WGRUNS))) return 1;
   static const int env = []() { const char* e = getenv("XSMM_SMMJIT_DEPTH"); return (nullptr != e && 0 != *e) ? atoi(e) : 0; }();
+  static const int env_bytes = []() { const char* e = getenv("XSMM_SMMJIT_DEPTH_BYTES"); return (nullptr != e && 0 != *e) ? atoi(e) : 0; }(); // (developer knob: only products up to this many operand bytes)
+  if (0 < env_bytes && (long long)typesize * ((long long)m * k + (long long)k * n) > env_bytes) return 1;
   return (0 < env && env <= 8) ? env : 1;
 }
 

@@ -62,6 +62,8 @@ struct Ring { // one per thread; outlives its thread (handed on), never freed: t
   const void* last_c = nullptr;
   uintptr_t c_lo = 0, c_hi = 0, a_lo = 0, a_hi = 0, b_lo = 0, b_hi = 0; // address ranges written / read by the burst
   Range known[3];                                       // device allocations the operands were found in (valid within the burst)
+  // a burst of per-panel operator calls (defer_panels): panel i of the burst is at b0 / c0 + i * step
+  const void* panel_handle = nullptr; uintptr_t b0 = 0, c0 = 0; size_t step = 0; int max_panels = 0;
   bool ok = false;
 };
 
@@ -176,7 +178,7 @@ void close_burst(Ring& r)
     if (r.open_slot.compare_exchange_strong(expect, -1, std::memory_order_acq_rel)) g_open_bursts.fetch_sub(1, std::memory_order_acq_rel);
   }
   tl_defer_open = false;
-  r.mine = -1; r.kernel = nullptr; r.ncalls = 0; r.last_c = nullptr;
+  r.mine = -1; r.kernel = nullptr; r.ncalls = 0; r.last_c = nullptr; r.panel_handle = nullptr;
 }
 
 // queue gate + batch kernel of a new burst on the caller's stream
@@ -291,6 +293,77 @@ bool defer_call(Kernel* k, const void* a, const void* b, void* c)
     if (!open_burst(r, k)) return false;
   }
   return false;
+}
+
+// Per-panel calls of a fixed operator: libxsmm_?fsspmdm_execute(handle, B + i * N, C + i * N) for i = 0, 1, ... (the PyFR driver,
+// samples/pyfr/pyfr_driver_asp_reg.c:300-308) -- a panel of N columns is a few kilobytes, a launch per panel is a hundred times
+// its work. The same scheme as above: the first call queues the gate and the operator kernel (which reads the number of panels
+// from device memory), the following calls only count up as long as they continue the walk along the rows.
+bool defer_panels(const void* handle, JitKernel* jit, const void* B, void* C, int typesize, int M, int N, int K, long long ldb, long long ldc, int vec)
+{
+  if (!defer_enabled() || nullptr == handle || nullptr == jit || nullptr == B || nullptr == C) return false;
+  Ring* const rp = my_ring();
+  if (nullptr == rp) return false;
+  Ring& r = *rp;
+  const uintptr_t pb = reinterpret_cast<uintptr_t>(B), pc = reinterpret_cast<uintptr_t>(C);
+  const size_t ts = (size_t)typesize, step = (size_t)N * ts;
+  if (tl_defer_open) {
+    if (r.panel_handle == handle && r.stream == device_raw().stream && r.ncalls < r.max_panels
+      && pb == r.b0 + (size_t)r.ncalls * step && pc == r.c0 + (size_t)r.ncalls * step)
+    {
+      Slot& sl = r.slot[r.mine];
+      unsigned long long expect = (unsigned long long)r.ncalls;
+      if (sl.word->compare_exchange_strong(expect, expect + 1, std::memory_order_release, std::memory_order_relaxed)) {
+        ++r.ncalls;
+        r.last_ns.store(now_ns(), std::memory_order_relaxed);
+        return true;
+      }
+    }
+    close_burst(r);
+  }
+  // a new burst: both panels in device memory, aligned for the kernel's vector width; how far may the walk go?
+  if (0 != ((pb | pc) & (ts * (size_t)vec - 1))) return false;
+  const Range rb = device_range(B), rc = device_range(C);
+  if (0 == rb.hi || 0 == rc.hi) return false;
+  const size_t rows_b = (size_t)(K - 1) * (size_t)ldb * ts, rows_c = (size_t)(M - 1) * (size_t)ldc * ts; // offset of a panel's last row
+  if (pb + rows_b + step > rb.hi || pc + rows_c + step > rc.hi) return false;
+  long long maxp = DEFER_CAP;
+  const long long by_b = (long long)((rb.hi - pb - rows_b) / step), by_c = (long long)((rc.hi - pc - rows_c) / step);
+  if (maxp > by_b) maxp = by_b;
+  if (maxp > by_c) maxp = by_c;
+  const long long by_row = (ldb < ldc ? ldb : ldc) / N; // a walk stays inside one row of B and C
+  if (maxp > by_row) maxp = by_row;
+  if (maxp < 1) return false;
+  { // the panels of B that are read and the panels of C that are written must not meet
+    const uintptr_t be = pb + rows_b + (size_t)maxp * step, ce = pc + rows_c + (size_t)maxp * step;
+    if (pb < ce && pc < be) return false;
+  }
+  Device& dev = device_raw();
+  hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+  if (hipSuccess != hipStreamIsCapturing((hipStream_t)dev.stream, &capturing)) { (void)hipGetLastError(); return false; }
+  if (hipStreamCaptureStatusNone != capturing) return false;
+  const int s = r.cur;
+  Slot& sl = r.slot[s];
+  if (sl.pending) { (void)hipEventSynchronize(sl.done); sl.pending = false; }
+  sl.word->store(1, std::memory_order_release); // this call is the burst's first panel
+  if (0 != launch_defer_gate(reinterpret_cast<unsigned long long*>(sl.word), sl.count, dev.stream)) return false;
+  const int e = jit_launch_panels(jit, B, C, maxp * N, ldb, ldc, vec, dev.stream, sl.count, (long long)N);
+  if (0 != e) {
+    sl.word->store(SEALED, std::memory_order_release); // (the gate is queued already: let it through)
+    fprintf(stderr, "LIBXSMM-AMD ERROR: kernel launch failed (fsspmdm operator, hip error %d)\n", e);
+    return false;
+  }
+  note_launch(8 == typesize ? "fsspmdm_f64_jit_operator_deferred" : "fsspmdm_f32_jit_operator_deferred");
+  if (hipSuccess == hipEventRecord(sl.done, (hipStream_t)dev.stream)) sl.pending = true; else (void)hipGetLastError();
+  sl.stream = dev.stream;
+  r.cur = (s + 1) % DEFER_SLOTS;
+  r.kernel = nullptr; r.panel_handle = handle; r.stream = dev.stream; r.ncalls = 1; r.mine = s;
+  r.b0 = pb; r.c0 = pc; r.step = step; r.max_panels = (int)maxp;
+  r.last_ns.store(now_ns(), std::memory_order_relaxed);
+  r.open_slot.store(s, std::memory_order_release);
+  tl_defer_open = true;
+  if (0 == g_open_bursts.fetch_add(1, std::memory_order_acq_rel)) { std::lock_guard<std::mutex> guard(g_rings_lock); g_helper_wake.notify_one(); }
+  return true;
 }
 
 } // namespace xsmm

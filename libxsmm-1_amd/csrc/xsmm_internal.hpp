@@ -85,7 +85,10 @@ int launch_smm_generic(const SmmBatch& s, void* stream, const char** name);
 // deferred per-call kernels (xsmm_defer.cpp)
 struct Kernel;
 bool defer_call(Kernel* k, const void* a, const void* b, void* c);  // true: recorded (runs later, in stream order)
-void defer_flush();                                                  // seal the calling thread's open burst
+void defer_flush();
+struct JitKernel;
+// per-panel calls of a fixed operator (libxsmm_?fsspmdm_execute) that walk along the rows of B and C: recorded like per-product calls
+bool defer_panels(const void* handle, JitKernel* jit, const void* B, void* C, int typesize, int M, int N, int K, long long ldb, long long ldc, int vec);                                                  // seal the calling thread's open burst
 extern thread_local bool tl_defer_open;
 
 // CSR "register" kernel family (fsspmdm sparse path, libxsmm_create_?csr_reg): row-major
@@ -107,7 +110,7 @@ int launch_csr_panels(const CsrPanels& args, void* stream, const char** name);
 // run-time specialised operator kernels (xsmm_jit.cpp)
 struct JitKernel;
 std::string gen_csr_panels_source(int typesize, int M, int K, const unsigned* rowptr, const unsigned* colidx, const double* values,
-                                  int beta0, int skip_empty_rows, int vec, const char* fname);
+                                  int beta0, int skip_empty_rows, int vec, const char* fname, bool burst_args = false);
 JitKernel* jit_compile(const std::string& src, const char* fname, std::string* log);
 JitKernel* jit_from_cache(const std::string& src, const char* fname); // only if the code-object cache on disk holds it
 int jit_build_offline(const std::string& src, std::string* log);      // compile into the cache on disk (no device needed); 0: there
@@ -117,7 +120,8 @@ void jit_async_wait();
 void jit_async_drain(); // drop queued compile jobs, wait for the running one                                                // until the compiler thread has nothing left to do
 int jit_check_source(const std::string& src, std::string* log);
 void jit_release(JitKernel* k);
-int jit_launch_panels(JitKernel* k, const void* B, void* C, long long ncols, long long ldb, long long ldc, int vec, void* stream);
+int jit_launch_panels(JitKernel* k, const void* B, void* C, long long ncols, long long ldb, long long ldc, int vec, void* stream,
+                      const unsigned long long* npanels = nullptr, long long panel = 0);
 int jit_blocks_per_cu(JitKernel* k, int threads); // occupancy of a generated kernel (0: unknown)
 int jit_launch_args(JitKernel* k, unsigned blocks, unsigned threads, void** args, void* stream);
 int jit_launch_raw(JitKernel* k, unsigned blocks, unsigned threads, void* arg0, size_t arg0_size, void* arg1, void* stream);

@@ -93,7 +93,7 @@ H* fsspmdm_create(libxsmm_blasint M, libxsmm_blasint N, libxsmm_blasint K, libxs
     if (vec < 1) vec = 1;
     std::vector<double> dv(values.begin(), values.end());
     const std::string src = gen_csr_panels_source((int)sizeof(T), (int)M, (int)K, rowptr.data(), colidx.data(), dv.data(),
-      h->beta0, 0/*empty rows are zeroed for beta == 0*/, vec, "xsmm_fsspmdm_op");
+      h->beta0, 0/*empty rows are zeroed for beta == 0*/, vec, "xsmm_fsspmdm_op", true);
     std::string log;
     h->jit = jit_compile(src, "xsmm_fsspmdm_op", &log);
     h->jit_vec = vec;
@@ -124,6 +124,10 @@ int fsspmdm_run(const H* h, const T* B, T* C, long long batch)
     const int e = launch_csr_panels(p, device().stream, &name); note_launch(name);
     return e;
   };
+  // one panel per call on device memory (the PyFR driver's loop, samples/pyfr/pyfr_driver_asp_reg.c:300-308): consecutive calls
+  // that walk along the rows are recorded into a burst instead of costing a launch each (xsmm_defer.cpp)
+  if (1 == batch && nullptr != h->jit && 0 == (h->N % h->jit_vec)
+    && defer_panels(h, h->jit, B, C, h->typesize, h->M, h->N, h->K, h->ldb, h->ldc, h->jit_vec)) return EXIT_SUCCESS;
   if (is_device_ptr(B) && is_device_ptr(C)) { const int e = launch(B, C); if (0 == e) settle(B, C); return 0 == e ? EXIT_SUCCESS : EXIT_FAILURE; }
   // host panels: stage rows [0,K) x columns [0, N*batch) of B and rows [0,M) of C (strided by ldb/ldc)
   const long long ncols = (long long)h->N * batch;

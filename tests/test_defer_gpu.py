@@ -19,6 +19,10 @@ LOOP_C = r"""
 typedef void (*fn3)(const void*, const void*, void*);
 void call_loop(fn3 f, const char* a, const char* b, char* c, const long long* ia, const long long* ib, const long long* ic, long long n, int ts)
 { long long i; for (i = 0; i < n; ++i) f(a + ia[i] * ts, b + ib[i] * ts, c + ic[i] * ts); }
+typedef void (*fnx)(const void*, const void*, void*);
+/* the PyFR driver's loop (samples/pyfr/pyfr_driver_asp_reg.c:300-308): execute(handle, B + z, C + z) for z = 0, nblock, 2 nblock, ... */
+void panel_loop(fnx execute, const void* handle, const char* b, char* c, long long n, long long nblock, int ts, int backwards)
+{ long long z; if (!backwards) for (z = 0; z < n; z += nblock) execute(handle, b + z * ts, c + z * ts); else for (z = n - nblock; z >= 0; z -= nblock) execute(handle, b + z * ts, c + z * ts); }
 void call_loop2(fn3 f0, fn3 f1, int period, const char* a, const char* b, char* c, const long long* ia, const long long* ib, const long long* ic, long long n, int ts)
 { long long i; for (i = 0; i < n; ++i) (((i / period) & 1) ? f1 : f0)(a + ia[i] * ts, b + ib[i] * ts, c + ic[i] * ts); }
 """
@@ -35,6 +39,7 @@ def loop(tmp_path_factory):
     vp, ll = C.c_void_p, C.c_longlong
     lib.call_loop.argtypes = [vp, vp, vp, vp, vp, vp, vp, ll, C.c_int]; lib.call_loop.restype = None
     lib.call_loop2.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, ll, C.c_int]; lib.call_loop2.restype = None
+    lib.panel_loop.argtypes = [vp, vp, vp, vp, ll, ll, C.c_int, C.c_int]; lib.panel_loop.restype = None
     return lib
 
 
@@ -216,3 +221,46 @@ def test_calls_during_stream_capture_are_launched(xs, orc, torch_gpu, scalar_ker
     finally:
         xs.lib().libxsmm_amd_set_stream(None)
     assert np.array_equal(dc.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("beta", [1.0, 0.0])
+def test_operator_applied_panel_by_panel(xs, orc, torch_gpu, loop, dtype, beta):
+    """libxsmm_?fsspmdm_execute once per 48-column panel (the PyFR driver's loop): the calls that walk along the rows are recorded
+    into a burst (one operator launch for all of them); a walk in the other direction, and a second operator in between, fall
+    back to a burst per call. Results equal the oracle's per-element chain, without a library call before the copy back."""
+    torch = torch_gpu
+    L = xs.lib()
+    M, K, N, panels = 35, 35, 48, 300
+    rng = np.random.default_rng(17)
+    A = np.ascontiguousarray(np.where(rng.random((M, K)) < 0.15, rng.uniform(-1, 1, (M, K)), 0.0).astype(dtype))
+    A[4, :] = 0.0
+    ntot = N * panels
+    B = rng.uniform(-1, 1, (K, ntot)).astype(dtype); Cin = rng.uniform(-1, 1, (M, ntot)).astype(dtype)
+    ref = Cin.copy()
+    h = orc.Fsspmdm(A, M, N, K, K, ntot, ntot, 1.0, beta, have_avx512=True)
+    for p in range(panels):
+        h.execute(B.reshape(-1)[p * N:], ref.reshape(-1)[p * N:])
+    h.close()
+    create = L.libxsmm_dfsspmdm_create if dtype == np.float64 else L.libxsmm_sfsspmdm_create
+    execute = L.libxsmm_dfsspmdm_execute if dtype == np.float64 else L.libxsmm_sfsspmdm_execute
+    destroy = L.libxsmm_dfsspmdm_destroy if dtype == np.float64 else L.libxsmm_sfsspmdm_destroy
+    hd = create(M, N, K, K, ntot, ntot, 1.0, beta, xs.dptr(A))
+    assert hd
+    fexec = C.cast(execute, C.c_void_p)
+    rows = [r for r in range(M) if r != 4]  # (the empty row: see test_sparse_gpu.py::test_fsspmdm_synthetic)
+    dB = torch.from_numpy(B).cuda()
+    try:
+        for backwards in (0, 1):
+            dC = torch.from_numpy(Cin).cuda()
+            torch.cuda.synchronize()
+            before = L.libxsmm_amd_launch_count()
+            loop.panel_loop(fexec, hd, dB.data_ptr(), dC.data_ptr(), ntot, N, B.itemsize, backwards)
+            got = dC.cpu().numpy()  # ordered behind the calls on the stream
+            launches = L.libxsmm_amd_launch_count() - before
+            assert np.array_equal(got[rows], ref[rows]), backwards
+            if not backwards:
+                assert launches <= 8, launches  # recorded: a handful of operator launches for 300 panels
+                assert xs.last_kernel().endswith("_jit_operator_deferred")
+    finally:
+        destroy(hd)

@@ -762,24 +762,30 @@ extern "C" __global__ __launch_bounds__(64 * XWAVES) void xsmm_smm_op(DevAddr ad
 const char* const SMM_JIT_MFMA_WAVE_BODY = R"XSMM(
 constexpr int M = XM, N = XN, K = XK;
 constexpr int TS = (int)sizeof(T);
-constexpr int VEC = 16 / TS;
-typedef T V __attribute__((ext_vector_type(VEC)));
+// XVEC: elements per memory access -- a 16-byte chunk where the shape and the operands' alignment allow it (M a multiple of the
+// chunk, K of four, 16-byte aligned items), else 1: any M, N, K and element-aligned operands (index and pointer batches)
+constexpr int VEC = XVEC;
+template<int W> struct VecOf { typedef T type __attribute__((ext_vector_type(W))); };
+template<> struct VecOf<1> { typedef T type; };
+typedef VecOf<VEC>::type V;
 typedef T ACC __attribute__((ext_vector_type(4)));
 typedef float ACC32 __attribute__((ext_vector_type(4)));
 typedef double ACC64 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ ACC32 xmfma(float a, float b, ACC32 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ ACC64 xmfma(double a, double b, ACC64 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
 constexpr bool F64 = (8 == TS);
-constexpr int MI = (M + 15) / 16, NI = (N + 15) / 16, KS = K / 4;
+// K is padded to a multiple of four with A = -0 and B = +0: the product -0 is the identity of the addition for every sum,
+// signs of zeros included, so the chain stays the reference's bit for bit (as in kernels/smm_mfma_wg.inc)
+constexpr int MI = (M + 15) / 16, NI = (N + 15) / 16, KS = (K + 3) / 4, KP4 = 4 * KS;
 constexpr int MS = (M <= 16) ? 16 : (M <= 48 ? 48 : 64);
 constexpr bool ASWZ = (64 == MS);
-constexpr int kstride() { int s = ((K + VEC - 1) / VEC); if (0 == (s & 1)) ++s; return s * VEC; }
+constexpr int kstride() { int s = ((KP4 + VEC - 1) / VEC); if (0 == (s & 1)) ++s; return s * VEC; }
 constexpr int KSD = kstride();
 // image of C: column stride such that the four column groups of a tile access fall into different banks
 constexpr int cstride() { int s = M; for (;; s += VEC) { if (F64 ? (16 == s % 32) : (4 == s % 16 || 12 == s % 16)) break; } return s; }
 constexpr int CSD = cstride();
 constexpr int C_ELEMS = N * CSD;
-constexpr int A_ELEMS = (C_ELEMS > K * MS) ? C_ELEMS : K * MS, B_ELEMS = N * KSD;
+constexpr int A_ELEMS = (C_ELEMS > KP4 * MS) ? C_ELEMS : KP4 * MS, B_ELEMS = N * KSD;
 #if XLOWP
 // bf16 inputs (XLOWP 3: fp32 result, 2: bf16 result) as the reference's low-precision kernels store them: A in pairs of k
 // (a[(k/2)*M*2 + m*2 + k%2]), B column-major -- both sequences of 32-bit k pairs. A 16-byte chunk is four pairs (A: four
@@ -800,7 +806,7 @@ __device__ __forceinline__ void widen8(UV p, V& v0, V& v1)
 #else
 constexpr int NCA = M * K / VEC, NCB = K * N / VEC, NCC = M * N / VEC;
 typedef V UV;
-static_assert(0 == M % VEC && 0 == K % 4, "shape");
+static_assert(1 == VEC || (0 == M % VEC && 0 == K % 4), "shape");
 #endif
 constexpr int CA = (NCA + 63) / 64, CB = (NCB + 63) / 64, CC = (NCC + 63) / 64;
 __device__ __forceinline__ int clampi(int v, int hi) { return v < hi ? v : hi; }
@@ -852,14 +858,22 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(X
   if (item >= batch) return;
   load_ab(item);
   if (!XBETA0) load_c(item);
+  if (KP4 > K) { // the padding of B's image: written once (its place is not shared)
+    for (int e = lane; e < N * (KP4 - K); e += 64) Bs[(e / (KP4 - K)) * KSD + K + e % (KP4 - K)] = T(0);
+  }
   for (;;) {
     __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): this item's operands (the only other instructions in flight are older stores)
     if (0 <= prev) { store_c(prev); wave_lds_sync(); }
+    // (the places in the images a lane parks its pieces at do not change from item to item: left to the compiler they are all
+    // computed once and kept in registers -- a hundred of them in the element-wise form, which then spills. Recomputed per item
+    // from a lane index the compiler cannot see through.)
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
     ACC acc[NI][MI];
     if (!XBETA0) {
 #pragma unroll
       for (int j = 0; j < CC; ++j) {
-        const int ch = clampi(64 * j + lane, NCC - 1);
+        const int ch = clampi(64 * j + ln, NCC - 1);
 #if (2 == XLOWP)
         const int e = ch * 8, n = e / M, m = e % M;
         V v0, v1; widen8(rc[j], v0, v1);
@@ -887,9 +901,12 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(X
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = ACC{ 0, 0, 0, 0 };
     }
+    if (KP4 > K) { // the padding rows of A's image (the image of C has been lying over them)
+      for (int e = lane; e < (KP4 - K) * MS; e += 64) As[K * MS + e] = -T(0);
+    }
 #pragma unroll
     for (int j = 0; j < CA; ++j) {
-      const int ch = clampi(64 * j + lane, NCA - 1);
+      const int ch = clampi(64 * j + ln, NCA - 1);
 #if XLOWP
       const int w = ch * 4, sp = w / M, m = w % M, k0 = 2 * sp, k1 = 2 * sp + 1; // four rows of the k pair (2 sp, 2 sp + 1)
       *reinterpret_cast<V*>(As + k0 * MS + (ASWZ ? (m ^ ((k0 & 3) << 4)) : m)) = widen_lo(ra[j]);
@@ -901,7 +918,7 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(X
     }
 #pragma unroll
     for (int j = 0; j < CB; ++j) {
-      const int ch = clampi(64 * j + lane, NCB - 1);
+      const int ch = clampi(64 * j + ln, NCB - 1);
 #if XLOWP
       const int e = ch * 8, n = e / K, k = e % K; // eight consecutive k of column n
       V v0, v1; widen8(rb[j], v0, v1);
@@ -1075,14 +1092,16 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(X
 )XSMM";
 
 // LDS bytes of a wave of that kernel (mirrors the constexpr arithmetic of the source); 0: the shape is not served
-static size_t smm_mfma_wave_lds(int typesize, int m, int n, int k)
-{
-  const int vec = 16 / typesize;
-  if (0 != m % vec || 0 != k % 4 || m > 64 || n > 64 || k > 64 || k < 4) return 0;
+static size_t smm_mfma_wave_lds(int typesize, int m, int n, int k, int vec = 0)
+{ // vec: elements per memory access (0: a 16-byte chunk)
+  if (0 == vec) vec = 16 / typesize;
+  if (m > 64 || n > 64 || k > 64 || m < 1 || n < 1 || k < 1) return 0;
+  if (1 != vec && (0 != m % vec || 0 != k % 4)) return 0;
+  const int kp4 = 4 * ((k + 3) / 4);
   const int ms = (m <= 16) ? 16 : (m <= 48 ? 48 : 64);
-  int ksd = (k + vec - 1) / vec; if (0 == (ksd & 1)) ++ksd; ksd *= vec;
+  int ksd = (kp4 + vec - 1) / vec; if (0 == (ksd & 1)) ++ksd; ksd *= vec;
   int csd = m; for (;; csd += vec) { if (8 == typesize ? (16 == csd % 32) : (4 == csd % 16 || 12 == csd % 16)) break; }
-  const int a_elems = (n * csd > k * ms) ? n * csd : k * ms;
+  const int a_elems = (n * csd > kp4 * ms) ? n * csd : kp4 * ms;
   return (size_t)(a_elems + n * ksd + 64) * typesize;
 }
 // ... of the form that works on the columns of C in two halves (0: not served)
@@ -1098,7 +1117,15 @@ static size_t smm_mfma_wave2_lds(int typesize, int m, int n, int k)
 }
 // waves per SIMD the kernel is compiled for: two where LDS leaves room for eight waves per CU, else one (the register file
 // then holds an item's operands, the next item's and the accumulators without spilling)
-static int smm_mfma_wave_wpe(size_t lds) { return (8 * lds <= 160u * 1024u) ? 2 : 1; }
+static int smm_mfma_wave_wpe(size_t lds, int typesize = 0, int m = 0, int n = 0, int k = 0, int vec = 0)
+{
+  if (8 * lds > 160u * 1024u) return 1;
+  if (1 == vec) { // element-wise form: a register per element in flight plus what parking them costs (45^3 fp32 spills at two waves per SIMD)
+    const int w = typesize / 4, regs = w * ((m * k + 63) / 64 + (k * n + 63) / 64 + (m * n + 63) / 64) + w * 4 * ((m + 15) / 16) * ((n + 15) / 16);
+    if (regs > 125) return 1;
+  }
+  return 2;
+}
 
 // ---- shapes with 32 < M or N <= 64: one work-group (256 threads, 16 x 16) per item, K in chunks of KC through LDS ------
 const char* const SMM_JIT_BIG_BODY = R"XSMM(
@@ -1344,14 +1371,15 @@ std::string gen_smm_source(int typesize, int m, int n, int k, int flags, int var
   s += std::string("#define XBETA0 ") + ((flags & LIBXSMM_GEMM_FLAG_BETA_0) ? "1" : "0") + "\n";
   s += std::string("#define XTRANSB ") + ((flags & LIBXSMM_GEMM_FLAG_TRANS_B) ? "1" : "0") + "\n";
   if (0 != (variant & SMM_JIT_MFMA_WAVE2)) { // ... the columns of C in two halves
-    s += "#define XFLAT 0\n#define XWPE 1\n#define XNSPLIT 2\n";
+    s += "#define XFLAT 0\n#define XWPE 1\n#define XNSPLIT 2\n#define XVEC " + std::to_string(16 / typesize) + "\n";
     s += SMM_JIT_PRELUDE;
     s += SMM_JIT_MFMA_WAVE_BODY;
     return s;
   }
   if (0 != (variant & SMM_JIT_MFMA_WAVE)) { // matrix-core kernel, one wave per item
-    s += "#define XNSPLIT 1\n";
-    s += "#define XFLAT 0\n#define XWPE " + std::to_string(smm_mfma_wave_wpe(smm_mfma_wave_lds(typesize, m, n, k))) + "\n";
+    const int wvec = (0 != (variant & SMM_JIT_SCALAR)) ? 1 : 16 / typesize;
+    s += "#define XNSPLIT 1\n#define XVEC " + std::to_string(wvec) + "\n";
+    s += "#define XFLAT 0\n#define XWPE " + std::to_string(smm_mfma_wave_wpe(smm_mfma_wave_lds(typesize, m, n, k, wvec), typesize, m, n, k, wvec)) + "\n";
     s += SMM_JIT_PRELUDE;
     s += SMM_JIT_MFMA_WAVE_BODY;
     return s;
@@ -1759,21 +1787,24 @@ int launch_smm_jit_mfma(const SmmBatch& s, void* stream, const char** name)
   const bool f64 = (8 == s.typesize);
   { // one wave per item: independent items of a strided batch, tight and 16-byte aligned operands, at least four waves per CU
     static const int wave_on = []() { const char* e = getenv("XSMM_SMMJIT_MFMA_WAVE"); return (nullptr != e && 0 != *e) ? atoi(e) : 1; }(); // developer knob
-    const size_t wlds = smm_mfma_wave_lds(s.typesize, s.m, s.n, s.k);
+    // 16-byte chunks for strided batches of suitably shaped and aligned items, else element by element (any shape, index and
+    // pointer batches: the kernel resolves the addresses like every other batch kernel)
     const uintptr_t bits = reinterpret_cast<uintptr_t>(s.a) | reinterpret_cast<uintptr_t>(s.b) | reinterpret_cast<uintptr_t>(s.c)
                          | (uintptr_t)(s.sa * s.typesize) | (uintptr_t)(s.sb * s.typesize) | (uintptr_t)(s.sc * s.typesize);
-    if (0 != wave_on && 0 != wlds && 4 * wlds <= 160u * 1024u && SYNC_NONE == s.sync && ADDR_STRIDED == s.mode && 0 == (bits & 15)
-      && s.lda == s.m && s.ldb == s.k && s.ldc == s.m)
+    const int chunk = 16 / s.typesize;
+    const bool wide = (ADDR_STRIDED == s.mode && 0 == (bits & 15) && 0 == s.m % chunk && 0 == s.k % 4);
+    const size_t wlds = smm_mfma_wave_lds(s.typesize, s.m, s.n, s.k, wide ? chunk : 1);
+    if (0 != wave_on && 0 != wlds && 4 * wlds <= 160u * 1024u && SYNC_NONE == s.sync && s.lda == s.m && s.ldb == s.k && s.ldc == s.m)
     {
-      const SmmKey wkey = { s.typesize, s.m, s.n, s.k, s.flags & LIBXSMM_GEMM_FLAG_BETA_0, SMM_JIT_MFMA_WAVE, s.lda, s.ldb, s.ldc };
+      const SmmKey wkey = { s.typesize, s.m, s.n, s.k, s.flags & LIBXSMM_GEMM_FLAG_BETA_0, SMM_JIT_MFMA_WAVE | (wide ? 0 : SMM_JIT_SCALAR), s.lda, s.ldb, s.ldc };
       JitKernel* const wk = smm_jit_get(wkey);
       if (nullptr != wk) {
         struct { const char* a; const char* b; char* c; const char* ia; const char* ib; const char* ic; long long sa, sb, sc; int index_base, index_stride, mode; const int* flags; } wad;
-        wad.a = (const char*)s.a; wad.b = (const char*)s.b; wad.c = (char*)s.c; wad.ia = wad.ib = wad.ic = nullptr;
-        wad.sa = s.sa; wad.sb = s.sb; wad.sc = s.sc; wad.index_base = 0; wad.index_stride = 0; wad.mode = 0; wad.flags = nullptr;
+        wad.a = (const char*)s.a; wad.b = (const char*)s.b; wad.c = (char*)s.c; wad.ia = (const char*)s.ia; wad.ib = (const char*)s.ib; wad.ic = (const char*)s.ic;
+        wad.sa = s.sa; wad.sb = s.sb; wad.sc = s.sc; wad.index_base = s.index_base; wad.index_stride = s.index_stride; wad.mode = s.mode; wad.flags = nullptr;
         long long wbatch = s.batch; int one = 1;
         int per_cu = (int)((160u * 1024u) / wlds);
-        const int by_regs = 4 * smm_mfma_wave_wpe(wlds);
+        const int by_regs = 4 * smm_mfma_wave_wpe(wlds, s.typesize, s.m, s.n, s.k, wide ? chunk : 1);
         if (per_cu > by_regs) per_cu = by_regs;
         long long wblocks = 256LL * per_cu;
         if (wblocks > s.batch) wblocks = s.batch;
@@ -1961,7 +1992,7 @@ int smm_jit_prebuild(const SmmBatch* shapes, int nshapes, int grouped, int* buil
         const size_t wlds = smm_mfma_wave_lds(s.typesize, s.m, s.n, s.k);
         const bool f64 = (8 == s.typesize);
         const size_t w2lds = f64 ? smm_mfma_wave2_lds(s.typesize, s.m, s.n, s.k) : 0;
-        if (0 != wlds && 4 * wlds <= 160u * 1024u && s.lda == s.m && s.ldb == s.k && s.ldc == s.m) one(SMM_JIT_MFMA_WAVE);
+        if (0 != wlds && 4 * wlds <= 160u * 1024u && s.lda == s.m && s.ldb == s.k && s.ldc == s.m) { one(SMM_JIT_MFMA_WAVE); one(SMM_JIT_MFMA_WAVE | SMM_JIT_SCALAR); }
         else if (0 != w2lds && 4 * w2lds <= 160u * 1024u && !(64 == s.m && 64 == s.n) && s.lda == s.m && s.ldb == s.k && s.ldc == s.m) one(SMM_JIT_MFMA_WAVE2);
         else if (!(!f64 && 64 == s.m && 64 == s.n && 64 == s.k && 64 == s.lda && 64 == s.ldb && 64 == s.ldc)) {
           const bool tight = !f64 && s.lda == s.m && s.ldb == s.k && 0 == ((s.m * s.k) & 3) && 0 == ((s.k * s.n) & 3);

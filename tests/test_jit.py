@@ -46,6 +46,13 @@ def test_generated_sources_compile_for_gfx950(xs):
                 blob, d = xs.descriptor(prec, m, n, k, beta=beta)
                 assert 0 == L.libxsmm_amd_smm_kernel_source(d, 16384, buf, len(buf), 1), (prec, m, n, k, beta)
                 assert "xmfma" in buf.value.decode() and "#define XWPE" in buf.value.decode()
+    # ... element by element (variant bits 16384 | 1): any shape, K padded to a multiple of four
+    for prec in (xs.F32, xs.F64):
+        for (m, n, k) in [(33, 33, 33), (45, 37, 19), (64, 5, 7), (40, 40, 40), (57, 39, 1)]:
+            for beta in (1.0, 0.0):
+                blob, d = xs.descriptor(prec, m, n, k, beta=beta)
+                assert 0 == L.libxsmm_amd_smm_kernel_source(d, 16384 | 1, buf, len(buf), 1), (prec, m, n, k, beta)
+                assert "#define XVEC 1\n" in buf.value.decode()
     # ... the fp64 form that works on the columns of C in two halves (variant bit 32768)
     for (m, n, k) in [(56, 56, 56), (16, 64, 64), (64, 56, 56)]:
         for beta in (1.0, 0.0):

@@ -155,25 +155,29 @@ MFMA_WG_SHAPES = [  # 32 < max(M, N) <= 64, K <= 64: tight and with gaps, odd K 
 
 def mfma_wave_serves(dtype, m, n, k, lda, ldb, ldc):
     """mirror of smm_mfma_wave_lds / smm_mfma_wave2_lds and the eligibility rules in csrc/xsmm_jit_smm.cpp: the one-wave-per-item
-    matrix-core kernel takes tight operands with M a multiple of a 16-byte chunk and K a multiple of four whose LDS images leave
-    room for four waves per CU ("wave"); fp64 items too large for that are worked on in two halves of C's columns ("wave2",
-    not for 64 x 64 x K). None: the work-group form."""
+    matrix-core kernel takes tight operands whose LDS images leave room for four waves per CU ("wave": 16-byte chunks when M is a
+    multiple of a chunk and K of four, else element by element); fp64 items too large for that are worked on in two halves of
+    C's columns ("wave2", not for 64 x 64 x K). None: the work-group form."""
     ts = np.dtype(dtype).itemsize
-    vec = 16 // ts
-    if (lda, ldb, ldc) != (m, k, m) or m % vec or k % 4 or max(m, n) <= 32:
+    chunk = 16 // ts
+    if (lda, ldb, ldc) != (m, k, m) or max(m, n) <= 32:
         return None
+    vec = chunk if (m % chunk == 0 and k % 4 == 0) else 1
+    kp4 = 4 * ((k + 3) // 4)
     ms = 16 if m <= 16 else (48 if m <= 48 else 64)
-    ksd = (k + vec - 1) // vec
+    ksd = (kp4 + vec - 1) // vec
     ksd = (ksd + 1 if ksd % 2 == 0 else ksd) * vec
     csd = m
     while not ((csd % 32 == 16) if ts == 8 else (csd % 16 in (4, 12))):
         csd += vec
-    lds = (max(n * csd, k * ms) + n * ksd + 64) * ts
+    lds = (max(n * csd, kp4 * ms) + n * ksd + 64) * ts
     if 4 * lds <= 160 * 1024:
         return "wave"
     nh = n // 2
-    if ts == 8 and n % 2 == 0 and (k * nh) % vec == 0 and (m * nh) % vec == 0 and not (m == 64 and n == 64):
-        lds2 = (k * m + max(nh * ksd, nh * m) + 64) * ts
+    if ts == 8 and vec == chunk and n % 2 == 0 and (k * nh) % vec == 0 and (m * nh) % vec == 0 and not (m == 64 and n == 64):
+        ksd2 = (k + vec - 1) // vec
+        ksd2 = (ksd2 + 1 if ksd2 % 2 == 0 else ksd2) * vec
+        lds2 = (k * m + max(nh * ksd2, nh * m) + 64) * ts
         if 4 * lds2 <= 160 * 1024:
             return "wave2"
     return None
@@ -224,8 +228,39 @@ def test_smm_mfma_wg(xs, orc, torch_gpu, dtype, shape, beta, specialised):
     assert np.array_equal(out.view(bits), ref.view(bits))
 
 
+def test_smm_mfma_wave_index_batches(xs, orc, torch_gpu):
+    """index batches whose C blocks the caller promises to be distinct (negative batch size) reach the one-wave-per-item kernel in
+    its element-wise form: shuffled operands, index base 1"""
+    torch = torch_gpu
+    old_jit = os.environ.get("LIBXSMM_AMD_JIT")
+    os.environ["LIBXSMM_AMD_JIT"] = "1"; os.environ["LIBXSMM_AMD_JIT_MINBATCH"] = "1"
+    old = xs.lib().libxsmm_amd_set_mfma(1)
+    try:
+        for dtype, prec in ((np.float64, xs.F64), (np.float32, xs.F32)):
+            for (m, n, k) in ((40, 40, 40), (33, 35, 37)):
+                batch = 1500
+                rng = np.random.default_rng(m + n)
+                a = rng.uniform(-1, 1, batch * m * k).astype(dtype); b = rng.uniform(-1, 1, batch * k * n).astype(dtype); c = rng.uniform(-1, 1, batch * m * n).astype(dtype)
+                pa, pb = rng.permutation(batch), rng.permutation(batch)
+                sa = (pa * m * k + 1).astype(np.int32); sb = (pb * k * n + 1).astype(np.int32); sc = (np.arange(batch) * m * n + 1).astype(np.int32)
+                ref = c.copy()
+                orc.gemm_batch_idx(orc.FMA, 0, m, n, k, m, k, m, a, b, ref, 1, sa, sb, sc, batch)
+                da, db, dc = (torch.from_numpy(x).cuda() for x in (a, b, c))
+                xs.gemm_batch(prec, "N", "N", m, n, k, 1.0, da, m, db, k, 1.0, dc, m, 1, 4, sa, sb, sc, -batch)
+                torch.cuda.synchronize()
+                assert xs.last_kernel() == ("smm_f64_mfma_wave_jit" if dtype == np.float64 else "smm_f32_mfma_wave_jit"), xs.last_kernel()
+                assert np.array_equal(dc.cpu().numpy(), ref), (dtype, m, n, k)
+    finally:
+        xs.lib().libxsmm_amd_set_mfma(old)
+        os.environ.pop("LIBXSMM_AMD_JIT_MINBATCH", None)
+        if old_jit is None:
+            del os.environ["LIBXSMM_AMD_JIT"]
+        else:
+            os.environ["LIBXSMM_AMD_JIT"] = old_jit
+
+
 MFMA_WAVE_SHAPES = [(40, 40, 40), (48, 48, 48), (56, 56, 56), (36, 64, 8), (64, 20, 12), (44, 52, 36), (64, 64, 60), (16, 48, 64), (34, 40, 4),
-                    (16, 64, 64), (56, 64, 48), (64, 56, 56)]
+                    (16, 64, 64), (56, 64, 48), (64, 56, 56), (33, 33, 33), (45, 37, 19), (57, 39, 1), (64, 5, 7), (35, 64, 62)]
 
 
 @pytest.mark.parametrize("shape", MFMA_WAVE_SHAPES)

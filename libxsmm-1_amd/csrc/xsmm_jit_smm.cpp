@@ -1119,6 +1119,8 @@ static size_t smm_mfma_wave2_lds(int typesize, int m, int n, int k)
 // then holds an item's operands, the next item's and the accumulators without spilling)
 static int smm_mfma_wave_wpe(size_t lds, int typesize = 0, int m = 0, int n = 0, int k = 0, int vec = 0)
 {
+  static const int env = []() { const char* e = getenv("XSMM_SMMJIT_WAVE_WPE"); return (nullptr != e && 0 != *e) ? atoi(e) : 0; }(); // developer knob
+  if (0 < env) return env;
   if (8 * lds > 160u * 1024u) return 1;
   if (1 == vec) { // element-wise form: a register per element in flight plus what parking them costs (45^3 fp32 spills at two waves per SIMD)
     const int w = typesize / 4, regs = w * ((m * k + 63) / 64 + (k * n + 63) / 64 + (m * n + 63) / 64) + w * 4 * ((m + 15) / 16) * ((n + 15) / 16);

@@ -151,6 +151,15 @@ Ring* my_ring()
   return ok ? r : nullptr;
 }
 
+// a stream that is being captured takes no part in bursts (a call appended to a burst queued before the capture began would run
+// outside the graph)
+bool capturing_now(void* stream)
+{
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipSuccess != hipStreamIsCapturing((hipStream_t)stream, &st)) { (void)hipGetLastError(); return true; }
+  return hipStreamCaptureStatusNone != st;
+}
+
 bool defer_enabled()
 {
   static const int env = []() { const char* e = getenv("LIBXSMM_AMD_DEFER"); return (nullptr == e || 0 == *e) ? 1 : atoi(e); }();
@@ -248,7 +257,7 @@ bool defer_call(Kernel* k, const void* a, const void* b, void* c)
   const uintptr_t pa = reinterpret_cast<uintptr_t>(a), pb = reinterpret_cast<uintptr_t>(b), pc = reinterpret_cast<uintptr_t>(c);
   for (int attempt = 0; attempt < 2; ++attempt) {
     if (tl_defer_open) {
-      bool fits = (r.kernel == k && r.stream == device_raw().stream && r.ncalls < DEFER_CAP);
+      bool fits = (r.kernel == k && r.stream == device_raw().stream && r.ncalls < DEFER_CAP && !capturing_now(r.stream));
       // operands inside device allocations already seen in this burst? (anything else is looked up, below, in a new burst)
       auto known = [&](uintptr_t p, size_t n) { return r.known[0].has(p, n) || r.known[1].has(p, n) || r.known[2].has(p, n); };
       fits = fits && known(pa, bytes_a) && known(pb, bytes_b) && known(pc, bytes_c);
@@ -309,7 +318,7 @@ bool defer_panels(const void* handle, JitKernel* jit, const void* B, void* C, in
   const size_t ts = (size_t)typesize, step = (size_t)N * ts;
   if (tl_defer_open) {
     if (r.panel_handle == handle && r.stream == device_raw().stream && r.ncalls < r.max_panels
-      && pb == r.b0 + (size_t)r.ncalls * step && pc == r.c0 + (size_t)r.ncalls * step)
+      && pb == r.b0 + (size_t)r.ncalls * step && pc == r.c0 + (size_t)r.ncalls * step && !capturing_now(r.stream))
     {
       Slot& sl = r.slot[r.mine];
       unsigned long long expect = (unsigned long long)r.ncalls;

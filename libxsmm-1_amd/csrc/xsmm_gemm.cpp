@@ -28,7 +28,8 @@ int run_smm(const SmmBatch& s)
 {
   const char* name = "";
   int e = -1;
-  if (0 == s.general && (32 < s.m || 32 < s.n)) e = launch_smm_jit_mfma(s, device().stream, &name); // matrix-core work-group kernel of this very descriptor
+  static const int wave_min = []() { const char* w = getenv("XSMM_SMMJIT_WAVE_MIN"); return (nullptr != w && 0 != *w) ? atoi(w) : 32; }();
+  if (0 == s.general && (wave_min < s.m || wave_min < s.n)) e = launch_smm_jit_mfma(s, device().stream, &name); // matrix-core work-group kernel of this very descriptor
   if (e < 0 && 0 == s.general) e = launch_smm_special(s, device().stream, &name);  // hand-tuned shapes; the same kernels for any descriptor
   if (e < 0 && smm_jit_eligible(s)) {                                               // shape-specialised via hiprtc
     e = launch_smm_jit(s, device().stream, &name); // (SYNC_DEVICE: whatever the verdict on the device, one of its kernels works)

@@ -1777,7 +1777,8 @@ int launch_smm_jit_mfma(const SmmBatch& s, void* stream, const char** name)
   if (nullptr != env_jit && 0 == atoi(env_jit)) return -1;
   static const int on = []() { const char* e = getenv("XSMM_SMMJIT_MFMA"); return (nullptr != e && 0 != *e) ? atoi(e) : 1; }(); // developer knob
   if (0 == on || 0 == s.use_mfma || 0 != s.general || 0 != s.lowp) return -1;
-  if (!((32 < s.m || 32 < s.n) && s.m <= 64 && s.n <= 64 && 0 < s.k && s.k <= 64 && s.lda >= s.m && s.ldb >= s.k && s.ldc >= s.m)) return -1;
+  static const int wave_min = []() { const char* e = getenv("XSMM_SMMJIT_WAVE_MIN"); return (nullptr != e && 0 != *e) ? atoi(e) : 32; }(); // developer knob: the wave form below 33
+  if (!((wave_min < s.m || wave_min < s.n) && s.m <= 64 && s.n <= 64 && 0 < s.k && s.k <= 64 && s.lda >= s.m && s.ldb >= s.k && s.ldc >= s.m)) return -1;
   if (0 != (s.flags & LIBXSMM_GEMM_FLAG_TRANS_B)) return -1;
   if (4 == s.typesize && 64 == s.m && 64 == s.n && 64 == s.k && 64 == s.lda && 64 == s.ldb && 64 == s.ldc && SYNC_NONE == s.sync) return -1; // the hand-tuned tight 64^3 kernel
   long long units = 0; int runlen = 1;
@@ -1840,6 +1841,7 @@ int launch_smm_jit_mfma(const SmmBatch& s, void* stream, const char** name)
       }
     }
   }
+  if (!(32 < s.m || 32 < s.n)) return -1; // (the work-group forms below are for shapes beyond 32)
   const bool tight = !f64 && s.lda == s.m && s.ldb == s.k && 0 == ((s.m * s.k) & 3) && 0 == ((s.k * s.n) & 3);
   static const int tightc_on = []() { const char* e = getenv("XSMM_SMM64_TIGHTC"); return (nullptr != e && 0 != *e) ? atoi(e) : 1; }();
   const bool tightc = !f64 && s.ldc == s.m && 0 == ((s.m * s.n) & 3) && 0 != (s.m & 31) && 0 != tightc_on;

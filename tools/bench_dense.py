@@ -86,7 +86,7 @@ if os.environ.get("DENSE_SHAPES"):  # e.g. DENSE_SHAPES=5x5x5,13x13x13
     shapes = [tuple(int(v) for v in t.split("x")) for t in os.environ["DENSE_SHAPES"].split(",")]
 for dt in ([torch.float64] if which == "f64" else [torch.float32] if which == "f32" else [torch.float64, torch.float32]):
     for (m, n, k) in shapes:
-        for mfma in ((0, 1) if (dt == torch.float32 and (m, n, k) == (32, 32, 32)) or max(m, n) > 32 else (0,)):
+        for mfma in ((0, 1) if (dt == torch.float32 and (m, n, k) == (32, 32, 32)) or max(m, n) > 32 or os.environ.get("DENSE_BOTH") else (0,)):
             run(dt, m, n, k, mfma)
 if not os.environ.get("DENSE_SHAPES"):
     run(torch.float64, 23, 23, 23, 0, beta=0.0)

@@ -112,9 +112,15 @@ def main():
     B = args.batch
     # synthetic data of the configured shape: uniform [-0.5, 0.5) (random data: zero/trivial operands flatter the clock)
     g = torch.Generator(device="cuda"); g.manual_seed(1 + rank)
-    a = torch.rand(B * M * K, device="cuda", dtype=torch.float32, generator=g) - 0.5
-    b = torch.rand(B * K * N, device="cuda", dtype=torch.float32, generator=g) - 0.5
-    c = torch.rand(B * M * N, device="cuda", dtype=torch.float32, generator=g) - 0.5
+    # Placement in HBM: the three arrays are pieces of one allocation, B and C 8 KiB and 16 KiB off the spacing of the arrays. A
+    # wave reads a[i], b[i] and c[i] at the same time; when the three land at the same offset modulo the memory system's
+    # interleave (three separate 4 GiB allocations do so in some processes and not in others) the kernel takes 3.3 ms instead of
+    # 2.9-3.0 ms (tools/probe_headline_offsets.py, profiles/r2_headline_placement.txt). Items stay contiguous and 16-byte aligned.
+    na, nb, nc = B * M * K, B * K * N, B * M * N
+    skew = 2048  # floats = 8 KiB
+    pool = torch.empty(na + nb + nc + 3 * skew, device="cuda", dtype=torch.float32)
+    pool.uniform_(-0.5, 0.5, generator=g)
+    a = pool[0:na]; b = pool[na + skew:na + skew + nb]; c = pool[na + nb + 2 * skew:na + nb + 2 * skew + nc]
     blob, desc = xs.descriptor(xs.F32, M, N, K, M, K, M, 1.0, 1.0)
     assert desc, "descriptor rejected"
     if args.mode == "index":

@@ -36,8 +36,14 @@ if what == "spmdm":
     density = float(os.environ.get("SP_DENSITY", "0.5"))
     a = torch.rand(B * M * K, device="cuda", generator=g) - 0.5
     a = torch.where(torch.rand(B * M * K, device="cuda", generator=g) < density, a, torch.zeros_like(a))
-    b = torch.rand(B * K * N, device="cuda", generator=g) - 0.5
-    c = torch.zeros(B * M * N, device="cuda")
+    if os.environ.get("SP_PLACED", "1") != "0":  # B and C out of one allocation, C 8 KiB off (see profiles/r2_headline_placement.txt)
+        nb_, nc_ = B * K * N, B * M * N
+        ob_ = (nb_ + 63) // 64 * 64 + 2048
+        pool = torch.rand(ob_ + nc_, device="cuda", generator=g) - 0.5
+        b = pool[0:nb_]; c = pool[ob_:ob_ + nc_]; c.zero_()
+    else:
+        b = torch.rand(B * K * N, device="cuda", generator=g) - 0.5
+        c = torch.zeros(B * M * N, device="cuda")
     sb = L.libxsmm_amd_spmdm_batch_create(M, N, K, B)
     for beta_v in (0.0, 1.0):
         beta = C.c_float(beta_v)

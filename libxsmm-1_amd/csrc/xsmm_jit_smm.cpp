@@ -792,6 +792,8 @@ constexpr int A_ELEMS = (C_ELEMS > KP4 * MS) ? C_ELEMS : KP4 * MS, B_ELEMS = N *
 // rows m of one pair of k; B: eight consecutive k of one column); the halves are widened on the way into the same fp32 LDS
 // images (a bf16 product is exact in fp32, so fma(a, b, acc) is the gold loop's product-then-add, samples/xgemm/kernel.c).
 typedef unsigned UV __attribute__((ext_vector_type(4)));
+constexpr int LDA = M, LDB = K, LDC = M;
+constexpr bool TIGHT = true;
 constexpr int NCA = M * K / 8, NCB = K * N / 8;                    // chunks per operand
 constexpr int NCC = (2 == XLOWP) ? (M * N / 8) : (M * N / 4);
 static_assert(0 == M % 4 && 0 == K % 8 && (2 != XLOWP || 0 == M % 8), "shape");
@@ -804,9 +806,13 @@ __device__ __forceinline__ void widen8(UV p, V& v0, V& v1)
   v1 = V{ __uint_as_float(p[2] << 16), __uint_as_float(p[2] & 0xFFFF0000u), __uint_as_float(p[3] << 16), __uint_as_float(p[3] & 0xFFFF0000u) };
 }
 #else
-constexpr int NCA = M * K / VEC, NCB = K * N / VEC, NCC = M * N / VEC;
+// Leading dimensions as in memory (gaps only in the element-wise build): an operand is fetched as the one span of memory it
+// occupies, elements in the gaps are dropped on the way into the images and never written on the way out.
+constexpr int LDA = XLDA, LDB = XLDB, LDC = XLDC;
+constexpr bool TIGHT = (LDA == M && LDB == K && LDC == M);
+constexpr int NCA = (LDA * (K - 1) + M) / VEC, NCB = (LDB * (N - 1) + K) / VEC, NCC = (LDC * (N - 1) + M) / VEC;
 typedef V UV;
-static_assert(1 == VEC || (0 == M % VEC && 0 == K % 4), "shape");
+static_assert(1 == VEC || (TIGHT && 0 == M % VEC && 0 == K % 4), "shape");
 #endif
 constexpr int CA = (NCA + 63) / 64, CB = (NCB + 63) / 64, CC = (NCC + 63) / 64;
 __device__ __forceinline__ int clampi(int v, int hi) { return v < hi ? v : hi; }
@@ -849,8 +855,8 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(X
                        (__float_as_uint(v1[0]) >> 16) | (__float_as_uint(v1[1]) & 0xFFFF0000u), (__float_as_uint(v1[2]) >> 16) | (__float_as_uint(v1[3]) & 0xFFFF0000u) };
       __builtin_nontemporal_store(w, pc + ch);
 #else
-      const int e = ch * VEC, n = e / M, m = e % M;
-      __builtin_nontemporal_store(*reinterpret_cast<const UV*>(Cs + n * CSD + m), pc + ch);
+      const int e = ch * VEC, n = e / LDC, m = e % LDC;
+      if (TIGHT || m < M) __builtin_nontemporal_store(*reinterpret_cast<const UV*>(Cs + n * CSD + (TIGHT ? m : clampi(m, M - 1))), pc + ch);
 #endif
     }
   };
@@ -879,8 +885,8 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(X
         V v0, v1; widen8(rc[j], v0, v1);
         *reinterpret_cast<V*>(Cs + n * CSD + m) = v0; *reinterpret_cast<V*>(Cs + n * CSD + m + 4) = v1;
 #else
-        const int e = ch * VEC, n = e / M, m = e % M;
-        *reinterpret_cast<UV*>(Cs + n * CSD + m) = rc[j];
+        const int e = ch * VEC, n = e / LDC, m = e % LDC;
+        *reinterpret_cast<UV*>((TIGHT || m < M) ? Cs + n * CSD + m : dummy + lane) = rc[j];
 #endif
       }
       wave_lds_sync();
@@ -912,8 +918,8 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(X
       *reinterpret_cast<V*>(As + k0 * MS + (ASWZ ? (m ^ ((k0 & 3) << 4)) : m)) = widen_lo(ra[j]);
       *reinterpret_cast<V*>(As + k1 * MS + (ASWZ ? (m ^ ((k1 & 3) << 4)) : m)) = widen_hi(ra[j]);
 #else
-      const int e = ch * VEC, k = e / M, m = e % M;
-      *reinterpret_cast<V*>(As + k * MS + (ASWZ ? (m ^ ((k & 3) << 4)) : m)) = ra[j];
+      const int e = ch * VEC, k = e / LDA, m = e % LDA;
+      *reinterpret_cast<V*>((TIGHT || m < M) ? As + k * MS + (ASWZ ? (m ^ ((k & 3) << 4)) : m) : dummy + lane) = ra[j];
 #endif
     }
 #pragma unroll
@@ -924,8 +930,8 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(X
       V v0, v1; widen8(rb[j], v0, v1);
       *reinterpret_cast<V*>(Bs + n * KSD + k) = v0; *reinterpret_cast<V*>(Bs + n * KSD + k + 4) = v1;
 #else
-      const int e = ch * VEC, n = e / K, k = e % K;
-      *reinterpret_cast<V*>(Bs + n * KSD + k) = rb[j];
+      const int e = ch * VEC, n = e / LDB, k = e % LDB;
+      *reinterpret_cast<V*>((TIGHT || k < K) ? Bs + n * KSD + k : dummy + lane) = rb[j];
 #endif
     }
     const long long next = item + gridDim.x;
@@ -1117,13 +1123,16 @@ static size_t smm_mfma_wave2_lds(int typesize, int m, int n, int k)
 }
 // waves per SIMD the kernel is compiled for: two where LDS leaves room for eight waves per CU, else one (the register file
 // then holds an item's operands, the next item's and the accumulators without spilling)
-static int smm_mfma_wave_wpe(size_t lds, int typesize = 0, int m = 0, int n = 0, int k = 0, int vec = 0)
+static int smm_mfma_wave_wpe(size_t lds, int typesize = 0, int m = 0, int n = 0, int k = 0, int vec = 0, int lda = 0, int ldb = 0, int ldc = 0)
 {
+  if (lda < m) lda = m;
+  if (ldb < k) ldb = k;
+  if (ldc < m) ldc = m;
   static const int env = []() { const char* e = getenv("XSMM_SMMJIT_WAVE_WPE"); return (nullptr != e && 0 != *e) ? atoi(e) : 0; }(); // developer knob
   if (0 < env) return env;
   if (8 * lds > 160u * 1024u) return 1;
   if (1 == vec) { // element-wise form: a register per element in flight plus what parking them costs (45^3 fp32 spills at two waves per SIMD)
-    const int w = typesize / 4, regs = w * ((m * k + 63) / 64 + (k * n + 63) / 64 + (m * n + 63) / 64) + w * 4 * ((m + 15) / 16) * ((n + 15) / 16);
+    const int w = typesize / 4, regs = w * ((lda * (k - 1) + m + 63) / 64 + (ldb * (n - 1) + k + 63) / 64 + (ldc * (n - 1) + m + 63) / 64) + w * 4 * ((m + 15) / 16) * ((n + 15) / 16);
     if (regs > 125) return 1;
   }
   return 2;
@@ -1374,6 +1383,7 @@ std::string gen_smm_source(int typesize, int m, int n, int k, int flags, int var
   s += std::string("#define XTRANSB ") + ((flags & LIBXSMM_GEMM_FLAG_TRANS_B) ? "1" : "0") + "\n";
   if (0 != (variant & SMM_JIT_MFMA_WAVE2)) { // ... the columns of C in two halves
     s += "#define XFLAT 0\n#define XWPE 1\n#define XNSPLIT 2\n#define XVEC " + std::to_string(16 / typesize) + "\n";
+    s += "#define XLDA " + std::to_string(m) + "\n#define XLDB " + std::to_string(k) + "\n#define XLDC " + std::to_string(m) + "\n";
     s += SMM_JIT_PRELUDE;
     s += SMM_JIT_MFMA_WAVE_BODY;
     return s;
@@ -1381,7 +1391,8 @@ std::string gen_smm_source(int typesize, int m, int n, int k, int flags, int var
   if (0 != (variant & SMM_JIT_MFMA_WAVE)) { // matrix-core kernel, one wave per item
     const int wvec = (0 != (variant & SMM_JIT_SCALAR)) ? 1 : 16 / typesize;
     s += "#define XNSPLIT 1\n#define XVEC " + std::to_string(wvec) + "\n";
-    s += "#define XFLAT 0\n#define XWPE " + std::to_string(smm_mfma_wave_wpe(smm_mfma_wave_lds(typesize, m, n, k, wvec), typesize, m, n, k, wvec)) + "\n";
+    s += "#define XLDA " + std::to_string(1 == wvec ? lda : m) + "\n#define XLDB " + std::to_string(1 == wvec ? ldb : k) + "\n#define XLDC " + std::to_string(1 == wvec ? ldc : m) + "\n";
+    s += "#define XFLAT 0\n#define XWPE " + std::to_string(smm_mfma_wave_wpe(smm_mfma_wave_lds(typesize, m, n, k, wvec), typesize, m, n, k, wvec, lda, ldb, ldc)) + "\n";
     s += SMM_JIT_PRELUDE;
     s += SMM_JIT_MFMA_WAVE_BODY;
     return s;
@@ -1795,9 +1806,15 @@ int launch_smm_jit_mfma(const SmmBatch& s, void* stream, const char** name)
     const uintptr_t bits = reinterpret_cast<uintptr_t>(s.a) | reinterpret_cast<uintptr_t>(s.b) | reinterpret_cast<uintptr_t>(s.c)
                          | (uintptr_t)(s.sa * s.typesize) | (uintptr_t)(s.sb * s.typesize) | (uintptr_t)(s.sc * s.typesize);
     const int chunk = 16 / s.typesize;
-    const bool wide = (ADDR_STRIDED == s.mode && 0 == (bits & 15) && 0 == s.m % chunk && 0 == s.k % 4);
+    const bool tight_ld = (s.lda == s.m && s.ldb == s.k && s.ldc == s.m);
+    const bool wide = (tight_ld && ADDR_STRIDED == s.mode && 0 == (bits & 15) && 0 == s.m % chunk && 0 == s.k % 4);
     const size_t wlds = smm_mfma_wave_lds(s.typesize, s.m, s.n, s.k, wide ? chunk : 1);
-    if (0 != wave_on && 0 != wlds && 4 * wlds <= 160u * 1024u && SYNC_NONE == s.sync && s.lda == s.m && s.ldb == s.k && s.ldc == s.m)
+    // gaps in the leading dimensions: the element-wise build fetches the spans and drops the gaps (up to half as much again)
+    // -- where the spans are short: with more than ~80 elements per lane in flight the work-group form is the faster one
+    // (tools/bench_gaps.py: 43x9x27 ld 48/32/48 55.9 vs 51.4 %, 40x64x17 ld 40/17/44 48.6 vs 40.5 %, but 48^3 ld 56 28.8 vs 56.8 %)
+    const long long span_loads = ((long long)s.lda * (s.k - 1) + s.m + 63) / 64 + ((long long)s.ldb * (s.n - 1) + s.k + 63) / 64 + ((long long)s.ldc * (s.n - 1) + s.m + 63) / 64;
+    const bool gaps_ok = tight_ld || (2 * s.lda <= 3 * s.m && 2 * s.ldb <= 3 * s.k && 2 * s.ldc <= 3 * s.m && span_loads <= 80);
+    if (0 != wave_on && 0 != wlds && 4 * wlds <= 160u * 1024u && SYNC_NONE == s.sync && gaps_ok)
     {
       const SmmKey wkey = { s.typesize, s.m, s.n, s.k, s.flags & LIBXSMM_GEMM_FLAG_BETA_0, SMM_JIT_MFMA_WAVE | (wide ? 0 : SMM_JIT_SCALAR), s.lda, s.ldb, s.ldc };
       JitKernel* const wk = smm_jit_get(wkey);
@@ -1807,7 +1824,7 @@ int launch_smm_jit_mfma(const SmmBatch& s, void* stream, const char** name)
         wad.sa = s.sa; wad.sb = s.sb; wad.sc = s.sc; wad.index_base = s.index_base; wad.index_stride = s.index_stride; wad.mode = s.mode; wad.flags = nullptr;
         long long wbatch = s.batch; int one = 1;
         int per_cu = (int)((160u * 1024u) / wlds);
-        const int by_regs = 4 * smm_mfma_wave_wpe(wlds, s.typesize, s.m, s.n, s.k, wide ? chunk : 1);
+        const int by_regs = 4 * smm_mfma_wave_wpe(wlds, s.typesize, s.m, s.n, s.k, wide ? chunk : 1, s.lda, s.ldb, s.ldc);
         if (per_cu > by_regs) per_cu = by_regs;
         long long wblocks = 256LL * per_cu;
         if (wblocks > s.batch) wblocks = s.batch;

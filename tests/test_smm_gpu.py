@@ -160,9 +160,11 @@ def mfma_wave_serves(dtype, m, n, k, lda, ldb, ldc):
     C's columns ("wave2", not for 64 x 64 x K). None: the work-group form."""
     ts = np.dtype(dtype).itemsize
     chunk = 16 // ts
-    if (lda, ldb, ldc) != (m, k, m) or max(m, n) <= 32:
-        return None
-    vec = chunk if (m % chunk == 0 and k % 4 == 0) else 1
+    tight = (lda, ldb, ldc) == (m, k, m)
+    span_loads = (lda * (k - 1) + m + 63) // 64 + (ldb * (n - 1) + k + 63) // 64 + (ldc * (n - 1) + m + 63) // 64
+    if max(m, n) <= 32 or not (tight or (2 * lda <= 3 * m and 2 * ldb <= 3 * k and 2 * ldc <= 3 * m and span_loads <= 80)):
+        return None  # (moderate gaps over short spans are served by the element-wise build)
+    vec = chunk if (tight and m % chunk == 0 and k % 4 == 0) else 1
     kp4 = 4 * ((k + 3) // 4)
     ms = 16 if m <= 16 else (48 if m <= 48 else 64)
     ksd = (kp4 + vec - 1) // vec

@@ -65,11 +65,14 @@ else:
     ntot = N * B
     for dtype, tdt, create, run, destroy in ((np.float64, torch.float64, L.libxsmm_dfsspmdm_create, L.libxsmm_amd_dfsspmdm_execute_batch, L.libxsmm_dfsspmdm_destroy),
                                              (np.float32, torch.float32, L.libxsmm_sfsspmdm_create, L.libxsmm_amd_sfsspmdm_execute_batch, L.libxsmm_sfsspmdm_destroy)):
-        Bm = torch.rand(K * ntot, device="cuda", dtype=tdt, generator=g) - 0.5
-        Cm = torch.zeros(M * ntot, device="cuda", dtype=tdt)
+        # SP_LDPAD: elements added to the leading dimension of the panels. With ld = ntot = 3 * 2^21 (65 536 items of 96 columns) the 35
+        # rows of B and the 35 rows of C a thread touches all sit at the same offset modulo 2^24 bytes and more
+        ld = ntot + int(os.environ.get("SP_LDPAD", "0"))
+        Bm = torch.rand(K * ld, device="cuda", dtype=tdt, generator=g) - 0.5
+        Cm = torch.zeros(M * ld, device="cuda", dtype=tdt)
         es = Bm.element_size()
         for beta in (1.0, 0.0):
-            h = create(M, N, K, K, ntot, ntot, 1.0, beta, xs.dptr(np.ascontiguousarray(A.astype(dtype))))
+            h = create(M, N, K, K, ld, ld, 1.0, beta, xs.dptr(np.ascontiguousarray(A.astype(dtype))))
             mn, md = timeit(lambda: run(h, xs.dptr(Bm), xs.dptr(Cm), B), reps)
             by = es * N * (K + (2 if beta else 1) * M)
             print("fsspmdm %-26s %s beta=%g min %.4f ms median %.4f ms  %.0f GB/s (%.1f%% of 8 TB/s)"

@@ -1649,7 +1649,8 @@ std::string gen_smm_grouped_source(int typesize, const std::vector<GroupedBody>&
   // on the 27 CP2K shapes: 1.37 ms with four waves per work-group).
   // (two waves per SIMD: the bodies are called, not inlined; without the bound the kernel is given the registers of the
   // hungriest body plus its own -- 308 for the 27 CP2K shapes in fp64 -- and one wave per SIMD)
-  s += "extern \"C\" __global__ __launch_bounds__(" + std::to_string(threads) + ", 2) void xsmm_smm_grouped(const GroupEntry* __restrict__ tab, int nentries)\n{\n";
+  static const int grouped_wpe = []() { const char* e = getenv("XSMM_SMMJIT_GROUPED_WPE"); return (nullptr != e && 0 != *e) ? atoi(e) : 2; }(); // developer knob: waves per SIMD the dispatcher is compiled for
+  s += "extern \"C\" __global__ __launch_bounds__(" + std::to_string(threads) + ", " + std::to_string(grouped_wpe) + ") void xsmm_smm_grouped(const GroupEntry* __restrict__ tab, int nentries)\n{\n";
   s += "  extern __shared__ __attribute__((aligned(16))) unsigned char xsmm_dyn_lds[];\n";
   s += "  int e = 0;\n  while (e + 1 < nentries && blockIdx.x >= tab[e + 1].block_begin) ++e;\n";
   s += "  const GroupEntry g = tab[e];\n  const unsigned bid = blockIdx.x - g.block_begin;\n  T* const lds = reinterpret_cast<T*>(xsmm_dyn_lds);\n";

@@ -266,3 +266,49 @@ def test_operator_applied_panel_by_panel(xs, orc, torch_gpu, loop, dtype, beta):
                 assert xs.last_kernel().endswith("_jit_operator_deferred")
     finally:
         destroy(hd)
+
+
+def test_threads_with_their_own_streams_and_bursts(xs, orc, torch_gpu, loop, scalar_kernels):
+    """four threads, each with its own stream, loop over their own products at the same time: every thread has its own ring of
+    bursts (ctypes releases the GIL inside the C loop, so the calls really interleave)"""
+    import threading
+    torch = torch_gpu
+    L = xs.lib()
+    m = n = k = 11
+    calls, nthreads = 12000, 4
+    fn = _dispatch(xs, np.float64, m, n, k)
+    rng = np.random.default_rng(23)
+    data, errors = [], []
+    for t in range(nthreads):
+        a = rng.uniform(-1, 1, calls * m * k); b = rng.uniform(-1, 1, calls * k * n); c = rng.uniform(-1, 1, calls * m * n)
+        ref = c.copy(); orc.gemm_batch_strided(orc.FMA, 0, m, n, k, m, k, m, a, b, ref, m * k, k * n, m * n, calls)
+        data.append((a, b, c, ref))
+    dev = [tuple(torch.from_numpy(x).cuda() for x in d[:3]) for d in data]
+    streams = [torch.cuda.Stream() for _ in range(nthreads)]
+    torch.cuda.synchronize()
+    i = np.arange(calls)
+    out = [None] * nthreads
+
+    def work(t):
+        try:
+            L.libxsmm_amd_set_stream(C.c_void_p(streams[t].cuda_stream))
+            da, db, dc = dev[t]
+            for _ in range(3):
+                _run(loop, fn, da, db, dc, i * m * k, i * k * n, i * m * n, 8)
+            streams[t].synchronize()  # the thread's own wait, no library call
+            out[t] = dc.cpu().numpy()
+            L.libxsmm_amd_set_stream(None)
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(nthreads)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    for t in range(nthreads):
+        a, b, c, ref = data[t]
+        want = c.copy()
+        for _ in range(3):
+            orc.gemm_batch_strided(orc.FMA, 0, m, n, k, m, k, m, a, b, want, m * k, k * n, m * n, calls)
+        assert np.array_equal(out[t], want), t

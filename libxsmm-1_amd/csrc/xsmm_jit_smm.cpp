@@ -781,11 +781,14 @@ constexpr int MS = (M <= 16) ? 16 : (M <= 48 ? 48 : 64);
 constexpr bool ASWZ = (64 == MS);
 constexpr int kstride() { int s = ((KP4 + VEC - 1) / VEC); if (0 == (s & 1)) ++s; return s * VEC; }
 constexpr int KSD = kstride();
+// TRANS_B (memory holds B^T: element (k, n) at k * ldb + n): the image is k-major like A's, [k][NS], fetched the same way
+constexpr int NS = (N <= 16) ? 16 : (N <= 48 ? 48 : 64);
+constexpr bool BSWZ = (64 == NS);
 // image of C: column stride such that the four column groups of a tile access fall into different banks
 constexpr int cstride() { int s = M; for (;; s += VEC) { if (F64 ? (16 == s % 32) : (4 == s % 16 || 12 == s % 16)) break; } return s; }
 constexpr int CSD = cstride();
 constexpr int C_ELEMS = N * CSD;
-constexpr int A_ELEMS = (C_ELEMS > KP4 * MS) ? C_ELEMS : KP4 * MS, B_ELEMS = N * KSD;
+constexpr int A_ELEMS = (C_ELEMS > KP4 * MS) ? C_ELEMS : KP4 * MS, B_ELEMS = XTRANSB ? KP4 * NS : N * KSD;
 #if XLOWP
 // bf16 inputs (XLOWP 3: fp32 result, 2: bf16 result) as the reference's low-precision kernels store them: A in pairs of k
 // (a[(k/2)*M*2 + m*2 + k%2]), B column-major -- both sequences of 32-bit k pairs. A 16-byte chunk is four pairs (A: four
@@ -809,10 +812,10 @@ __device__ __forceinline__ void widen8(UV p, V& v0, V& v1)
 // Leading dimensions as in memory (gaps only in the element-wise build): an operand is fetched as the one span of memory it
 // occupies, elements in the gaps are dropped on the way into the images and never written on the way out.
 constexpr int LDA = XLDA, LDB = XLDB, LDC = XLDC;
-constexpr bool TIGHT = (LDA == M && LDB == K && LDC == M);
-constexpr int NCA = (LDA * (K - 1) + M) / VEC, NCB = (LDB * (N - 1) + K) / VEC, NCC = (LDC * (N - 1) + M) / VEC;
+constexpr bool TIGHT = (LDA == M && LDB == (XTRANSB ? N : K) && LDC == M);
+constexpr int NCA = (LDA * (K - 1) + M) / VEC, NCB = (XTRANSB ? (LDB * (K - 1) + N) : (LDB * (N - 1) + K)) / VEC, NCC = (LDC * (N - 1) + M) / VEC;
 typedef V UV;
-static_assert(1 == VEC || (TIGHT && 0 == M % VEC && 0 == K % 4), "shape");
+static_assert(1 == VEC || (TIGHT && 0 == M % VEC && 0 == K % 4 && (!XTRANSB || 0 == N % VEC)), "shape");
 #endif
 constexpr int CA = (NCA + 63) / 64, CB = (NCB + 63) / 64, CC = (NCC + 63) / 64;
 __device__ __forceinline__ int clampi(int v, int hi) { return v < hi ? v : hi; }
@@ -865,7 +868,8 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(X
   load_ab(item);
   if (!XBETA0) load_c(item);
   if (KP4 > K) { // the padding of B's image: written once (its place is not shared)
-    for (int e = lane; e < N * (KP4 - K); e += 64) Bs[(e / (KP4 - K)) * KSD + K + e % (KP4 - K)] = T(0);
+    if (XTRANSB) { for (int e = lane; e < (KP4 - K) * NS; e += 64) Bs[K * NS + e] = T(0); }
+    else { for (int e = lane; e < N * (KP4 - K); e += 64) Bs[(e / (KP4 - K)) * KSD + K + e % (KP4 - K)] = T(0); }
   }
   for (;;) {
     __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): this item's operands (the only other instructions in flight are older stores)
@@ -930,8 +934,13 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(X
       V v0, v1; widen8(rb[j], v0, v1);
       *reinterpret_cast<V*>(Bs + n * KSD + k) = v0; *reinterpret_cast<V*>(Bs + n * KSD + k + 4) = v1;
 #else
+#if XTRANSB
+      const int e = ch * VEC, k = e / LDB, n = e % LDB;
+      *reinterpret_cast<V*>((TIGHT || n < N) ? Bs + k * NS + (BSWZ ? (n ^ ((k & 3) << 4)) : n) : dummy + lane) = rb[j];
+#else
       const int e = ch * VEC, n = e / LDB, k = e % LDB;
       *reinterpret_cast<V*>((TIGHT || k < K) ? Bs + n * KSD + k : dummy + lane) = rb[j];
+#endif
 #endif
     }
     const long long next = item + gridDim.x;
@@ -943,7 +952,10 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(X
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) { const int m = 16 * mi + l16; af[mi] = As[(4 * ks + lq) * MS + (ASWZ ? (m ^ (lq << 4)) : m)]; }
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) { const int n = clampi(16 * ni + l16, N - 1); bf[ni] = Bs[n * KSD + 4 * ks + lq]; }
+      for (int ni = 0; ni < NI; ++ni) {
+        const int n = XTRANSB ? (16 * ni + l16) : clampi(16 * ni + l16, N - 1);
+        bf[ni] = XTRANSB ? Bs[(4 * ks + lq) * NS + (BSWZ ? (n ^ (lq << 4)) : n)] : Bs[n * KSD + 4 * ks + lq];
+      }
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
@@ -1098,7 +1110,7 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(X
 )XSMM";
 
 // LDS bytes of a wave of that kernel (mirrors the constexpr arithmetic of the source); 0: the shape is not served
-static size_t smm_mfma_wave_lds(int typesize, int m, int n, int k, int vec = 0)
+static size_t smm_mfma_wave_lds(int typesize, int m, int n, int k, int vec = 0, bool transb = false)
 { // vec: elements per memory access (0: a 16-byte chunk)
   if (0 == vec) vec = 16 / typesize;
   if (m > 64 || n > 64 || k > 64 || m < 1 || n < 1 || k < 1) return 0;
@@ -1108,7 +1120,9 @@ static size_t smm_mfma_wave_lds(int typesize, int m, int n, int k, int vec = 0)
   int ksd = (kp4 + vec - 1) / vec; if (0 == (ksd & 1)) ++ksd; ksd *= vec;
   int csd = m; for (;; csd += vec) { if (8 == typesize ? (16 == csd % 32) : (4 == csd % 16 || 12 == csd % 16)) break; }
   const int a_elems = (n * csd > kp4 * ms) ? n * csd : kp4 * ms;
-  return (size_t)(a_elems + n * ksd + 64) * typesize;
+  const int ns = (n <= 16) ? 16 : (n <= 48 ? 48 : 64);
+  if (transb && 1 != vec && 0 != n % vec) return 0;
+  return (size_t)(a_elems + (transb ? kp4 * ns : n * ksd) + 64) * typesize;
 }
 // ... of the form that works on the columns of C in two halves (0: not served)
 static size_t smm_mfma_wave2_lds(int typesize, int m, int n, int k)
@@ -1391,8 +1405,9 @@ std::string gen_smm_source(int typesize, int m, int n, int k, int flags, int var
   if (0 != (variant & SMM_JIT_MFMA_WAVE)) { // matrix-core kernel, one wave per item
     const int wvec = (0 != (variant & SMM_JIT_SCALAR)) ? 1 : 16 / typesize;
     s += "#define XNSPLIT 1\n#define XVEC " + std::to_string(wvec) + "\n";
-    s += "#define XLDA " + std::to_string(1 == wvec ? lda : m) + "\n#define XLDB " + std::to_string(1 == wvec ? ldb : k) + "\n#define XLDC " + std::to_string(1 == wvec ? ldc : m) + "\n";
-    s += "#define XFLAT 0\n#define XWPE " + std::to_string(smm_mfma_wave_wpe(smm_mfma_wave_lds(typesize, m, n, k, wvec), typesize, m, n, k, wvec, lda, ldb, ldc)) + "\n";
+    const bool wtb = (0 != (flags & LIBXSMM_GEMM_FLAG_TRANS_B));
+    s += "#define XLDA " + std::to_string(1 == wvec ? lda : m) + "\n#define XLDB " + std::to_string(1 == wvec ? ldb : (wtb ? n : k)) + "\n#define XLDC " + std::to_string(1 == wvec ? ldc : m) + "\n";
+    s += "#define XFLAT 0\n#define XWPE " + std::to_string(smm_mfma_wave_wpe(smm_mfma_wave_lds(typesize, m, n, k, wvec, wtb), typesize, m, n, k, wvec, lda, wtb ? 0 : ldb, ldc)) + "\n";
     s += SMM_JIT_PRELUDE;
     s += SMM_JIT_MFMA_WAVE_BODY;
     return s;
@@ -1790,8 +1805,8 @@ int launch_smm_jit_mfma(const SmmBatch& s, void* stream, const char** name)
   static const int on = []() { const char* e = getenv("XSMM_SMMJIT_MFMA"); return (nullptr != e && 0 != *e) ? atoi(e) : 1; }(); // developer knob
   if (0 == on || 0 == s.use_mfma || 0 != s.general || 0 != s.lowp) return -1;
   static const int wave_min = []() { const char* e = getenv("XSMM_SMMJIT_WAVE_MIN"); return (nullptr != e && 0 != *e) ? atoi(e) : 32; }(); // developer knob: the wave form below 33
-  if (!((wave_min < s.m || wave_min < s.n) && s.m <= 64 && s.n <= 64 && 0 < s.k && s.k <= 64 && s.lda >= s.m && s.ldb >= s.k && s.ldc >= s.m)) return -1;
-  if (0 != (s.flags & LIBXSMM_GEMM_FLAG_TRANS_B)) return -1;
+  const bool transb = (0 != (s.flags & LIBXSMM_GEMM_FLAG_TRANS_B)); // (B^T in memory: served by the one-wave-per-item form only)
+  if (!((wave_min < s.m || wave_min < s.n) && s.m <= 64 && s.n <= 64 && 0 < s.k && s.k <= 64 && s.lda >= s.m && s.ldb >= (transb ? s.n : s.k) && s.ldc >= s.m)) return -1;
   if (4 == s.typesize && 64 == s.m && 64 == s.n && 64 == s.k && 64 == s.lda && 64 == s.ldb && 64 == s.ldc && SYNC_NONE == s.sync) return -1; // the hand-tuned tight 64^3 kernel
   long long units = 0; int runlen = 1;
   if (SYNC_NONE == s.sync) units = s.batch;
@@ -1807,17 +1822,18 @@ int launch_smm_jit_mfma(const SmmBatch& s, void* stream, const char** name)
     const uintptr_t bits = reinterpret_cast<uintptr_t>(s.a) | reinterpret_cast<uintptr_t>(s.b) | reinterpret_cast<uintptr_t>(s.c)
                          | (uintptr_t)(s.sa * s.typesize) | (uintptr_t)(s.sb * s.typesize) | (uintptr_t)(s.sc * s.typesize);
     const int chunk = 16 / s.typesize;
-    const bool tight_ld = (s.lda == s.m && s.ldb == s.k && s.ldc == s.m);
-    const bool wide = (tight_ld && ADDR_STRIDED == s.mode && 0 == (bits & 15) && 0 == s.m % chunk && 0 == s.k % 4);
-    const size_t wlds = smm_mfma_wave_lds(s.typesize, s.m, s.n, s.k, wide ? chunk : 1);
+    const int bdim = transb ? s.n : s.k, bcnt = transb ? s.k : s.n; // B in memory: bcnt columns of bdim elements at a distance of ldb
+    const bool tight_ld = (s.lda == s.m && s.ldb == bdim && s.ldc == s.m);
+    const bool wide = (tight_ld && ADDR_STRIDED == s.mode && 0 == (bits & 15) && 0 == s.m % chunk && 0 == s.k % 4 && (!transb || 0 == s.n % chunk));
+    const size_t wlds = smm_mfma_wave_lds(s.typesize, s.m, s.n, s.k, wide ? chunk : 1, transb);
     // gaps in the leading dimensions: the element-wise build fetches the spans and drops the gaps (up to half as much again)
     // -- where the spans are short: with more than ~80 elements per lane in flight the work-group form is the faster one
     // (tools/bench_gaps.py: 43x9x27 ld 48/32/48 55.9 vs 51.4 %, 40x64x17 ld 40/17/44 48.6 vs 40.5 %, but 48^3 ld 56 28.8 vs 56.8 %)
-    const long long span_loads = ((long long)s.lda * (s.k - 1) + s.m + 63) / 64 + ((long long)s.ldb * (s.n - 1) + s.k + 63) / 64 + ((long long)s.ldc * (s.n - 1) + s.m + 63) / 64;
-    const bool gaps_ok = tight_ld || (2 * s.lda <= 3 * s.m && 2 * s.ldb <= 3 * s.k && 2 * s.ldc <= 3 * s.m && span_loads <= 80);
+    const long long span_loads = ((long long)s.lda * (s.k - 1) + s.m + 63) / 64 + ((long long)s.ldb * (bcnt - 1) + bdim + 63) / 64 + ((long long)s.ldc * (s.n - 1) + s.m + 63) / 64;
+    const bool gaps_ok = tight_ld || (2 * s.lda <= 3 * s.m && 2 * s.ldb <= 3 * bdim && 2 * s.ldc <= 3 * s.m && span_loads <= 80);
     if (0 != wave_on && 0 != wlds && 4 * wlds <= 160u * 1024u && SYNC_NONE == s.sync && gaps_ok)
     {
-      const SmmKey wkey = { s.typesize, s.m, s.n, s.k, s.flags & LIBXSMM_GEMM_FLAG_BETA_0, SMM_JIT_MFMA_WAVE | (wide ? 0 : SMM_JIT_SCALAR), s.lda, s.ldb, s.ldc };
+      const SmmKey wkey = { s.typesize, s.m, s.n, s.k, s.flags & (LIBXSMM_GEMM_FLAG_BETA_0 | LIBXSMM_GEMM_FLAG_TRANS_B), SMM_JIT_MFMA_WAVE | (wide ? 0 : SMM_JIT_SCALAR), s.lda, s.ldb, s.ldc };
       JitKernel* const wk = smm_jit_get(wkey);
       if (nullptr != wk) {
         struct { const char* a; const char* b; char* c; const char* ia; const char* ib; const char* ic; long long sa, sb, sc; int index_base, index_stride, mode; const int* flags; } wad;
@@ -1835,6 +1851,7 @@ int launch_smm_jit_mfma(const SmmBatch& s, void* stream, const char** name)
       }
     }
   }
+  if (transb) return -1; // (the forms below read B as stored column by column)
   { // fp64 items too large for that: the two-halves form where it leaves room for four waves per CU (56^3: 66 % against 54-58 % on the
     // work-group form; 64 x 64 x K stays on the work-group form, which is the faster one there -- tools/probe/mfma_wave.hip)
     static const int wave_on = []() { const char* e = getenv("XSMM_SMMJIT_MFMA_WAVE"); return (nullptr != e && 0 != *e) ? atoi(e) : 1; }();

@@ -261,6 +261,43 @@ def test_smm_mfma_wave_index_batches(xs, orc, torch_gpu):
             os.environ["LIBXSMM_AMD_JIT"] = old_jit
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("shape", [(48, 48, 48), (40, 36, 20), (33, 35, 37), (56, 40, 32)])
+def test_smm_mfma_wave_trans_b(xs, orc, torch_gpu, dtype, shape):
+    """TRANS_B (B^T in memory, src/generator_gemm.c:219-223) beyond 32 on the one-wave-per-item kernel: the image of B is k-major like
+    A's; the oracle's fma chain bit for bit, beta = 1 and 0."""
+    torch = torch_gpu
+    m, n, k = shape
+    old_jit = os.environ.get("LIBXSMM_AMD_JIT")
+    os.environ["LIBXSMM_AMD_JIT"] = "1"; os.environ["LIBXSMM_AMD_JIT_MINBATCH"] = "1"
+    old = xs.lib().libxsmm_amd_set_mfma(1)
+    try:
+        for beta in (1.0, 0.0):
+            batch = 1300
+            rng = np.random.default_rng(m + 3 * n + k)
+            a = rng.uniform(-1, 1, batch * m * k).astype(dtype); bt = rng.uniform(-1, 1, batch * n * k).astype(dtype); c = rng.uniform(-1, 1, batch * m * n).astype(dtype)
+            flags = xs.FLAG_TRANS_B | (xs.FLAG_BETA_0 if beta == 0.0 else 0)
+            ref = c.copy()
+            orc.gemm_batch_strided(orc.FMA, flags, m, n, k, m, n, m, a, bt, ref, m * k, n * k, m * n, batch, 8)
+            if beta == 0.0:
+                c[:] = np.nan
+            da, db, dc = (torch.from_numpy(x).cuda() for x in (a, bt, c))
+            blob, desc = xs.descriptor(xs.F64 if dtype == np.float64 else xs.F32, m, n, k, m, n, m, 1.0, beta, flags=xs.FLAG_TRANS_B)
+            assert desc
+            assert 0 == xs.lib().libxsmm_amd_gemm_batch_strided(desc, xs.dptr(da), xs.dptr(db), xs.dptr(dc), m * k, n * k, m * n, batch)
+            torch.cuda.synchronize()
+            assert xs.last_kernel() == ("smm_f64_mfma_wave_jit" if dtype == np.float64 else "smm_f32_mfma_wave_jit"), xs.last_kernel()
+            bits = np.uint64 if dtype == np.float64 else np.uint32
+            assert np.array_equal(dc.cpu().numpy().view(bits), ref.view(bits)), beta
+    finally:
+        xs.lib().libxsmm_amd_set_mfma(old)
+        os.environ.pop("LIBXSMM_AMD_JIT_MINBATCH", None)
+        if old_jit is None:
+            del os.environ["LIBXSMM_AMD_JIT"]
+        else:
+            os.environ["LIBXSMM_AMD_JIT"] = old_jit
+
+
 MFMA_WAVE_SHAPES = [(40, 40, 40), (48, 48, 48), (56, 56, 56), (36, 64, 8), (64, 20, 12), (44, 52, 36), (64, 64, 60), (16, 48, 64), (34, 40, 4),
                     (16, 64, 64), (56, 64, 48), (64, 56, 56), (33, 33, 33), (45, 37, 19), (57, 39, 1), (64, 5, 7), (35, 64, 62)]
 

@@ -639,6 +639,17 @@ LIBXSMM_API int libxsmm_mmbatch_kernel(libxsmm_xmmfunction kernel, libxsmm_blasi
 
 namespace {
 
+// What BLAS checks before it computes (xerbla: "parameter ... had an illegal value"; the reference hands these calls to BLAS):
+// a leading dimension smaller than the rows it has to hold is an error, never a launch -- the kernel would read beyond the operands.
+bool blas_lds_valid(const char* who, int flags, long long m, long long n, long long k, long long lda, long long ldb, long long ldc)
+{
+  const long long rows_a = (0 == (LIBXSMM_GEMM_FLAG_TRANS_A & flags)) ? m : k, rows_b = (0 == (LIBXSMM_GEMM_FLAG_TRANS_B & flags)) ? k : n;
+  if (lda >= (rows_a > 1 ? rows_a : 1) && ldb >= (rows_b > 1 ? rows_b : 1) && ldc >= (m > 1 ? m : 1)) return true;
+  static int error_once = 0;
+  if (once(&error_once)) fprintf(stderr, "LIBXSMM ERROR: %s: illegal leading dimension (lda=%lld ldb=%lld ldc=%lld for m=%lld n=%lld k=%lld)\n", who, lda, ldb, ldc, m, n, k);
+  return false;
+}
+
 // C = alpha*op(A)*op(B) + beta*C for every item -- what the reference delegates to BLAS
 // (libxsmm_mmbatch_blas, src/libxsmm_gemm.c:1778-1806): shapes/scalars outside the SMM domain.
 int batch_general(int typesize, const char* transa, const char* transb, libxsmm_blasint m, libxsmm_blasint n, libxsmm_blasint k,
@@ -659,6 +670,7 @@ int batch_general(int typesize, const char* transa, const char* transb, libxsmm_
   if (8 == typesize) { s.alpha = (nullptr != alpha ? *static_cast<const double*>(alpha) : 1.0); s.beta = (nullptr != beta ? *static_cast<const double*>(beta) : 1.0); }
   else { s.alpha = (nullptr != alpha ? *static_cast<const float*>(alpha) : 1.f); s.beta = (nullptr != beta ? *static_cast<const float*>(beta) : 1.f); }
   if (m <= 0 || n <= 0 || k < 0) return EXIT_SUCCESS;
+  if (!blas_lds_valid("batch of general products", s.flags, m, n, k, s.lda, s.ldb, s.ldc)) return EXIT_FAILURE;
   return batch_execute(s, index_base, index_stride, stride_a, stride_b, stride_c, a, b, c, begin, end, true);
 }
 
@@ -933,6 +945,7 @@ void xgemm(int prec, const char* transa, const char* transb, const libxsmm_blasi
   s.flags = flags & (LIBXSMM_GEMM_FLAG_TRANS_A | LIBXSMM_GEMM_FLAG_TRANS_B);
   s.general = 1; s.alpha = (double)aa; s.beta = (double)bb;
   if (0 >= kk) { s.k = 0; }
+  if (!blas_lds_valid("libxsmm_?gemm", s.flags, mm, nn, s.k, ilda, ildb, ildc)) return;
   (void)single_execute(s, a, b, c);
 }
 } // namespace

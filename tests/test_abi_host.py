@@ -326,3 +326,21 @@ def test_product_does_not_reference_the_oracle():
     assert not bad, bad
     out = subprocess.run(["nm", "-D", os.path.join(ROOT, "libxsmm-1_amd", "lib", "libxsmm.so")], capture_output=True, text=True).stdout
     assert " xo_" not in out
+
+
+def test_illegal_leading_dimensions_are_an_error_not_a_launch(xs):
+    """What the reference hands to BLAS (general products, batches of them) BLAS rejects with xerbla when a leading dimension is
+    smaller than the rows it has to hold; here the call fails before anything is launched (a kernel would read beyond the operands)."""
+    L = xs.lib()
+    m, n, k, batch = 40, 8, 12, 3
+    a = np.zeros(batch * 19 * k); b = np.zeros(batch * k * n); c = np.zeros(batch * m * n)
+    lda, ldb, ldc = C.c_int(19), C.c_int(k), C.c_int(m)  # lda < m
+    alpha, beta = C.c_double(1.0), C.c_double(1.0)
+    sa = (np.arange(batch) * 19 * k).astype(np.int32); sb = (np.arange(batch) * k * n).astype(np.int32); sc = (np.arange(batch) * m * n).astype(np.int32)
+    L.libxsmm_mmbatch_blas.restype = C.c_int
+    L.libxsmm_mmbatch_blas.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    rc = L.libxsmm_mmbatch_blas(xs.F64, xs.F64, b"N", b"N", m, n, k, C.addressof(alpha), a.ctypes.data, C.addressof(lda), b.ctypes.data, C.addressof(ldb),
+                                C.addressof(beta), c.ctypes.data, C.addressof(ldc), 0, 4, sa.ctypes.data, sb.ctypes.data, sc.ctypes.data, batch)
+    assert rc != 0
+    assert not np.any(c)

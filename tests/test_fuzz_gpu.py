@@ -9,10 +9,12 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _case(rng):
+def _case(rng, big_only=False):
     dtype = np.float64 if rng.random() < 0.5 else np.float32
-    big = rng.random() < 0.15
+    big = big_only or rng.random() < 0.15
     m, n = int(rng.integers(1, 65 if big else 33)), int(rng.integers(1, 65 if big else 33))
+    if big_only and max(m, n) <= 32:
+        m = int(rng.integers(33, 65))
     k = int(rng.integers(1, 80 if rng.random() < 0.2 else 40))
     transb = rng.random() < 0.25
     gaps = rng.random() < 0.35
@@ -24,19 +26,22 @@ def _case(rng):
     cpat = ("distinct", "runs", "unordered")[int(rng.integers(0, 3))] if (mode != "strided" and beta == 1.0) else "distinct"
     batch = int(rng.integers(1, 2500))
     relaxed = rng.random() < 0.4
-    forced = rng.random() < 0.7
+    forced = big_only or rng.random() < 0.7
     return dtype, m, n, k, lda, ldb, ldc, transb, beta, mode, cpat, batch, relaxed, forced
 
 
-@pytest.mark.parametrize("chunk", range(6))
+@pytest.mark.parametrize("chunk", list(range(6)) + [100, 101, 102])
 def test_dense_batches_fuzz(xs, orc, torch_gpu, chunk):
+    """(chunks 100+: shapes beyond 32 only, matrix cores on, specialised kernels forced -- the one-wave-per-item forms with chunks,
+    element by element, gaps, TRANS_B, index and pointer batches, next to the work-group and run forms)"""
     torch = torch_gpu
     rng = np.random.default_rng(20241004 + chunk)
     old_env = os.environ.get("LIBXSMM_AMD_JIT_MINBATCH")
-    old_mfma = xs.lib().libxsmm_amd_set_mfma(int(chunk % 2))
+    big_only = chunk >= 100
+    old_mfma = xs.lib().libxsmm_amd_set_mfma(1 if big_only else int(chunk % 2))
     try:
         for it in range(30):
-            dtype, m, n, k, lda, ldb, ldc, transb, beta, mode, cpat, batch, relaxed, forced = _case(rng)
+            dtype, m, n, k, lda, ldb, ldc, transb, beta, mode, cpat, batch, relaxed, forced = _case(rng, big_only)
             if forced:
                 os.environ["LIBXSMM_AMD_JIT_MINBATCH"] = "1"
             else:

@@ -316,3 +316,49 @@ def test_low_precision_batch_reduce(xs, orc, torch_gpu, kind, shape):
     assert not disp(m, n, 7, None, None, None, None, None, None, None)
     if kind == 3:
         assert not disp(m + 4, n, k, None, None, None, None, None, None, None)
+
+
+@pytest.mark.gpu
+def test_low_precision_wave_kernel_fuzz(xs, orc, torch_gpu):
+    """random shapes of the bf16 matrix-core form (M a multiple of 4 -- of 16 for a bf16 result --, K of 8, any N up to 64), batches
+    around the size of the resident grid, beta 0 / 1: the gold loop bit for bit"""
+    import os
+    torch = torch_gpu
+    L = xs.lib()
+    rng = np.random.default_rng(424242)
+    L.libxsmm_gemm_descriptor_dinit2.restype = C.c_void_p
+    L.libxsmm_gemm_descriptor_dinit2.argtypes = [C.c_void_p] + [C.c_int] * 8 + [C.c_double, C.c_double, C.c_int, C.c_int]
+    old_env = os.environ.get("LIBXSMM_AMD_JIT_MINBATCH")
+    os.environ["LIBXSMM_AMD_JIT_MINBATCH"] = "1"
+    old_mfma = L.libxsmm_amd_set_mfma(1)
+    try:
+        for it in range(14):
+            kind = 2 if rng.random() < 0.5 else 3
+            m = int(rng.integers(1, 5)) * 16 if kind == 3 else int(rng.integers(2, 17)) * 4
+            n = int(rng.integers(1, 65)); k = int(rng.integers(1, 9)) * 8
+            if max(m, n) < 32:
+                n = int(rng.integers(32, 65))
+            beta0 = int(rng.random() < 0.4)
+            batch = int(rng.choice([1, 3, 257, 1100, 2100]))
+            blob = xs.DescriptorBlob()
+            ip, op = {2: (xs.BF16, xs.F32), 3: (xs.BF16, xs.BF16)}[kind]
+            desc = L.libxsmm_gemm_descriptor_dinit2(C.byref(blob), ip, op, m, n, k, m, k, m, 1.0, 0.0 if beta0 else 1.0, 0, 0)
+            assert desc, (kind, m, n, k)
+            a = _bf16(rng.uniform(-1, 1, batch * m * k)); b = _bf16(rng.uniform(-1, 1, batch * k * n))
+            c = rng.uniform(-1, 1, batch * m * n).astype(np.float32) if kind == 2 else _bf16(rng.uniform(-1, 1, batch * m * n))
+            ref = c.copy()
+            for i in range(batch):
+                assert 0 == orc.gemm_lowp(kind, beta0, m, n, k, m, k, m, a[i * m * k:(i + 1) * m * k], b[i * k * n:(i + 1) * k * n], ref[i * m * n:(i + 1) * m * n], 1.0)
+            da, db = (torch.from_numpy(x.view(np.int16)).cuda() for x in (a, b))
+            dc = torch.from_numpy(c.view(np.int16) if kind == 3 else c).cuda()
+            assert 0 == L.libxsmm_amd_gemm_batch_strided(C.c_void_p(desc), da.data_ptr(), db.data_ptr(), dc.data_ptr(), m * k, k * n, m * n, batch)
+            torch.cuda.synchronize()
+            got = dc.cpu().numpy(); got = got.view(np.uint16) if kind == 3 else got
+            assert xs.last_kernel().endswith("_lowp")
+            assert np.array_equal(got.view(np.uint8), ref.view(np.uint8)), (it, kind, m, n, k, beta0, batch, xs.last_kernel())
+    finally:
+        L.libxsmm_amd_set_mfma(old_mfma)
+        if old_env is None:
+            os.environ.pop("LIBXSMM_AMD_JIT_MINBATCH", None)
+        else:
+            os.environ["LIBXSMM_AMD_JIT_MINBATCH"] = old_env

@@ -312,3 +312,49 @@ def test_threads_with_their_own_streams_and_bursts(xs, orc, torch_gpu, loop, sca
         for _ in range(3):
             orc.gemm_batch_strided(orc.FMA, 0, m, n, k, m, k, m, a, b, want, m * k, k * n, m * n, calls)
         assert np.array_equal(out[t], want), t
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_call_sequences_over_one_pool(xs, orc, torch_gpu, loop, scalar_kernels, seed):
+    """random sequences of calls of three kernels whose operands are blocks of one pool: a call may read blocks earlier calls wrote
+    and write blocks again that were written or read before -- whatever is recorded side by side, the pool must end up as the
+    sequential loop leaves it (stretches of independent calls alternate with stretches full of dependences)"""
+    torch = torch_gpu
+    rng = np.random.default_rng(seed)
+    nblk, sz, calls = 96, 256, 3000
+    pool = rng.uniform(-0.05, 0.05, nblk * sz)  # (small: results feed later products, larger values grow without bound)
+    ks = (4, 8, 16)
+    fns = [_dispatch(xs, np.float64, 16, 16, kk) for kk in ks]
+    which = np.zeros(calls, dtype=np.int64); ia = np.zeros(calls, dtype=np.int64); ib = np.zeros(calls, dtype=np.int64); ic = np.zeros(calls, dtype=np.int64)
+    i = 0
+    while i < calls:
+        stretch = int(rng.integers(20, 200)); kern = int(rng.integers(0, 3)); tangled = rng.random() < 0.4
+        for j in range(min(stretch, calls - i)):
+            if rng.random() < 0.1:
+                kern = int(rng.integers(0, 3))
+            if tangled:
+                c = int(rng.integers(0, nblk)); a = int(rng.integers(0, nblk)); b = int(rng.integers(0, nblk))
+                while a == c:
+                    a = int(rng.integers(0, nblk))
+                while b == c:
+                    b = int(rng.integers(0, nblk))
+            else:  # inputs from the upper half, outputs walk through the lower half
+                c = (i + j) % (nblk // 2); a = nblk // 2 + int(rng.integers(0, nblk // 2)); b = nblk // 2 + int(rng.integers(0, nblk // 2))
+            which[i + j], ia[i + j], ib[i + j], ic[i + j] = kern, a, b, c
+        i += stretch
+    ref = pool.copy()
+    for j in range(calls):
+        kk = ks[which[j]]
+        orc.smm(orc.FMA, 0, 16, 16, kk, 16, kk, 16, ref[ia[j] * sz:ia[j] * sz + 16 * kk].copy(), ref[ib[j] * sz:ib[j] * sz + kk * 16].copy(), ref[ic[j] * sz:(ic[j] + 1) * sz])
+    dp = torch.from_numpy(pool).cuda()
+    # runs of one kernel go through the C loop (bursts), the kernel changes between them
+    j = 0
+    while j < calls:
+        e = j
+        while e < calls and which[e] == which[j]:
+            e += 1
+        _run(loop, fns[which[j]], dp, dp, dp, ia[j:e] * sz, ib[j:e] * sz, ic[j:e] * sz, 8)
+        j = e
+    torch.cuda.synchronize()
+    assert np.all(np.isfinite(ref))
+    assert np.array_equal(dp.cpu().numpy().view(np.uint64), ref.view(np.uint64))

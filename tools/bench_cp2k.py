@@ -28,6 +28,9 @@ L.libxsmm_amd_set_mfma(0)
 
 shapes = [(m, n, k) for m in (13, 23, 32) for n in (13, 23, 32) for k in (13, 23, 32)]
 per = products // len(shapes)
+_subset = os.environ.get("CP2K_SUBSET", "")  # developer knob: "light" / "heavy" = shapes whose operands are up to / beyond 900 elements per product
+if _subset:
+    shapes = [sh for sh in shapes if ((sh[0] * sh[2] + sh[2] * sh[1]) <= 900) == (_subset == "light")]
 groups = []
 tot_bytes = 0.0; tot_flops = 0.0; tot_runs = 0
 for gi, (m, n, k) in enumerate(shapes):

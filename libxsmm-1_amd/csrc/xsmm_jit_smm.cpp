@@ -1941,7 +1941,11 @@ int launch_smm_jit_lowp(const SmmBatch& s, void* stream, const char** name)
       }
     }
   }
-  if (s.m > 32 || s.n > 32 || s.k > 64 || 0 != (s.k & 1) || s.lda != s.m || s.ldb != s.k || s.ldc != s.m) return -1;
+  // (i16 -> i32 has no matrix-core form: beyond 32 the same streaming kernel with a larger tile per lane -- 48^3 18 -> 57 %,
+  // 64^3 16 -> 56 % of the HBM peak; XSMM_SMMJIT_LOWP_BIG=0: the pre-compiled kernel)
+  static const int big_i16 = []() { const char* e = getenv("XSMM_SMMJIT_LOWP_BIG"); return (nullptr != e && 0 != *e) ? atoi(e) : 1; }();
+  const int lim = (0 != big_i16) ? 64 : 32; // (bf16 shapes the matrix-core form above does not take -- M or K not a multiple of 4 / 8 -- come here as well)
+  if (s.m > lim || s.n > lim || s.k > 64 || 0 != (s.k & 1) || s.lda != s.m || s.ldb != s.k || s.ldc != s.m) return -1;
   if (s.sa != (long long)s.m * s.k || s.sb != (long long)s.k * s.n || s.sc != (long long)s.m * s.n) return -1;
   const char* const env_min = getenv("LIBXSMM_AMD_JIT_MINBATCH");
   if (s.batch < ((nullptr != env_min && 0 != *env_min) ? atoll(env_min) : 1024LL)) return -1;

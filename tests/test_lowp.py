@@ -222,7 +222,7 @@ def test_low_precision_batches(xs, orc, torch_gpu, kind):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind", [2, 3])
-@pytest.mark.parametrize("shape", [(48, 48, 48), (64, 40, 56), (64, 64, 64), (16, 64, 8), (40, 33, 16)])
+@pytest.mark.parametrize("shape", [(48, 48, 48), (64, 40, 56), (64, 64, 64), (16, 64, 8), (40, 33, 16), (45, 40, 26), (48, 50, 12)])
 def test_low_precision_wave_kernel(xs, orc, torch_gpu, kind, shape):
     """bf16 inputs beyond 32 on the one-wave-per-item matrix-core kernel (csrc/xsmm_jit_smm.cpp, SMM_JIT_MFMA_WAVE_BODY with
     XLOWP): the fp32 instruction on the widened operands is the gold loop's product-then-add (samples/xgemm/kernel.c:1104-1123,
@@ -358,6 +358,43 @@ def test_low_precision_wave_kernel_fuzz(xs, orc, torch_gpu):
             assert np.array_equal(got.view(np.uint8), ref.view(np.uint8)), (it, kind, m, n, k, beta0, batch, xs.last_kernel())
     finally:
         L.libxsmm_amd_set_mfma(old_mfma)
+        if old_env is None:
+            os.environ.pop("LIBXSMM_AMD_JIT_MINBATCH", None)
+        else:
+            os.environ["LIBXSMM_AMD_JIT_MINBATCH"] = old_env
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(48, 48, 48), (64, 64, 64), (40, 64, 16), (64, 33, 62)])
+def test_i16_streaming_form_beyond_32(xs, orc, torch_gpu, shape):
+    """i16 -> i32 beyond 32 x 32 on the specialised streaming kernel (a larger tile per lane, v_dot2_i32_i16 per k pair): the wrapping
+    sums of the gold loop (samples/xgemm/kernel.c:915-927), exact in any order; strided batches, beta 1 and 0."""
+    import os
+    torch = torch_gpu
+    L = xs.lib()
+    m, n, k = shape
+    blob = xs.DescriptorBlob()
+    L.libxsmm_gemm_descriptor_dinit2.restype = C.c_void_p
+    L.libxsmm_gemm_descriptor_dinit2.argtypes = [C.c_void_p] + [C.c_int] * 8 + [C.c_double, C.c_double, C.c_int, C.c_int]
+    old_env = os.environ.get("LIBXSMM_AMD_JIT_MINBATCH")
+    os.environ["LIBXSMM_AMD_JIT_MINBATCH"] = "1"
+    try:
+        for beta0 in (0, 1):
+            desc = L.libxsmm_gemm_descriptor_dinit2(C.byref(blob), xs.I16, xs.I32, m, n, k, m, k, m, 1.0, 0.0 if beta0 else 1.0, 0, 0)
+            assert desc
+            for batch in (1, 700):
+                rng = np.random.default_rng(batch + m + n)
+                a = rng.integers(-30000, 30000, batch * m * k).astype(np.int16).view(np.uint16); b = rng.integers(-30000, 30000, batch * k * n).astype(np.int16).view(np.uint16)
+                c = rng.integers(-2 ** 31, 2 ** 31 - 1, batch * m * n).astype(np.int32)
+                ref = c.copy()
+                for i in range(batch):
+                    assert 0 == orc.gemm_lowp(0, beta0, m, n, k, m, k, m, a[i * m * k:(i + 1) * m * k], b[i * k * n:(i + 1) * k * n], ref[i * m * n:(i + 1) * m * n], 1.0)
+                da, db = (torch.from_numpy(x.view(np.int16)).cuda() for x in (a, b)); dc = torch.from_numpy(c).cuda()
+                assert 0 == L.libxsmm_amd_gemm_batch_strided(C.c_void_p(desc), da.data_ptr(), db.data_ptr(), dc.data_ptr(), m * k, k * n, m * n, batch)
+                torch.cuda.synchronize()
+                assert xs.last_kernel() == "smm_i16i32_jit_shape_lowp", xs.last_kernel()
+                assert np.array_equal(dc.cpu().numpy(), ref), (beta0, batch)
+    finally:
         if old_env is None:
             os.environ.pop("LIBXSMM_AMD_JIT_MINBATCH", None)
         else:

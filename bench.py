@@ -325,6 +325,30 @@ def secondary(torch, xs, L):
         res[name] = {"batch": B64, "kernel": xs.last_kernel(), "ms": round(md * 1e3, 4), "hbm_gbs": round(byt64 / md / 1e9, 1),
                      "frac": round(byt64 / md / 1e9 / HBM_PEAK_GBS, 4), "gflops": round(2.0 * m * n * k * B64 / md / 1e9, 1)}
         del a, b, c, pool
+    # bf16 inputs, fp32 result, 64^3 (reference: libxsmm_bsmmdispatch, src/libxsmm_main.c:2230-2244): the one-wave-per-item
+    # matrix-core kernel on the widened operands (bit-identical to the gold loop's product-then-add)
+    try:
+        m = n = k = 64
+        Bl = 131072
+        a16 = (torch.randint(0, 1024, (Bl * m * k,), device="cuda", dtype=torch.int32, generator=g) + 0x3C00).to(torch.int16)
+        b16 = (torch.randint(0, 1024, (Bl * k * n,), device="cuda", dtype=torch.int32, generator=g) + 0x3C00).to(torch.int16)
+        c32 = torch.zeros(Bl * m * n, device="cuda", dtype=torch.float32)
+        blob = xs.DescriptorBlob()
+        L.libxsmm_gemm_descriptor_dinit2.restype = C.c_void_p
+        L.libxsmm_gemm_descriptor_dinit2.argtypes = [C.c_void_p] + [C.c_int] * 8 + [C.c_double, C.c_double, C.c_int, C.c_int]
+        dl = L.libxsmm_gemm_descriptor_dinit2(C.byref(blob), xs.BF16, xs.F32, m, n, k, m, k, m, 1.0, 1.0, 0, 0)
+
+        def lowp64():
+            assert 0 == L.libxsmm_amd_gemm_batch_strided(C.c_void_p(dl), xs.dptr(a16), xs.dptr(b16), xs.dptr(c32), m * k, k * n, m * n, Bl)
+        lowp64(); L.libxsmm_amd_jit_wait()
+        _, tl = time_steps(torch, lowp64, 5, 2, None)
+        ml = sum(tl) / len(tl) * 1e-3
+        bytl = Bl * (2.0 * (m * k + k * n) + 8.0 * m * n)
+        res["smm_bf16f32_64x64x64"] = {"batch": Bl, "kernel": xs.last_kernel(), "ms": round(ml * 1e3, 4), "hbm_gbs": round(bytl / ml / 1e9, 1),
+                                       "frac": round(bytl / ml / 1e9 / HBM_PEAK_GBS, 4), "gflops": round(2.0 * m * n * k * Bl / ml / 1e9, 1)}
+        del a16, b16, c32
+    except Exception as e:  # noqa: BLE001 (a secondary figure must not take the bench line down)
+        res["smm_bf16f32_64x64x64"] = {"error": str(e)[:200]}
     L.libxsmm_amd_set_mfma(old_mfma)
     return res
 

@@ -78,20 +78,44 @@ def time_steps(torch, fn, steps, warmup, dist):
     return t1 - t0, [e0.elapsed_time(e1) for (e0, e1) in evs]
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` outside a torchrun job: this process starts the N ranks itself (one process per GPU,
+    `python -m torch.distributed.run`, rendezvous on 127.0.0.1), relays what they print -- rank 0's JSON line -- and exits with
+    their status. It runs before anything here has touched the GPU (no torch import yet) and starts the ranks as CHILD processes
+    (never an exec); a rank that fails is not restarted (--max-restarts 0): the job ends non-zero."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL between processes on this driver)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--max-restarts", "0",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args))
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(1, args.gpus):
+        print("bench.py: --gpus %d but the job has %d ranks: reporting n_gpus = %d" % (args.gpus, world, world), file=sys.stderr)
+    if not torch.cuda.is_available():
+        print("bench.py needs a GPU (rank %d of %d): the engine has no CPU compute path" % (rank, world), file=sys.stderr, flush=True)
+        if world > 1:
+            time.sleep(2.0)  # (the launcher ends the other ranks as soon as one has failed: let each say why first)
+        raise SystemExit(1)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist_mod.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
         dist = dist_mod
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the engine has no CPU compute path")
     torch.cuda.set_device(local)
     xs = importlib.import_module("libxsmm-1_amd")
     L = xs.lib()

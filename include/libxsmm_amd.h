@@ -21,14 +21,25 @@ LIBXSMM_API int libxsmm_amd_device_count(void);
  *  on different streams, by one thread switching streams between calls or by several threads. */
 LIBXSMM_API void libxsmm_amd_set_stream(void* hip_stream);
 LIBXSMM_API void* libxsmm_amd_get_stream(void);
-/** Calls of a dispatched kernel on device memory, kernel(a, b, c) once per product (samples/smm/specialized.cpp:172-190), do
- *  not cost a launch each: consecutive calls form a burst whose work is queued on the stream with the first call (a gate
- *  kernel that waits for the burst to be complete and the batch kernel behind it) while the following calls only append
- *  their operands to a ring in pinned memory. A burst is completed by the next entry point of the library called on the
- *  thread, by a call that may not run beside the recorded ones, or by a helper thread a few microseconds after the
- *  last call -- so whatever the caller queues or waits for afterwards (its own kernels, hipMemcpy, hipStreamSynchronize,
- *  hipDeviceSynchronize) is ordered behind the calls as behind any asynchronous launch. libxsmm_amd_flush completes the
- *  calling thread's burst at once (a latency hint, never needed for correctness). LIBXSMM_AMD_DEFER=0: a launch per call. */
+/** Calls of a dispatched kernel on device memory, kernel(a, b, c) once per product (samples/smm/specialized.cpp:172-190;
+ *  likewise libxsmm_?fsspmdm_execute once per panel, samples/pyfr/pyfr_driver_asp_reg.c:300-308).
+ *  DEFAULT: every call is an asynchronous launch of its own on the calling thread's stream; stream order is call order,
+ *  so work the caller queues on that stream between two calls (own kernels, hipMemcpyAsync, torch operations) is
+ *  ordered between them exactly as it was issued.
+ *  OPT-IN, no launch per call: between libxsmm_amd_defer_begin() and libxsmm_amd_defer_end() on the calling thread (the
+ *  analogue of the reference's libxsmm_mmbatch_begin/end bracket, src/libxsmm_ext_gemm.c:1016-1135; brackets nest), or
+ *  process-wide with LIBXSMM_AMD_DEFER=1, consecutive calls form a burst: the first call queues a gate kernel and the
+ *  batch kernel behind it on the stream, the following calls only append their operands to a ring in pinned memory and
+ *  RUN AT THE STREAM POSITION OF THE BURST'S FIRST CALL. The caller's side of the contract: inside the bracket, before
+ *  queueing work of its own on that stream that reads or writes operands of the calls -- call libxsmm_amd_flush().
+ *  Work queued or waited for after libxsmm_amd_defer_end() / libxsmm_amd_flush() / any other entry point of the library
+ *  on the thread is ordered behind all recorded calls (an idle burst is also sealed by a helper thread after a few
+ *  microseconds, so a caller's hipStreamSynchronize inside the bracket never hangs). Calls that depend on each other
+ *  (a C read as A by a later call, a C written again later) are detected from the operand addresses and keep the call
+ *  order. libxsmm_amd_defer_active(): 1 if calls of this thread are being recorded. */
+LIBXSMM_API void libxsmm_amd_defer_begin(void);
+LIBXSMM_API void libxsmm_amd_defer_end(void);
+LIBXSMM_API int libxsmm_amd_defer_active(void);
 LIBXSMM_API void libxsmm_amd_flush(void);
 /** Block until all work enqueued by this library on its stream has completed. Returns EXIT_SUCCESS/FAILURE. */
 LIBXSMM_API int libxsmm_amd_synchronize(void);
@@ -76,7 +87,9 @@ LIBXSMM_API int libxsmm_amd_gemm_batch_strided(const libxsmm_gemm_descriptor* de
  *  shape-specialised run kernels apply (M, N <= 32, K <= 64), so is the multiplication -- the accumulation chains of all
  *  shapes are resident at the same time instead of one shape after the other. Per C block the products are added in batch
  *  order as in libxsmm_gemm_batch (relaxed != 0: any order, as libxsmm_gemm_batch_omp). The groups must be independent of
- *  each other: no C block is written by two groups. transa/transb/lda/ldb/ldc may be NULL ('N', tight leading dimensions);
+ *  each other: no C block is written by two groups and no group reads (as A or B) what another group writes -- the
+ *  fused groups run side by side (libxsmm_?gemm_batch with pointer arrays checks this itself and keeps dependent groups in
+ *  order). transa/transb/lda/ldb/ldc may be NULL ('N', tight leading dimensions);
  *  alpha/beta: scalars of the precision (NULL: 1), the SMM domain only (alpha = 1, beta in {0, 1}, no TRANS_A). Matrices in
  *  device memory (or libxsmm_malloc memory); index arrays in device or host memory. Returns EXIT_SUCCESS/EXIT_FAILURE. */
 LIBXSMM_API int libxsmm_amd_gemm_batch_groups(libxsmm_gemm_precision iprec, libxsmm_gemm_precision oprec, int ngroups,

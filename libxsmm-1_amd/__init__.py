@@ -234,6 +234,9 @@ def _declare(L):
     sig("libxsmm_amd_last_kernel", C.c_char_p)
     sig("libxsmm_amd_launch_count", C.c_ulonglong)
     sig("libxsmm_amd_flush", None)
+    sig("libxsmm_amd_defer_begin", None)
+    sig("libxsmm_amd_defer_end", None)
+    sig("libxsmm_amd_defer_active", i)
     sig("libxsmm_amd_is_device_pointer", i, vp)
     sig("libxsmm_amd_gemm_batch_strided", i, vp, vp, vp, vp, ll, ll, ll, ll)
     sig("libxsmm_amd_stream_probe", i, vp, vp, vp, ll)

@@ -573,7 +573,10 @@ void spmdm_compute_wg_kernel(long long batch, int M, int N, int K, float beta,
 // non-zero) and to multiply on the matrix cores: v_mfma_f32_16x16x4_f32 is a k-ordered fmaf chain (one rounding per
 // product, no wider accumulation), and fma(0, b, acc) == acc, so each C element still receives exactly the reference's
 // chain acc = fma(val_p, B[col_p][n], acc) over its row's entries in ascending column order -- the same bits as the
-// sparse kernels (provided B is finite where A has no entry: 0 * inf would be NaN; hence the policy bit).
+// sparse kernels. Where B holds inf / NaN against a structural zero of A the reference skips the entry while 0 * inf is NaN:
+// the B tile is inspected while it is parked, and an item whose tile holds a non-finite value is multiplied entry by entry
+// instead (the gather chain, by the same work-group; tests/test_sparse_gpu.py::test_spmdm_batch_nonfinite_b_under_zeros).
+// What remains of the zero-filled multiplication: an accumulator that is exactly -0 may end as +0.
 // Roles are swapped (D = B^T-tile x A^T-tile): lane l then holds C[m = l & 15][n = 4 * (l >> 4) .. + 3] of a 16 x 16 tile,
 // one 16-byte access per lane. LDS tiles are stored in blocks whose 64 words are exactly one operand fetch of a wave:
 //   As[(m >> 4)][k >> 2][m & 15][k & 3]   (B operand: lane (j = m & 15, kq) reads word 4 * j + kq)
@@ -605,6 +608,7 @@ void spmdm_compute_mfma_kernel(long long batch, int M_arg, int K_arg, float beta
   float2* const meta = reinterpret_cast<float2*>(Bs + 64 * 16 * NT);   // [SPM_META] {bitcast(word offset of the column inside a row of As), value}
   unsigned short* const ris = reinterpret_cast<unsigned short*>(meta + SPM_META); // [M + 1]
   float* const spare = reinterpret_cast<float*>(ris + 72) + (threadIdx.x & 63);     // a word per lane nobody reads (inactive scatter lanes; one shared word would be a 32-way bank conflict)
+  int* const nonfinite = reinterpret_cast<int*>(reinterpret_cast<float*>(ris + 72) + 64); // [2]: "this item's B tile holds inf / NaN", one word per register set
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
   const int M = FULL ? 64 : M_arg, K = FULL ? 64 : K_arg;
   constexpr int N = 16 * NT, n4 = 4 * NT;
@@ -641,6 +645,8 @@ void spmdm_compute_mfma_kernel(long long batch, int M_arg, int K_arg, float beta
   int nnz2 = (item + 2 * G < batch) ? (int)rowidx[(item + 2 * G) * rstride + M] : 0;
   fetch(std::integral_constant<int, 0>(), item, nnz);
   if (item + G < batch) fetch(std::integral_constant<int, 1>(), item + G, nnz1);
+  if (t < 2) nonfinite[t] = 0;
+  SPM_BARRIER();
   auto pass = [&](auto SET) {
     constexpr int S = decltype(SET)::value;
     float* const pc = c + item * (long long)M * N;
@@ -656,6 +662,17 @@ void spmdm_compute_mfma_kernel(long long batch, int M_arg, int K_arg, float beta
       }
     }
     if (t <= M) ris[t] = rix[S];
+    { // inf / NaN in the tile? (exponent all ones: the bits shifted left by one are >= 0xFF000000)
+      unsigned top = 0;
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        if (256 * j + t < nv4) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { const unsigned u = __float_as_uint(rb[S][j][q]) << 1; top = (u > top) ? u : top; }
+        }
+      }
+      if (top >= 0xFF000000u) nonfinite[S] = 1;
+    }
     {
       const int staged = nnz < SPM_META ? nnz : SPM_META;
 #pragma unroll
@@ -726,8 +743,25 @@ void spmdm_compute_mfma_kernel(long long batch, int M_arg, int K_arg, float beta
       }
     }
     SPM_BARRIER();
+    const bool exact_gather = (0 != nonfinite[S]);
+    if (0 == t) nonfinite[S ^ 1] = 0; // (the other set's word: last read before the previous pass's closing barrier, next written after this one's)
+    if (exact_gather) { // ---- (3') B holds inf / NaN: entry by entry, zeros of A skipped as the reference does (rare: speed does not matter)
+      const uint16_t* const ci = colidx + item * cap;
+      const float* const va = values + item * cap;
+      for (int e = t; e < M * N; e += 256) {
+        const int m = e / N, n = e - m * N;
+        float sum = 0.f;
+        if (0.f != beta) { sum = pc[e]; if (1.f != beta) sum = beta * sum; }
+        const int p1 = ris[m + 1];
+        for (int p = ris[m]; p < p1; ++p) {
+          const int kr = ci[p];
+          sum = __builtin_fmaf(va[p], Bs[(((kr >> 2) * NT + (n >> 4)) << 6) + ((kr & 3) << 4) + (n & 15)], sum);
+        }
+        pc[e] = sum;
+      }
+    }
     // ---- (3) wave w multiplies rows [16 w, 16 w + 16) against all NT column tiles
-    if (16 * wave < M) {
+    else if (16 * wave < M) {
       const int i = mi;
       if (0.f != beta && 1.f != beta) {
 #pragma unroll
@@ -1154,7 +1188,7 @@ int launch_spmdm_compute(const SpmdmGeom& g, int transb, int transc, float beta,
   }
   if (mfma_fits) { // dense slice in LDS, matrix cores
     const int nt = g.n / 16;
-    const size_t lds = (size_t)64 * 64 * 4 + (size_t)64 * 16 * nt * 4 + (size_t)SPM_META * 8 + 144 + 256; // + row starts (<= 65 x 2 bytes) + a spare word per lane
+    const size_t lds = (size_t)64 * 64 * 4 + (size_t)64 * 16 * nt * 4 + (size_t)SPM_META * 8 + 144 + 256 + 16; // + row starts (<= 65 x 2 bytes) + a spare word per lane + the non-finite flags
     long long per_cu = (long long)(160 * 1024 / lds); if (per_cu > 3) per_cu = 3; if (per_cu < 1) per_cu = 1;
     static const int bpc_env = []() { const char* e = getenv("XSMM_SPMDM_BPC"); return (nullptr != e && 0 != *e) ? atoi(e) : 0; }();
     if (0 < bpc_env) per_cu = bpc_env;

@@ -1,23 +1,33 @@
-// xsmm_defer.cpp -- per-call kernel invocations on device-resident operands without a launch per call.
+// xsmm_defer.cpp -- per-call kernel invocations on device-resident operands without a launch per call (opt-in).
 //
 // The reference's canonical caller loops over its products and calls the dispatched kernel once per product
 // (samples/smm/specialized.cpp:172-190, samples/cp2k/cp2k.cpp:341-346); its deferral concept is the explicit
 // libxsmm_mmbatch_begin/end bracket (src/libxsmm_ext_gemm.c:1016-1135). On the GPU a launch per product costs 6-8 us, a
-// hundred times the product itself. Here consecutive calls of one kernel on device memory form a *burst*:
+// hundred times the product itself.
+//
+// DEFAULT: every call is a launch of its own on the calling thread's stream -- stream order is call order, whatever the
+// caller queues on that stream between two calls (its own kernels, hipMemcpyAsync, torch operations) is ordered between
+// them. That is the only rule that is safe for a caller the library knows nothing about: HIP offers no way to see
+// whether a stream has received foreign work since the library's last submission.
+//
+// OPT-IN (libxsmm_amd_defer_begin/end bracket on the calling thread, or LIBXSMM_AMD_DEFER=1 for the whole process): the
+// caller promises that between two kernel calls it queues nothing of its own on the engine's stream that touches
+// operands of the recorded calls -- or calls libxsmm_amd_flush() first. Consecutive calls of one kernel on device
+// memory then form a *burst*:
 //   * the first call of a burst queues two launches on the caller's stream: a gate (one lane that waits until the burst
 //     is sealed) and the batch kernel behind it, which takes its item count from the gate and its operand pointers from a
 //     ring in pinned host memory;
-//   * every further call only appends {a, b, c} to that ring (a hundred nanoseconds, no driver call);
-//   * the burst is sealed by whatever comes first: another entry point of the library on this thread (it asks for the
-//     stream: device()), a call that must not run beside the recorded ones (other kernel, operands that overlap a C of
-//     the burst, a C that repeats but not consecutively, a full ring), or a helper thread once the calls have stopped
-//     coming for a few microseconds.
+//   * every further call only appends {a, b, c} to that ring (a hundred nanoseconds, no driver call) -- it RUNS AT THE
+//     STREAM POSITION OF THE BURST'S FIRST CALL, which is why foreign work in between needs the flush;
+//   * the burst is sealed by whatever comes first: libxsmm_amd_flush / libxsmm_amd_defer_end, another entry point of the
+//     library on this thread (it asks for the stream: device()), a call that must not run beside the recorded ones (other
+//     kernel, operands that overlap a C of the burst, a C that repeats but not consecutively, a full ring), or a helper
+//     thread once the calls have stopped coming for a few microseconds.
 // Everything the burst does is already queued on the stream when the first call returns, so whatever the caller queues
-// or waits for afterwards -- its own kernels, hipMemcpy, hipStreamSynchronize, hipDeviceSynchronize -- is ordered behind
-// it like behind any asynchronous call; no later "flush" has to win a race against the caller. Consecutive calls with
-// the same C are a run (summed in call order by one unit of the batch kernel: the sequential chain, bit for bit).
-// Not deferred: operands the CPU addresses (results must be there on return), calls while a stream is being captured,
-// LIBXSMM_AMD_DEFER=0.
+// or waits for AFTER the last call of the burst -- hipMemcpy, hipStreamSynchronize, hipDeviceSynchronize -- is ordered
+// behind it like behind any asynchronous call. Consecutive calls with the same C are a run (summed in call order by one
+// unit of the batch kernel: the sequential chain, bit for bit).
+// Never deferred: operands the CPU addresses (results must be there on return), calls while a stream is being captured.
 #include "xsmm_internal.hpp"
 
 #include <hip/hip_runtime_api.h>
@@ -160,10 +170,12 @@ bool capturing_now(void* stream)
   return hipStreamCaptureStatusNone != st;
 }
 
+// Off unless the caller opted in: the bracket of the calling thread (libxsmm_amd_defer_begin/end) or LIBXSMM_AMD_DEFER=1
+thread_local int tl_defer_bracket = 0;
 bool defer_enabled()
 {
-  static const int env = []() { const char* e = getenv("LIBXSMM_AMD_DEFER"); return (nullptr == e || 0 == *e) ? 1 : atoi(e); }();
-  return 0 != env;
+  static const int env = []() { const char* e = getenv("LIBXSMM_AMD_DEFER"); return (nullptr == e || 0 == *e) ? 0 : atoi(e); }();
+  return 0 != env || 0 < tl_defer_bracket;
 }
 
 // the device allocation p lies in (empty: not pure device memory)
@@ -380,3 +392,10 @@ bool defer_panels(const void* handle, JitKernel* jit, const void* B, void* C, in
 using namespace xsmm;
 
 LIBXSMM_API void libxsmm_amd_flush(void) { defer_flush(); }
+LIBXSMM_API void libxsmm_amd_defer_begin(void) { ++tl_defer_bracket; }
+LIBXSMM_API void libxsmm_amd_defer_end(void)
+{
+  if (0 < tl_defer_bracket) --tl_defer_bracket;
+  defer_flush(); // whatever was recorded is complete now: the caller may queue its own work behind it
+}
+LIBXSMM_API int libxsmm_amd_defer_active(void) { return defer_enabled() ? 1 : 0; }

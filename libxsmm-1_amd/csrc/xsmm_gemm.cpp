@@ -159,32 +159,46 @@ int sync_and_run(SmmBatch& s, bool nosync)
 // together. Whatever does not fit that form is launched batch by batch. Every s[i] arrives with its addressing resolved
 // (device index / pointer arrays) and s[i].sync == SYNC_DEVICE (verdict needed) or SYNC_NONE.
 int run_groups(std::vector<SmmBatch>& groups)
-{
+{ // The launches follow the caller's group order: groups that need the verdict are collected while they follow each other
+  // and leave as one fused launch as soon as a group of the other kind (beta == 0, the caller's promise of a negative size,
+  // a single item) comes up -- which is launched behind them, where the caller put it. (The reference works its groups off
+  // one after the other, src/libxsmm_gemm.c:1231-1262; groups inside one fused launch run side by side, which is why the
+  // callers of this function have made sure that those neither write the same C blocks nor read what another one writes.)
   int result = 0;
-  std::vector<SmmBatch> wanted; std::vector<size_t> where;
+  std::vector<SmmBatch> wanted;
+  auto flush_wanted = [&]() -> int {
+    for (size_t first = 0; first < wanted.size(); first += 32) { // (a check launch takes up to 32 batches)
+      const int n = (int)((wanted.size() - first < 32) ? (wanted.size() - first) : 32);
+      SmmBatch* const g = wanted.data() + first;
+      bool ok = true;
+      for (int i = 0; i < n && ok; ++i) {
+        int* const slot = flag_slot();
+        if (nullptr == slot) { ok = false; break; }
+        g[i].devflags = slot; // (c_atomics: set by the caller, who has looked at where C lives)
+      }
+      if (ok) ok = (0 == launch_c_order_check_groups(g, n, device().stream));
+      if (!ok) { flag_slot_commit(); wanted.clear(); return -1; }
+      const char* name = "";
+      int e = launch_smm_jit_grouped(g, n, device().stream, &name);
+      if (0 <= e) { note_launch(name); if (0 != e) { fprintf(stderr, "LIBXSMM-AMD ERROR: kernel launch failed (%s, hip error %d)\n", name, e); result = e; } }
+      else { // batch by batch (each reads its verdict slot)
+        for (int i = 0; i < n; ++i) { e = run_smm(g[i]); if (0 != e) result = e; }
+      }
+      flag_slot_commit();
+    }
+    wanted.clear();
+    return 0;
+  };
   for (size_t i = 0; i < groups.size(); ++i) {
-    if (SYNC_DEVICE == groups[i].sync && 1 < groups[i].batch && 0 == groups[i].general) { wanted.push_back(groups[i]); where.push_back(i); }
-    else if (0 < groups[i].batch) { groups[i].sync = SYNC_NONE; const int e = run_smm(groups[i]); if (0 != e) result = e; }
-  }
-  for (size_t first = 0; first < wanted.size(); first += 32) { // (a check launch takes up to 32 batches)
-    const int n = (int)((wanted.size() - first < 32) ? (wanted.size() - first) : 32);
-    SmmBatch* const g = wanted.data() + first;
-    bool ok = true;
-    for (int i = 0; i < n && ok; ++i) {
-      int* const slot = flag_slot();
-      if (nullptr == slot) { ok = false; break; }
-      g[i].devflags = slot; // (c_atomics: set by the caller, who has looked at where C lives)
+    if (SYNC_DEVICE == groups[i].sync && 1 < groups[i].batch && 0 == groups[i].general) wanted.push_back(groups[i]);
+    else if (0 < groups[i].batch) {
+      if (0 != flush_wanted()) return -1;
+      groups[i].sync = SYNC_NONE;
+      const int e = run_smm(groups[i]);
+      if (0 != e) result = e;
     }
-    if (ok) ok = (0 == launch_c_order_check_groups(g, n, device().stream));
-    if (!ok) { flag_slot_commit(); return -1; }
-    const char* name = "";
-    int e = launch_smm_jit_grouped(g, n, device().stream, &name);
-    if (0 <= e) { note_launch(name); if (0 != e) { fprintf(stderr, "LIBXSMM-AMD ERROR: kernel launch failed (%s, hip error %d)\n", name, e); result = e; } }
-    else { // batch by batch (each reads its verdict slot)
-      for (int i = 0; i < n; ++i) { e = run_smm(g[i]); if (0 != e) result = e; }
-    }
-    flag_slot_commit();
   }
+  if (0 != flush_wanted()) return -1;
   return result;
 }
 
@@ -771,7 +785,8 @@ bool try_grouped_pointer_batches(libxsmm_gemm_precision prec, bool relaxed, cons
   if (is_device_ptr(a_array) || is_device_ptr(b_array) || is_device_ptr(c_array)) return false; // (pointer arrays the CPU cannot read: group by group)
   std::vector<SmmBatch> groups; groups.reserve((size_t)ngroups);
   struct Range { uintptr_t lo, hi; };
-  std::vector<Range> ranges; ranges.reserve((size_t)ngroups);
+  struct Hulls { Range a, b, c; };
+  std::vector<Hulls> hulls; hulls.reserve((size_t)ngroups);
   long long j = 0;
   for (libxsmm_blasint g = 0; g < ngroups; ++g) {
     const long long size = LIBXSMM_ABS(group_size[g]);
@@ -788,15 +803,21 @@ bool try_grouped_pointer_batches(libxsmm_gemm_precision prec, bool relaxed, cons
     s.mode = ADDR_POINTER; s.sa = s.sb = s.sc = (long long)sizeof(void*); s.batch = size;
     s.relaxed = relaxed_order(relaxed ? 2 : 1, 0, c_array + j) ? 1 : 0; s.c_atomics = 1;
     s.sync = (0 != (s.flags & LIBXSMM_GEMM_FLAG_BETA_0) || group_size[g] < 0 || size < 2) ? SYNC_NONE : SYNC_DEVICE;
-    uintptr_t lo = reinterpret_cast<uintptr_t>(c_array[j]), hi = lo;
-    for (long long i = 1; i < size; ++i) { const uintptr_t p = reinterpret_cast<uintptr_t>(c_array[j + i]); if (p < lo) lo = p; if (p > hi) hi = p; }
-    ranges.push_back(Range{ lo, hi + span_c(s) * sizeof(T) });
+    auto hull = [&](const T* const* p, size_t span) { // address range the matrices behind `size` pointers occupy
+      uintptr_t lo = reinterpret_cast<uintptr_t>(p[0]), hi = lo;
+      for (long long i = 1; i < size; ++i) { const uintptr_t q = reinterpret_cast<uintptr_t>(p[i]); if (q < lo) lo = q; if (q > hi) hi = q; }
+      return Range{ lo, hi + span * sizeof(T) };
+    };
+    hulls.push_back(Hulls{ hull(a_array + j, span_a(s)), hull(b_array + j, span_b(s)), hull(const_cast<const T* const*>(c_array + j), span_c(s)) });
     s.a = a_array + j; s.b = b_array + j; s.c = c_array + j; // (host arrays for now: uploaded below, once all groups have passed)
     groups.push_back(s);
     j += size;
   }
-  for (size_t x = 0; x < ranges.size(); ++x) for (size_t y = x + 1; y < ranges.size(); ++y) {
-    if (ranges[x].lo < ranges[y].hi && ranges[y].lo < ranges[x].hi) return false; // C of two groups may overlap: keep the groups in order
+  // The reference runs the groups strictly one after the other: a later group may read (as A or B) or update what an earlier
+  // one wrote. Fused, the groups run side by side -- only if no group's C meets another group's C, A or B.
+  auto meet = [](const Range& x, const Range& y) { return x.lo < y.hi && y.lo < x.hi; };
+  for (size_t x = 0; x < hulls.size(); ++x) for (size_t y = 0; y < hulls.size(); ++y) {
+    if (x != y && (meet(hulls[x].c, hulls[y].a) || meet(hulls[x].c, hulls[y].b) || (x < y && meet(hulls[x].c, hulls[y].c)))) return false;
   }
   bool ok = true;
   for (SmmBatch& s : groups) {

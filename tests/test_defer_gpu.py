@@ -1,8 +1,10 @@
 """Per-call invocations of a dispatched kernel on device memory (the reference's canonical caller,
-samples/smm/specialized.cpp:172-190: `kernel(a + i * asize, b + i * bsize, c + i * csize)` once per product) are recorded
-into stream-ordered bursts instead of costing a launch each (libxsmm-1_amd/csrc/xsmm_defer.cpp). What must hold: the
-results equal the oracle's sequential loop bit for bit whatever the calls alias, and anything the caller queues or waits
-for afterwards -- without a further call into the library -- sees them.
+samples/smm/specialized.cpp:172-190: `kernel(a + i * asize, b + i * bsize, c + i * csize)` once per product) inside the
+opt-in bracket libxsmm_amd_defer_begin/end are recorded into stream-ordered bursts instead of costing a launch each
+(libxsmm-1_amd/csrc/xsmm_defer.cpp). What must hold: the results equal the oracle's sequential loop bit for bit whatever
+the calls alias, and anything the caller queues or waits for after the last call -- without a further call into the
+library -- sees them. (The default, a launch per call, and work of the caller's own between two calls:
+tests/test_call_order_gpu.py.)
 
 The calling loop is a few lines of C compiled here (a Python loop is too slow to keep a burst open).
 """
@@ -41,6 +43,18 @@ def loop(tmp_path_factory):
     lib.call_loop2.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, ll, C.c_int]; lib.call_loop2.restype = None
     lib.panel_loop.argtypes = [vp, vp, vp, vp, ll, ll, C.c_int, C.c_int]; lib.panel_loop.restype = None
     return lib
+
+
+@pytest.fixture(autouse=True)
+def bracket(xs):
+    """every test of this module runs inside the calling thread's opt-in bracket"""
+    L = xs.lib()
+    assert 0 == L.libxsmm_amd_defer_active()  # off by default
+    L.libxsmm_amd_defer_begin()
+    assert 1 == L.libxsmm_amd_defer_active()
+    yield
+    L.libxsmm_amd_defer_end()
+    assert 0 == L.libxsmm_amd_defer_active()
 
 
 def _dispatch(xs, dtype, m, n, k, flags=None):
@@ -292,11 +306,13 @@ def test_threads_with_their_own_streams_and_bursts(xs, orc, torch_gpu, loop, sca
     def work(t):
         try:
             L.libxsmm_amd_set_stream(C.c_void_p(streams[t].cuda_stream))
+            L.libxsmm_amd_defer_begin()  # (the bracket is a per-thread setting)
             da, db, dc = dev[t]
             for _ in range(3):
                 _run(loop, fn, da, db, dc, i * m * k, i * k * n, i * m * n, 8)
             streams[t].synchronize()  # the thread's own wait, no library call
             out[t] = dc.cpu().numpy()
+            L.libxsmm_amd_defer_end()
             L.libxsmm_amd_set_stream(None)
         except Exception as e:  # noqa: BLE001
             errors.append(e)

@@ -102,3 +102,24 @@ def test_shard_range_properties():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             assert max(e - b for b, e in spans) - min(e - b for b, e in spans) <= (n + world - 1) // world
+
+
+@pytest.mark.parametrize("config", [2, 4, 5])
+def test_bench_starts_its_own_ranks(config):
+    """`python bench.py --gpus 2` outside a torchrun job starts two ranks itself (bench.py:launch_ranks): in this GPU-less
+    container both reach the "needs a GPU" exit with RANK 0 / 1 of WORLD_SIZE 2, and the launcher passes their failure on
+    (non-zero exit, no restart). With WORLD_SIZE already set (the driver's torchrun form) nothing is spawned."""
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("the CPU form of this test expects the ranks to stop at the GPU check")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--config", str(config)],
+                         capture_output=True, text=True, env=env, timeout=600)
+    assert res.returncode != 0
+    for rank in (0, 1):
+        assert "needs a GPU (rank %d of 2)" % rank in res.stderr, res.stderr[-2000:]
+    # inside a job (WORLD_SIZE set) the same command is one rank of it: no second level of ranks
+    env.update({"RANK": "1", "WORLD_SIZE": "2", "LOCAL_RANK": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port())})
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", str(config)], capture_output=True, text=True, env=env, timeout=600)
+    assert res.returncode != 0 and "needs a GPU (rank 1 of 2)" in res.stderr and "rank 0 of 2" not in res.stderr

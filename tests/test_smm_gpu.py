@@ -414,6 +414,57 @@ def test_pointer_arrays_and_groups(xs, orc, torch_gpu):
         assert np.array_equal(dc.cpu().numpy(), ref)
 
 
+@pytest.mark.parametrize("omp", [False, True])
+@pytest.mark.parametrize("second", ["reads_c_of_first_as_a", "reads_c_of_first_as_b", "updates_c_of_first", "beta0_first_then_update"])
+def test_groups_that_depend_on_each_other_keep_the_group_order(xs, orc, torch_gpu, omp, second):
+    """libxsmm_dgemm_batch[_omp] with two groups where the second depends on the first. The reference works the groups off
+    strictly one after the other (src/libxsmm_gemm.c:1231-1262, each group a libxsmm_gemm_batch), so C1 += A B followed by
+    C2 += C1 D -- or a second update of C1 -- is legal in one call; the fused launch must not be taken then."""
+    torch = torch_gpu
+    L = xs.lib()
+    rng = np.random.default_rng(31)
+    m = n = k = 16
+    cnt = 300  # (large enough for the specialised kernels and the grouped launch to be candidates)
+    sz = m * n
+    A = rng.uniform(-1, 1, cnt * sz); B = rng.uniform(-1, 1, cnt * sz); D = rng.uniform(-1, 1, cnt * sz)
+    C1 = rng.uniform(-1, 1, cnt * sz); C2 = rng.uniform(-1, 1, cnt * sz)
+    beta0_first = (second == "beta0_first_then_update")
+    r1 = C1.copy(); r2 = C2.copy()
+    orc.gemm_batch_strided(orc.FMA, 16 if beta0_first else 0, m, n, k, m, k, m, A, B, r1, sz, sz, sz, cnt)
+    if second == "reads_c_of_first_as_a":
+        orc.gemm_batch_strided(orc.FMA, 0, m, n, k, m, k, m, r1, D, r2, sz, sz, sz, cnt)
+    elif second == "reads_c_of_first_as_b":
+        orc.gemm_batch_strided(orc.FMA, 0, m, n, k, m, k, m, D, r1, r2, sz, sz, sz, cnt)
+    else:  # the second group updates the blocks of the first once more
+        orc.gemm_batch_strided(orc.FMA, 0, m, n, k, m, k, m, D, B, r1, sz, sz, sz, cnt)
+    dA, dB, dD, d1, d2 = (torch.from_numpy(x).cuda() for x in (A, B, D, C1, C2))
+    blk = lambda t, i: t.data_ptr() + i * sz * 8
+    pa = np.zeros(2 * cnt, dtype=np.uint64); pb = np.zeros(2 * cnt, dtype=np.uint64); pc = np.zeros(2 * cnt, dtype=np.uint64)
+    for i in range(cnt):
+        pa[i], pb[i], pc[i] = blk(dA, i), blk(dB, i), blk(d1, i)
+        if second == "reads_c_of_first_as_a":
+            pa[cnt + i], pb[cnt + i], pc[cnt + i] = blk(d1, i), blk(dD, i), blk(d2, i)
+        elif second == "reads_c_of_first_as_b":
+            pa[cnt + i], pb[cnt + i], pc[cnt + i] = blk(dD, i), blk(d1, i), blk(d2, i)
+        else:
+            pa[cnt + i], pb[cnt + i], pc[cnt + i] = blk(dD, i), blk(dB, i), blk(d1, i)
+    ng = 2
+    ta = (C.c_char * ng)(*[b"N"] * ng); tb = (C.c_char * ng)(*[b"N"] * ng)
+    ms = (C.c_int * ng)(m, m); ns = (C.c_int * ng)(n, n); ks = (C.c_int * ng)(k, k)
+    lds = (C.c_int * ng)(m, m)
+    al = (C.c_double * ng)(1.0, 1.0); be = (C.c_double * ng)(0.0 if beta0_first else 1.0, 1.0)
+    gs = (C.c_int * ng)(cnt, cnt); gc = C.c_int(ng)
+    old = L.libxsmm_amd_set_mfma(0)
+    try:
+        f = L.libxsmm_dgemm_batch_omp if omp else L.libxsmm_dgemm_batch
+        f(ta, tb, ms, ns, ks, al, xs.dptr(pa), lds, xs.dptr(pb), lds, be, xs.dptr(pc), lds, C.byref(gc), gs)
+        torch.cuda.synchronize()
+    finally:
+        L.libxsmm_amd_set_mfma(old)
+    assert np.array_equal(d1.cpu().numpy(), r1)
+    assert np.array_equal(d2.cpu().numpy(), r2)
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_shared_c_runs_accumulate_in_batch_order(xs, orc, torch_gpu, dtype):
     """CP2K-style stacks (samples/cp2k/cp2k.cpp:328-360): consecutive products update the same C; the sequential

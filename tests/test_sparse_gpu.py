@@ -280,6 +280,55 @@ def test_spmdm_batch_config4(xs, orc, torch_gpu, keep, variant):
     L.libxsmm_amd_spmdm_batch_destroy(sb)
 
 
+@pytest.mark.parametrize("beta", [0.0, 1.0, 0.5])
+@pytest.mark.parametrize("mfma", [1, 0])
+def test_spmdm_batch_nonfinite_b_under_zeros(xs, orc, torch_gpu, beta, mfma):
+    """B holds inf / NaN in rows that meet only structural zeros of A (and, in other items, real entries). The reference
+    skips absent entries (compute tpl :321-371: the loop runs over the CSR entries), so C stays finite where no entry meets
+    the bad value and becomes inf / NaN exactly where one does. At 50 % density the batch goes to the matrix-core kernel, which
+    multiplies a zero-filled slice (0 * inf = NaN): it has to notice such tiles and work them off entry by entry."""
+    torch = torch_gpu
+    L = xs.lib()
+    M, N, K, batch = 64, 48, 64, 41
+    rng = np.random.default_rng(29)
+    a = rng.uniform(-1, 1, batch * M * K).astype(np.float32)
+    a[rng.random(batch * M * K) < 0.5] = 0.0
+    A = a.reshape(batch, M, K)
+    b = rng.uniform(-1, 1, batch * K * N).astype(np.float32)
+    Bt = b.reshape(batch, K, N)
+    A[1, :, 7] = 0.0; Bt[1, 7, :] = np.inf                     # a whole row of B under a column of zeros: C of item 1 stays finite
+    A[2, :, 9] = 0.0; Bt[2, 9, 5] = np.nan; Bt[2, 9, 40] = -np.inf
+    Bt[3, 11, 3] = np.inf                                      # meets real entries too: inf / NaN in column 3 of those rows only
+    A[4, 10:20, 30] = 0.0; Bt[4, 30, 17] = np.nan              # NaN reaches the rows with an entry in column 30, not rows 10..19
+    Bt[batch - 1, K - 1, N - 1] = np.inf
+    old = L.libxsmm_amd_set_mfma(mfma)
+    try:
+        sb = L.libxsmm_amd_spmdm_batch_create(M, N, K, batch)
+        assert sb
+        da, db = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+        assert 0 == L.libxsmm_amd_spmdm_batch_create_slices(sb, b"N", xs.dptr(da))
+        c = rng.uniform(-1, 1, batch * M * N).astype(np.float32)
+        if beta == 0.0:
+            c[:] = np.nan
+        ref = c.copy()
+        orc.spmdm_exec_batch(orc.FMA, M, N, K, 48, "N", "N", "N", beta, a, b, ref, batch, 4)
+        R = ref.reshape(batch, M, N)
+        assert np.all(np.isfinite(R[1])) and np.all(np.isfinite(R[2])) and np.all(np.isfinite(R[4, 10:20]))  # the oracle skips absent entries
+        assert not np.all(np.isfinite(R[3])) and not np.all(np.isfinite(R[4]))
+        dc = torch.from_numpy(c).cuda()
+        be = C.c_float(beta)
+        assert 0 == L.libxsmm_amd_spmdm_batch_compute(sb, b"N", xs.dptr(db), b"N", C.byref(be), xs.dptr(dc))
+        torch.cuda.synchronize()
+        got = dc.cpu().numpy()
+        finite = np.isfinite(ref)
+        assert np.array_equal(np.isnan(got), np.isnan(ref))
+        assert np.array_equal(got[~np.isnan(ref)], ref[~np.isnan(ref)])  # (inf compares equal to inf of the same sign)
+        assert np.array_equal(got[finite].view(np.uint32), ref[finite].view(np.uint32))
+        L.libxsmm_amd_spmdm_batch_destroy(sb)
+    finally:
+        L.libxsmm_amd_set_mfma(old)
+
+
 def _device_slices(xs, h, slices):
     """the handle's CSR slices copied from HBM: [(rowidx, colidx, values)] indexed kb*mb_count+mb"""
     L = xs.lib()

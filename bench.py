@@ -285,7 +285,7 @@ def secondary(torch, xs, L):
     # config 5 shape mix on one GPU: CP2K-style stacks, fp64, 27 shapes x 19418 products, runs of u products per C block
     # (samples/cp2k/cp2k.cpp:155,328-360); one libxsmm_gemm_batch (index arrays) per shape group, one stream
     import math
-    old_mfma = L.libxsmm_amd_set_mfma(0)
+    old_mfma = L.libxsmm_amd_set_mfma(1)  # (the default policy: runs of products per C block on the matrix-core run form, bit-exact chain)
     groups, byt, flops = [], 0.0, 0.0
     for (m, n, k) in [(m, n, k) for m in (13, 23, 32) for n in (13, 23, 32) for k in (13, 23, 32)]:
         s_ = 19418
@@ -454,7 +454,6 @@ def config5(args, torch, xs, L, dist, rank, world):
     -- every rank sums into its own copy of all C blocks, one fused all-reduce joins them."""
     import math
     dist_mod = importlib.import_module("libxsmm-1_amd.dist")
-    L.libxsmm_amd_set_mfma(0)
     products = 524288 if args.batch == 1048576 else args.batch
     shapes = [(m, n, k) for m in (13, 23, 32) for n in (13, 23, 32) for k in (13, 23, 32)]
     per = products // len(shapes)

@@ -172,8 +172,12 @@ int library_gemm(int typesize, int transa, int transb, int m, int n, int k, doub
 // flight on several streams, or more calls in flight than the ring is long, never share a slot.
 namespace {
 constexpr unsigned FLAG_RING = 256, FLAG_INTS = 4 + 2 * FLAG_SLOT_BLOCKS;
-struct FlagSlot { hipEvent_t done = nullptr; void* stream = nullptr; int state = 0; /* 1: handed out, 2: committed */ };
-struct FlagRing { int* mem = nullptr; FlagSlot slot[FLAG_RING]; unsigned next = 0; };
+// A call's slots share ONE event (recorded by flag_slot_commit): an event record is a barrier packet of its own on the queue, and
+// one per slot -- 27 for a grouped CP2K call -- left the GPU idle for 100 us behind every call (profiles/r3_cp2k_trace.txt). The
+// ring of commit events is as long as the ring of slots and every commit takes at least one slot, so an event is recorded
+// again only after every slot that referred to its previous recording has been handed out -- and waited for -- again.
+struct FlagSlot { int commit = -1; void* stream = nullptr; int state = 0; /* 1: handed out, 2: committed */ };
+struct FlagRing { int* mem = nullptr; FlagSlot slot[FLAG_RING]; hipEvent_t commits[FLAG_RING] = {}; unsigned next = 0, next_commit = 0; };
 // rings outlive their threads: a thread that ends hands its ring to the next thread that needs one (no HIP call at thread exit)
 std::mutex g_flag_rings_lock;
 std::vector<FlagRing*> g_flag_rings_idle;
@@ -190,12 +194,17 @@ FlagRing* flag_ring()
     if (!g_flag_rings_idle.empty()) { tl_flags.ring = g_flag_rings_idle.back(); g_flag_rings_idle.pop_back(); return tl_flags.ring; }
   }
   // a new ring: cleared once, and the clearing is complete before the first slot is handed out (a check kernel on another
-  // stream must never run ahead of it)
+  // stream must never run ahead of it). Cleared with a synchronous memset that involves no stream of the caller's: the first
+  // batch call of a thread may happen while its stream is being captured (nothing may be queued on, or waited for, there).
   void* p = nullptr;
   const size_t bytes = (size_t)FLAG_RING * FLAG_INTS * sizeof(int);
-  hipStream_t st = (hipStream_t)device().stream;
   if (hipSuccess != hipMalloc(&p, bytes)) { (void)hipGetLastError(); return nullptr; }
-  if (hipSuccess != hipMemsetAsync(p, 0, bytes, st) || hipSuccess != hipStreamSynchronize(st)) { (void)hipGetLastError(); (void)hipFree(p); return nullptr; }
+  hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed; // (a blocking memset is a "potentially unsafe" call for captures of other threads in global mode)
+  (void)hipThreadExchangeStreamCaptureMode(&mode);
+  const hipError_t e = hipMemset(p, 0, bytes);
+  const hipError_t e2 = (hipSuccess == e ? hipDeviceSynchronize() : e);
+  (void)hipThreadExchangeStreamCaptureMode(&mode);
+  if (hipSuccess != e || hipSuccess != e2) { (void)hipGetLastError(); (void)hipFree(p); return nullptr; }
   FlagRing* const r = new FlagRing();
   r->mem = static_cast<int*>(p);
   tl_flags.ring = r;
@@ -212,11 +221,10 @@ int* flag_slot()
   hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
   if (hipSuccess != hipStreamIsCapturing((hipStream_t)device().stream, &capturing)) { (void)hipGetLastError(); capturing = hipStreamCaptureStatusNone; }
   if (hipStreamCaptureStatusNone == capturing) { // (inside a stream capture nothing may be waited for: the slot's last use lies a whole ring back)
-    if (2 == f.state) { if (hipSuccess != hipEventSynchronize(f.done)) (void)hipGetLastError(); } // (an event recorded inside a capture cannot be waited for: treated as done)
+    if (2 == f.state && 0 <= f.commit) { if (hipSuccess != hipEventSynchronize(r->commits[f.commit])) (void)hipGetLastError(); } // (an event recorded inside a capture cannot be waited for: treated as done)
     else if (1 == f.state) (void)hipStreamSynchronize((hipStream_t)f.stream); // handed out but never committed (an error path)
   }
-  if (nullptr == f.done && hipSuccess != hipEventCreateWithFlags(&f.done, hipEventDisableTiming)) { (void)hipGetLastError(); f.done = nullptr; return nullptr; }
-  f.stream = device().stream; f.state = 1;
+  f.stream = device().stream; f.state = 1; f.commit = -1;
   return r->mem + (size_t)FLAG_INTS * i;
 }
 
@@ -224,9 +232,18 @@ void flag_slot_commit()
 {
   FlagRing* const r = tl_flags.ring;
   if (nullptr == r) return;
+  // one event per stream that holds handed-out slots (one stream, unless the caller switched streams inside a call)
   for (unsigned i = 0; i < FLAG_RING; ++i) {
-    FlagSlot& f = r->slot[i];
-    if (1 == f.state) { if (hipSuccess == hipEventRecord(f.done, (hipStream_t)f.stream)) f.state = 2; else (void)hipGetLastError(); }
+    if (1 != r->slot[i].state) continue;
+    void* const stream = r->slot[i].stream;
+    const int c = (int)(r->next_commit++ % FLAG_RING);
+    bool ok = (nullptr != r->commits[c]) || hipSuccess == hipEventCreateWithFlags(&r->commits[c], hipEventDisableTiming);
+    if (ok) ok = (hipSuccess == hipEventRecord(r->commits[c], (hipStream_t)stream));
+    if (!ok) { (void)hipGetLastError(); continue; } // (the slots stay "handed out": their next use waits for the stream)
+    for (unsigned j = i; j < FLAG_RING; ++j) {
+      FlagSlot& f = r->slot[j];
+      if (1 == f.state && f.stream == stream) { f.state = 2; f.commit = c; }
+    }
   }
 }
 
@@ -241,18 +258,21 @@ int flag_slot_set(int* slot, int equal_pairs, int decreasing_pairs)
 // of pinned buffers and copied with the copy engine, asynchronously -- the call does not wait for the GPU. A ring entry is
 // reused INDEX_RING calls later; by then the launch that read it (event recorded by index_upload_commit) is normally long done.
 namespace {
-struct IndexStage { void* host = nullptr; void* dev = nullptr; size_t size = 0; hipEvent_t done = nullptr; void* stream = nullptr; int state = 0; /* 1: filled, 2: committed */ };
+struct IndexStage { void* host = nullptr; void* dev = nullptr; size_t size = 0; int commit = -1; void* stream = nullptr; int state = 0; /* 1: filled, 2: committed */ };
 constexpr int INDEX_RING = 256; // (a grouped call stages three arrays per group plus its table)
 thread_local IndexStage tl_index_ring[INDEX_RING];
 thread_local unsigned tl_index_next = 0;
+// (one event per commit, shared by the entries a call has filled: see the flag ring above)
+thread_local hipEvent_t tl_index_commits[INDEX_RING] = {};
+thread_local unsigned tl_index_next_commit = 0;
 }
 
 void* index_upload(const void* src, size_t bytes)
 {
   IndexStage& e = tl_index_ring[tl_index_next++ % INDEX_RING];
-  if (2 == e.state) (void)hipEventSynchronize(e.done);
+  if (2 == e.state && 0 <= e.commit) (void)hipEventSynchronize(tl_index_commits[e.commit]);
   else if (1 == e.state) (void)hipStreamSynchronize((hipStream_t)e.stream); // filled but never committed (an error path)
-  e.state = 0;
+  e.state = 0; e.commit = -1;
   if (e.size < bytes) {
     if (nullptr != e.host) (void)hipHostFree(e.host);
     if (nullptr != e.dev) (void)hipFree(e.dev);
@@ -266,7 +286,6 @@ void* index_upload(const void* src, size_t bytes)
     }
     e.size = want;
   }
-  if (nullptr == e.done && hipSuccess != hipEventCreateWithFlags(&e.done, hipEventDisableTiming)) { (void)hipGetLastError(); return nullptr; }
   memcpy(e.host, src, bytes);
   e.stream = device().stream;
   if (hipSuccess != hipMemcpyAsync(e.dev, e.host, bytes, hipMemcpyHostToDevice, (hipStream_t)e.stream)) { (void)hipGetLastError(); return nullptr; }
@@ -277,8 +296,16 @@ void* index_upload(const void* src, size_t bytes)
 void index_upload_commit()
 { // the launches that read the staged arrays are queued: mark the point after which the entries may be overwritten
   for (int i = 0; i < INDEX_RING; ++i) {
-    IndexStage& e = tl_index_ring[i];
-    if (1 == e.state) { if (hipSuccess == hipEventRecord(e.done, (hipStream_t)e.stream)) e.state = 2; else (void)hipGetLastError(); }
+    if (1 != tl_index_ring[i].state) continue;
+    void* const stream = tl_index_ring[i].stream;
+    const int c = (int)(tl_index_next_commit++ % INDEX_RING);
+    bool ok = (nullptr != tl_index_commits[c]) || hipSuccess == hipEventCreateWithFlags(&tl_index_commits[c], hipEventDisableTiming);
+    if (ok) ok = (hipSuccess == hipEventRecord(tl_index_commits[c], (hipStream_t)stream));
+    if (!ok) { (void)hipGetLastError(); continue; }
+    for (int j = i; j < INDEX_RING; ++j) {
+      IndexStage& e = tl_index_ring[j];
+      if (1 == e.state && e.stream == stream) { e.state = 2; e.commit = c; }
+    }
   }
 }
 

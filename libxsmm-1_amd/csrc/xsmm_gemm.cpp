@@ -1046,7 +1046,7 @@ LIBXSMM_API int libxsmm_amd_smm_kernel_source(const libxsmm_gemm_descriptor* des
   const libxsmm_gemm_descriptor& d = *descriptor;
   const int ip = LIBXSMM_GETENUM_INP(d.datatype);
   if (LIBXSMM_GEMM_PRECISION_F64 != ip && LIBXSMM_GEMM_PRECISION_F32 != ip) return -1;
-  const std::string src = gen_smm_source(LIBXSMM_GEMM_PRECISION_F64 == ip ? 8 : 4, (int)d.m, (int)d.n, (int)d.k, d.flags, variant & 0xFFFF, (int)d.lda, (int)d.ldb, (int)d.ldc);
+  const std::string src = gen_smm_source(LIBXSMM_GEMM_PRECISION_F64 == ip ? 8 : 4, (int)d.m, (int)d.n, (int)d.k, d.flags, variant & 0x1FFFF, (int)d.lda, (int)d.ldb, (int)d.ldc);
   if (nullptr != buffer && 0 < buffer_size) {
     const size_t n = (src.size() < buffer_size - 1 ? src.size() : buffer_size - 1);
     memcpy(buffer, src.data(), n); buffer[n] = 0;

@@ -129,7 +129,8 @@ int jit_launch_raw(JitKernel* k, unsigned blocks, unsigned threads, void* arg0, 
 enum { SMM_JIT_SCALAR = 1, SMM_JIT_RUNS = 2, SMM_JIT_WGRUNS = 4, SMM_JIT_HASWG = 8, SMM_JIT_BIG = 16, SMM_JIT_SPLIT = 32,
        SMM_JIT_MFMA = 64 /* matrix-core work-group kernel (kernels/smm_mfma_wg.inc) with the shape baked in; + 128: tight fp32 operands as 16-byte chunks */, SMM_JIT_MFMA_TIGHT = 128, SMM_JIT_MFMA_TIGHTC = 8192 /* fp32: C as a contiguous array through LDS */,
        SMM_JIT_MFMA_WAVE = 16384 /* matrix-core kernel with one wave per item (16x16x4 tiles) */,
-       SMM_JIT_MFMA_WAVE2 = 32768 /* ... the columns of C in two halves against one image of A (fp64 56^3: the images of a whole item leave no room for four waves per CU) */ }; // variant bits of the generated dense kernel
+       SMM_JIT_MFMA_WAVE2 = 32768 /* ... the columns of C in two halves against one image of A (fp64 56^3: the images of a whole item leave no room for four waves per CU) */,
+       SMM_JIT_MFMA_RUNS = 65536 /* run form on the matrix cores: a wave per run, A fragments straight from memory, B through LDS (M, N <= 32) */ }; // variant bits of the generated dense kernel
 std::string gen_smm_source(int typesize, int m, int n, int k, int flags, int variant, int lda = 0, int ldb = 0, int ldc = 0); // (0: tight)
 bool smm_jit_eligible(const SmmBatch& s);
 int launch_smm_jit(const SmmBatch& s, void* stream, const char** name); // -1: not available

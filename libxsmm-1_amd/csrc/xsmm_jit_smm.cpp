@@ -102,7 +102,10 @@ constexpr int AS1 = ((K * M + TGM * TM + 3) / 4) * 4;                 // per ite
 constexpr int BS1 = XTRANSB ? (((K * N + NPAD + 3) / 4) * 4) : ((NPAD * KP + 3) / 4) * 4;
 constexpr int AS_SIZE = G * AS1, BS_SIZE = G * BS1;
 constexpr int CS_SIZE = ((G * CT1 + 3) / 4) * 4;                     // the items' C blocks stay contiguous (flat copy in and out)
-constexpr int WAVE_LDS = AS_SIZE + BS_SIZE + CS_SIZE;                // elements (wave form)
+// (wave run form: C is in LDS only while a run is opened or closed, when no operand image is alive -- its image lies over theirs;
+// a third less LDS per wave is a third more chains resident per CU)
+constexpr bool C_OVER_AB = (1 == XRUNS);
+constexpr int WAVE_LDS = C_OVER_AB ? ((AS_SIZE + BS_SIZE > CS_SIZE) ? (AS_SIZE + BS_SIZE) : CS_SIZE) : (AS_SIZE + BS_SIZE + CS_SIZE); // elements (wave form)
 constexpr int WG_BUF = AS_SIZE + BS_SIZE;                            // elements per operand buffer (work-group form)
 constexpr int WG_NBUF = (2 * WG_BUF * TS <= 65536) ? 2 : 1;          // double-buffered when 64 KiB allow
 
@@ -407,6 +410,11 @@ __device__ __forceinline__ void atomic_c(T* Cs, T* pc, int lane, int tx, int ty,
 }
 #endif
 
+)XSMM";
+
+// walking a batch run by run (shared by the register-tiled run forms below and the matrix-core run form): needs T, DevAddr /
+// resolve, XRUNS, XSPLIT, XDEPTH
+const char* const SMM_JIT_CHAIN = R"XSMM(
 // bit l: item first + l starts a run, i.e. its C differs from its predecessor's (item 0 always does)
 __device__ __forceinline__ unsigned long long head_mask(const DevAddr& ad, long long first, int lane, long long batch)
 {
@@ -493,6 +501,9 @@ __device__ __forceinline__ const T* window_pick(unsigned long long v, int src)
   const int w_src_ = __builtin_amdgcn_readfirstlane((int)((I) - (W).base)); \
   const T* const PA = window_pick((W).a, w_src_); const T* const PB = window_pick((W).b, w_src_)
 
+)XSMM";
+
+const char* const SMM_JIT_SHAPE_KERNELS = R"XSMM(
 #if (2 == XRUNS)
 // Work-group form for long runs (CP2K stacks, batch-reduce): the four waves of a work-group share every product of a run.
 // All 256 threads stream A and B of the products D ahead into register stages while the current one is multiplied out of
@@ -501,7 +512,7 @@ __device__ __forceinline__ const T* window_pick(unsigned long long v, int src)
 // the sequential reference's chain. A long run is a latency chain (HBM round trip per product): the depth of the register
 // ring, not the thread count, is what shortens it.
 #if XGROUPED
-__device__ __attribute__((noinline)) void xsmm_entry(const DevAddr& ad, long long batch, unsigned xbid, unsigned xgrid, T* lds)
+__device__ XENTRY_ATTR void xsmm_entry(const DevAddr& ad, long long batch, unsigned xbid, unsigned xgrid, T* lds)
 {
 #else
 extern "C" __global__ __launch_bounds__(256) void xsmm_smm_op(DevAddr ad, long long batch)
@@ -584,7 +595,7 @@ extern "C" __global__ __launch_bounds__(256) void xsmm_smm_op(DevAddr ad, long l
 }
 #else
 #if XGROUPED
-__device__ __attribute__((noinline)) void xsmm_entry(const DevAddr& ad, long long batch, unsigned xbid, unsigned xgrid, T* lds)
+__device__ XENTRY_ATTR void xsmm_entry(const DevAddr& ad, long long batch, unsigned xbid, unsigned xgrid, T* lds)
 {
   if ((int)(threadIdx.x >> 6) >= XWAVES) return; // (the grouped kernel's work-groups have four waves)
 #else
@@ -598,7 +609,7 @@ extern "C" __global__ __launch_bounds__(64 * XWAVES) void xsmm_smm_op(DevAddr ad
   const int grp = lane / LPI, tx = (lane % LPI) % TGM, ty = (lane % LPI) / TGM;
   T* const As = lds + wave * WAVE_LDS;
   T* const Bs = As + AS_SIZE;
-  T* const Cs = Bs + BS_SIZE;
+  T* const Cs = C_OVER_AB ? As : (Bs + BS_SIZE);
   const long long w = (long long)xbid * XWAVES + wave, W = (long long)xgrid * XWAVES;
 #if XRUNS
   // Consecutive items that share one C form a run (CP2K stacks, batch-reduce): the wave that owns the run's first item
@@ -650,6 +661,7 @@ extern "C" __global__ __launch_bounds__(64 * XWAVES) void xsmm_smm_op(DevAddr ad
               pc = resolve<T>(ad.c, ad.ic, ad.sc, ad, i);
               if (!XBETA0) { park_c(Cs, lane, rc); wave_lds_sync(); }
               acc_from_c(Cs, tx, ty, acc, XBETA0);
+              if (!XBETA0) wave_lds_sync(); // (the operand images are parked over C's next)
             }
           }
           park_ab(As, Bs, lane, ra[s], rb[s]);
@@ -1109,6 +1121,195 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(X
 #endif
 )XSMM";
 
+const char* const SMM_JIT_MFMA_RUNS_CONST = R"XSMM(
+// ---- run form on the matrix cores: M, N <= 32, K <= 64, fp32 / fp64, any addressing mode, any leading dimensions -------------
+// The register-tiled run form above spends a product's time on LDS round trips (every k step fetches TM + TN operands per lane
+// for TM x TN fma: the LDS pipe is half busy, the waves wait on it) and holds 250-300 registers for a 32^3 fp64 product -- two
+// waves per SIMD, spills in the grouped kernel. Here a wave still owns a run (C in the accumulators across its products, the
+// products added in batch order), but:
+//   * A never touches LDS: v_mfma_{f32,f64}_16x16x4 wants, in lane (l16, lq), the element A(m = 16 mi + l16, k = 4 ks + lq) --
+//     sixteen lanes along a column of A, i.e. contiguous in memory for any lda. The fragments of a product are loaded straight
+//     from global memory into the registers the instructions read, one k step at a time, and the registers of k step ks are
+//     refilled with the NEXT product's right behind the instructions that consumed them;
+//   * B (lanes along n would stride through memory) arrives as a flat, coalesced array and is parked in LDS as [n][KSD], KSD
+//     chosen so that a fragment fetch is conflict-free;
+//   * C goes straight between memory and the accumulators when a run opens and closes (a lane's elements of one register are
+//     sixteen consecutive rows of a column).
+// Both instructions are k-ordered fma chains with one rounding per product (tools/probe/mfma_f64_chain.hip), K is padded to a
+// multiple of four with A = -0 / B = +0 (the product -0 is the identity of the addition for every sum, signs of zeros
+// included): C equals the reference's sequential chain bit for bit, as in the register-tiled form.
+constexpr int M = XM, N = XN, K = XK;
+constexpr int LDA = XLDA, LDB = XLDB, LDC = XLDC;
+constexpr int TS = (int)sizeof(T);
+constexpr bool F64 = (8 == TS);
+typedef T ACC __attribute__((ext_vector_type(4)));
+typedef float ACC32 __attribute__((ext_vector_type(4)));
+typedef double ACC64 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ ACC32 xmfma(float a, float b, ACC32 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ ACC64 xmfma(double a, double b, ACC64 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+constexpr int MI = (M + 15) / 16, NI = (N + 15) / 16, KS = (K + 3) / 4, KP4 = 4 * KS;
+// row stride of B's image: fp64 fragments are fetched sixteen lanes (one k, sixteen n) at a time -- an odd stride spreads them
+// over all bank pairs; fp32 fragments thirty-two lanes (two k) at a time -- a stride of 2 mod 4 keeps the two k apart as well
+constexpr int KSD = F64 ? (KP4 + 1) : (KP4 + 2);
+constexpr int BE = LDB * (N - 1) + K;                  // span of B in memory
+constexpr int NLB = (BE + 63) / 64;
+constexpr int WAVE_LDS = ((N * KSD + 3) / 4) * 4;      // elements
+#define XNROW(r) (F64 ? (lq + 4 * (r)) : (4 * lq + (r)))
+__device__ __forceinline__ int clampi(int v, int hi) { return v < hi ? v : hi; }
+__device__ __forceinline__ void xatomic_add(double* p, double v) { (void)__builtin_amdgcn_global_atomic_fadd_f64((__attribute__((address_space(1))) double*)p, v); }
+__device__ __forceinline__ void xatomic_add(float* p, float v) { (void)__builtin_amdgcn_global_atomic_fadd_f32((__attribute__((address_space(1))) float*)p, v); }
+)XSMM";
+
+const char* const SMM_JIT_MFMA_RUNS_KERNEL = R"XSMM(
+// fragment of A for k step ks, tile mi (rows beyond M repeat row M - 1: they only reach rows of C that are never stored)
+__device__ __forceinline__ T load_a_frag(const T* pa, int ks, int moff, int lq)
+{
+  const int k = 4 * ks + lq;
+  const XGLOBAL T* const g = (const XGLOBAL T*)pa;
+  if (4 * ks + 3 < K) return __builtin_nontemporal_load(g + k * LDA + moff);
+  const T v = __builtin_nontemporal_load(g + clampi(k, K - 1) * LDA + moff); // (no divergent control flow around the load)
+  return (k < K) ? v : -T(0);
+}
+__device__ __forceinline__ void load_b_flat(const T* pb, int lane, T (&rb)[NLB])
+{
+  const XGLOBAL T* const g = (const XGLOBAL T*)pb;
+#pragma unroll
+  for (int j = 0; j < NLB; ++j) rb[j] = __builtin_nontemporal_load(g + clampi(64 * j + lane, BE - 1));
+}
+__device__ __forceinline__ void park_b(T* Bs, int lane, const T (&rb)[NLB])
+{
+#pragma unroll
+  for (int j = 0; j < NLB; ++j) {
+    const int e = 64 * j + lane, n = e / LDB, k = e - n * LDB;
+    if (e < BE && k < K) Bs[n * KSD + k] = rb[j];
+  }
+}
+__device__ __forceinline__ void acc_load(const T* pc, int l16, int lq, ACC (&acc)[NI][MI])
+{
+  const XGLOBAL T* const g = (const XGLOBAL T*)pc;
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = 16 * ni + XNROW(r), m = 16 * mi + l16;
+        acc[ni][mi][r] = g[clampi(n, N - 1) * LDC + clampi(m, M - 1)];
+      }
+}
+__device__ __forceinline__ void acc_store(T* pc, int l16, int lq, const ACC (&acc)[NI][MI], bool atomic)
+{
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = 16 * ni + XNROW(r), m = 16 * mi + l16;
+        if (n < N && m < M) {
+          if (atomic) xatomic_add(pc + n * LDC + m, acc[ni][mi][r]);
+          else ((XGLOBAL T*)pc)[n * LDC + m] = acc[ni][mi][r];
+        }
+      }
+}
+
+#if XGROUPED
+__device__ XENTRY_ATTR void xsmm_entry(const DevAddr& ad, long long batch, unsigned xbid, unsigned xgrid, T* lds)
+{
+  if ((int)(threadIdx.x >> 6) >= XWAVES) return; // (the grouped kernel's work-groups may have more waves than this body uses)
+#else
+extern "C" __global__ __launch_bounds__(64 * XWAVES) void xsmm_smm_op(DevAddr ad, long long batch)
+{
+  __shared__ __attribute__((aligned(16))) T lds[XWAVES * WAVE_LDS];
+  const unsigned xbid = blockIdx.x, xgrid = gridDim.x;
+#endif
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, l16 = lane & 15, lq = lane >> 4;
+  T* const Bs = lds + wave * WAVE_LDS;
+  const long long w = (long long)xbid * XWAVES + wave, W = (long long)xgrid * XWAVES;
+  // (walking the batch: chunks of 64 items, run heads, segments -- see the register-tiled wave form)
+  const int seg = segment_len(ad.flags, batch);
+  const long long step = (0 != seg ? seg : 64);
+  const long long nchunks = (batch + step - 1) / step, cpw = (nchunks + W - 1) / W;
+  const long long c_end = ((w + 1) * cpw < nchunks) ? (w + 1) * cpw : nchunks;
+  if (w * cpw >= c_end) return;
+  if (KP4 > K) { // the padding of B's image (+0): written once, never parked over
+    for (int e = lane; e < N * (KP4 - K); e += 64) Bs[(e / (KP4 - K)) * KSD + K + e % (KP4 - K)] = T(0);
+  }
+  int moff[MI], boff[NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) moff[mi] = clampi(16 * mi + l16, M - 1);
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) boff[ni] = clampi(16 * ni + l16, N - 1) * KSD + lq; // (columns beyond N repeat column N - 1: never stored)
+  for (long long ci = w * cpw; ci < c_end; ++ci) {
+    const long long chunk = ci * step;
+    unsigned long long heads; long long first, end;
+    if (0 != seg) { // a segment is walked from its first item, whoever opened the run it starts in
+      heads = head_mask(ad, chunk, lane, batch) | 1ULL;
+      first = chunk; end = (chunk + seg < batch ? chunk + seg : batch);
+    }
+    else if (!chain_of_chunk(ad, chunk, lane, batch, heads, first, end)) continue;
+    AddrWindow win; window_fill(win, ad, first, lane, end);
+    // D products in flight (register sets; the walk is unrolled over them so that every index is a constant): a light product's
+    // arithmetic is over in a tenth of a microsecond -- one product ahead, a run of 13^3 products is a chain of memory round trips
+    T af[D][KS][MI], rb[D][NLB];
+#pragma unroll
+    for (int s = 0; s < D; ++s) {
+      const long long j = (first + s < end) ? (first + s) : (end - 1);
+      WINDOW_AB(win, j, pa0, pb0);
+      load_b_flat(pb0, lane, rb[s]);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) af[s][ks][mi] = load_a_frag(pa0, ks, moff[mi], lq);
+    }
+    ACC acc[NI][MI];
+    T* pc = nullptr;
+    for (long long i0 = first; i0 < end; i0 += D) {
+#pragma unroll
+      for (int s = 0; s < D; ++s) {
+        const long long i = i0 + s;
+        if (i >= end) break;
+        if (is_head(heads, chunk, i)) { // item i opens a run: close the previous one, take over its C
+          if (nullptr != pc) acc_store(pc, l16, lq, acc, 0 != seg);
+          pc = resolve<T>(ad.c, ad.ic, ad.sc, ad, i);
+          if (XBETA0 || 0 != seg) {
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+              for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = ACC{ 0, 0, 0, 0 };
+          }
+          else acc_load(pc, l16, lq, acc);
+        }
+        park_b(Bs, lane, rb[s]);
+        // The operands of the product D ahead take this set's place: B right away, A behind the instructions that free its
+        // registers. No control flow around the loads -- the last D products of a walk fetch the last one's operands again (never
+        // used): with conditional loads the compiler loses count of what is in flight and waits for everything, the operands just
+        // requested included, in front of the first matrix instruction (one memory round trip per product: 1.4 instead of 0.8 us
+        // for 13^3).
+        const long long inext = (i + D < end) ? (i + D) : (end - 1);
+        WINDOW_AB(win, inext, pa1, pb1);
+        load_b_flat(pb1, lane, rb[s]);
+        wave_lds_sync();
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          T bf[NI];
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) bf[ni] = Bs[boff[ni] + 4 * ks];
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = xmfma(bf[ni], af[s][ks][mi], acc[ni][mi]);
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) af[s][ks][mi] = load_a_frag(pa1, ks, moff[mi], lq);
+        }
+        wave_lds_sync(); // (B's image is parked over next)
+      }
+    }
+    acc_store(pc, l16, lq, acc, 0 != seg);
+  }
+}
+)XSMM";
+
 // LDS bytes of a wave of that kernel (mirrors the constexpr arithmetic of the source); 0: the shape is not served
 static size_t smm_mfma_wave_lds(int typesize, int m, int n, int k, int vec = 0, bool transb = false)
 { // vec: elements per memory access (0: a 16-byte chunk)
@@ -1150,6 +1351,35 @@ static int smm_mfma_wave_wpe(size_t lds, int typesize = 0, int m = 0, int n = 0,
     if (regs > 125) return 1;
   }
   return 2;
+}
+
+// ---- the run form on the matrix cores (SMM_JIT_MFMA_RUNS_*): LDS bytes of a wave (mirrors the source); 0: shape not served
+static size_t smm_mfma_runs_lds(int typesize, int m, int n, int k, int ldb)
+{
+  if (m < 1 || n < 1 || k < 1 || m > 32 || n > 32 || k > 64 || (4 != typesize && 8 != typesize)) return 0;
+  if (ldb < k) ldb = k;
+  if ((long long)ldb * (n - 1) + k > 64 * 40) return 0; // B's span travels through registers, an element per lane and load
+  const int kp4 = 4 * ((k + 3) / 4), ksd = (8 == typesize) ? kp4 + 1 : kp4 + 2;
+  return (size_t)(((n * ksd + 3) / 4) * 4) * typesize;
+}
+// products in flight per wave (register sets): as many as fit ~80 registers, four at most
+static int smm_mfma_runs_depth(int typesize, int m, int n, int k, int ldb)
+{
+  static const int env = []() { const char* e = getenv("XSMM_SMMJIT_MFMA_RUNS_DEPTH"); return (nullptr != e && 0 != *e) ? atoi(e) : 0; }(); // developer knob
+  if (0 < env) return env > 4 ? 4 : env;
+  if (ldb < k) ldb = k;
+  const int regs = (typesize / 4) * (((k + 3) / 4) * ((m + 15) / 16) + (ldb * (n - 1) + k + 63) / 64);
+  const int d = 80 / (regs > 0 ? regs : 1);
+  return d < 1 ? 1 : (d > 4 ? 4 : d);
+}
+static int smm_mfma_runs_waves(size_t lds) { return (0 == lds) ? 0 : ((4 * lds <= 65536) ? 4 : ((2 * lds <= 65536) ? 2 : 1)); }
+// may batch s (shared C: runs) take that form?
+static bool smm_mfma_runs_ok(const SmmBatch& s)
+{
+  static const int on = []() { const char* e = getenv("XSMM_SMMJIT_MFMA_RUNS"); return (nullptr != e && 0 != *e) ? atoi(e) : 1; }(); // developer knob
+  if (0 == on || 0 == s.use_mfma || 0 != s.lowp || 0 != s.general || 0 != (s.flags & LIBXSMM_GEMM_FLAG_TRANS_B)) return false;
+  if (s.lda < s.m || s.ldb < s.k || s.ldc < s.m) return false;
+  return 0 != smm_mfma_runs_lds(s.typesize, s.m, s.n, s.k, s.ldb);
 }
 
 // ---- shapes with 32 < M or N <= 64: one work-group (256 threads, 16 x 16) per item, K in chunks of KC through LDS ------
@@ -1346,7 +1576,7 @@ JitKernel* jit_resolve(MAP& table, const KEY& key, const char* fname, bool wait,
 
 } // namespace
 
-static int smm_jit_waves(int typesize, int m, int n, int k, int flags, int pack = 1);
+static int smm_jit_waves(int typesize, int m, int n, int k, int flags, int pack = 1, bool runs = false);
 
 // k-chunk of the work-group-per-item form: the largest of 32/16/8 whose two LDS buffers fit 64 KiB (0: none does)
 static size_t smm_jit_big_buf(int typesize, int m, int n, int kc, int flags)
@@ -1395,6 +1625,15 @@ std::string gen_smm_source(int typesize, int m, int n, int k, int flags, int var
   s += "#define XM " + std::to_string(m) + "\n#define XN " + std::to_string(n) + "\n#define XK " + std::to_string(k) + "\n";
   s += std::string("#define XBETA0 ") + ((flags & LIBXSMM_GEMM_FLAG_BETA_0) ? "1" : "0") + "\n";
   s += std::string("#define XTRANSB ") + ((flags & LIBXSMM_GEMM_FLAG_TRANS_B) ? "1" : "0") + "\n";
+  if (0 != (variant & SMM_JIT_MFMA_RUNS)) { // run form on the matrix cores (a wave per run)
+    s += "#define XLDA " + std::to_string(lda) + "\n#define XLDB " + std::to_string(ldb) + "\n#define XLDC " + std::to_string(ldc) + "\n";
+    s += "#define XWAVES " + std::to_string(smm_mfma_runs_waves(smm_mfma_runs_lds(typesize, m, n, k, ldb))) + "\n";
+    s += "#define XFLAT 0\n#define XRUNS 1\n#define XHASWG 0\n#define XGROUPED 0\n";
+    s += "#define XDEPTH " + std::to_string(smm_mfma_runs_depth(typesize, m, n, k, ldb)) + "\n";
+    s += std::string("#define XSPLIT ") + ((variant & SMM_JIT_SPLIT) ? "1" : "0") + "\n";
+    s += SMM_JIT_PRELUDE; s += SMM_JIT_MFMA_RUNS_CONST; s += SMM_JIT_CHAIN; s += SMM_JIT_MFMA_RUNS_KERNEL;
+    return s;
+  }
   if (0 != (variant & SMM_JIT_MFMA_WAVE2)) { // ... the columns of C in two halves
     s += "#define XFLAT 0\n#define XWPE 1\n#define XNSPLIT 2\n#define XVEC " + std::to_string(16 / typesize) + "\n";
     s += "#define XLDA " + std::to_string(m) + "\n#define XLDB " + std::to_string(k) + "\n#define XLDC " + std::to_string(m) + "\n";
@@ -1430,7 +1669,8 @@ std::string gen_smm_source(int typesize, int m, int n, int k, int flags, int var
   const int pack = smm_jit_pack_of(variant);
   s += "#define XLDA " + std::to_string(lda) + "\n#define XLDB " + std::to_string(ldb) + "\n#define XLDC " + std::to_string(ldc) + "\n"; // leading dimensions in memory
   s += "#define XPACK " + std::to_string(pack) + "\n";   // items per wave pass (streaming form of tight strided batches)
-  s += "#define XWAVES " + std::to_string(smm_jit_waves(typesize, m, n, k, flags, pack)) + "\n";
+  const bool wave_runs = (0 != (variant & SMM_JIT_RUNS) && 0 == (variant & SMM_JIT_WGRUNS)); // (the wave run form keeps C's image over the operands')
+  s += "#define XWAVES " + std::to_string(smm_jit_waves(typesize, m, n, k, flags, pack, wave_runs)) + "\n";
   s += std::string("#define XSCALAR ") + ((variant & SMM_JIT_SCALAR) ? "1" : "0") + "\n"; // element-wide loads/stores only
   // runs of equal C accumulate in registers: 1 = a wave per run, 2 = a work-group per run (long runs)
   s += std::string("#define XRUNS ") + ((variant & SMM_JIT_WGRUNS) ? "2" : ((variant & SMM_JIT_RUNS) ? "1" : "0")) + "\n";
@@ -1451,26 +1691,27 @@ std::string gen_smm_source(int typesize, int m, int n, int k, int flags, int var
     s += std::string("#define XDEFER ") + (defer_env ? "1" : "0") + "\n";
   }
   s += SMM_JIT_PRELUDE;
-  s += SMM_JIT_SHAPE;
+  s += SMM_JIT_SHAPE; s += SMM_JIT_CHAIN; s += SMM_JIT_SHAPE_KERNELS;
   return s;
 }
 
 // LDS bytes one wave of the generated kernel needs (mirrors the constexpr arithmetic of the source)
-static size_t smm_jit_wave_lds(int typesize, int m, int n, int k, int flags, int pack = 1)
-{
+static size_t smm_jit_wave_lds(int typesize, int m, int n, int k, int flags, int pack = 1, bool runs = false)
+{ // runs: the wave run form (XRUNS 1), where C's image lies over the operand images
   const int tgm = (pack >= 4) ? ((pack >= 16) ? 2 : 4) : 8, tgn = 64 / (pack * tgm);
   const int tm = (m + tgm - 1) / tgm, tn = (n + tgn - 1) / tgn;
   int kp = k; if (0 == (tn * (typesize / 4)) % 16) kp = k | 1; else while (0 == (tn * kp * (typesize / 4)) % 16) ++kp;
   const size_t as = ((size_t)(k * m + tgm * tm + 3) / 4) * 4;
   const size_t bs = (flags & LIBXSMM_GEMM_FLAG_TRANS_B) ? (((size_t)(k * n + tgn * tn + 3) / 4) * 4) : ((((size_t)tgn * tn) * kp + 3) / 4) * 4;
   const size_t cs = ((size_t)(pack * m * n + 3) / 4) * 4;
+  if (runs) return ((pack * (as + bs) > cs) ? pack * (as + bs) : cs) * typesize;
   return (pack * (as + bs) + cs) * typesize;
 }
 
 // wavefronts per work-group: as many (4, 2, 1) as fit 64 KiB of static LDS; 0 if even one wave does not fit
-static int smm_jit_waves(int typesize, int m, int n, int k, int flags, int pack)
+static int smm_jit_waves(int typesize, int m, int n, int k, int flags, int pack, bool runs)
 {
-  const size_t w = smm_jit_wave_lds(typesize, m, n, k, flags, pack);
+  const size_t w = smm_jit_wave_lds(typesize, m, n, k, flags, pack, runs);
   return (4 * w <= 65536) ? 4 : ((2 * w <= 65536) ? 2 : ((w <= 65536) ? 1 : 0));
 }
 
@@ -1578,13 +1819,26 @@ static int smm_jit_launch_variant(const SmmBatch& s, int variant, void* stream)
     if (blocks < 1) blocks = 1;
     return jit_launch_raw(k, (unsigned)blocks, 256u, &ad, sizeof(ad), &batch, stream);
   }
+  if (0 != (variant & SMM_JIT_MFMA_RUNS)) { // a wave per run on the matrix cores, dealt chunks of 64 items (segments of 8 and more if the verdict cuts the batch up)
+    const size_t wlds = smm_mfma_runs_lds(s.typesize, s.m, s.n, s.k, s.ldb);
+    const int waves = smm_mfma_runs_waves(wlds);
+    if (0 == waves) return -1;
+    const long long units = (nullptr != ad.flags) ? (batch + 7) / 8 : (batch + 63) / 64;
+    long long blocks = (units + waves - 1) / waves;
+    long long per_cu = (long long)((160 * 1024) / (wlds * (size_t)waves)); if (per_cu * waves > 16) per_cu = 16 / waves; if (per_cu < 1) per_cu = 1;
+    if (0 < bpc_env) per_cu = bpc_env;
+    if (blocks > 256 * per_cu) blocks = 256 * per_cu;
+    if (blocks < 1) blocks = 1;
+    return jit_launch_raw(k, (unsigned)blocks, 64u * (unsigned)waves, &ad, sizeof(ad), &batch, stream);
+  }
   const int pack = smm_jit_pack_of(variant);
   if (1 < pack) { // the launch covers batch / pack groups of `pack` consecutive items (the caller handles the remainder)
     ad.sa *= pack; ad.sb *= pack; ad.sc *= pack; batch /= pack;
     if (0 == batch) return 0;
   }
-  const int waves = smm_jit_waves(s.typesize, s.m, s.n, s.k, s.flags, pack);
-  const size_t lds = (size_t)waves * smm_jit_wave_lds(s.typesize, s.m, s.n, s.k, s.flags, pack);
+  const bool wave_runs = (0 != (variant & SMM_JIT_RUNS));
+  const int waves = smm_jit_waves(s.typesize, s.m, s.n, s.k, s.flags, pack, wave_runs);
+  const size_t lds = (size_t)waves * smm_jit_wave_lds(s.typesize, s.m, s.n, s.k, s.flags, pack, wave_runs);
   long long per_cu = (long long)((160 * 1024) / (lds ? lds : 1));
   if (per_cu * waves > 16) per_cu = 16 / waves; // the streaming rate peaks around 12-16 waves per CU
   if (per_cu < 1) per_cu = 1;
@@ -1639,6 +1893,12 @@ std::string gen_smm_grouped_source(int typesize, const std::vector<GroupedBody>&
 {
   std::string s = "// generated by libxsmm-amd (dense SMM run kernels of several shapes behind one dispatcher)\n";
   s += std::string("typedef ") + (8 == typesize ? "double" : "float") + " T;\n#define XLOWP 0\n#define XFLAT 0\n#define XGROUPED 1\n";
+  bool all_mfma = true;
+  for (const GroupedBody& b : bodies) all_mfma = all_mfma && 0 != (b.variant & SMM_JIT_MFMA_RUNS);
+  // The register-tiled bodies are called (inlined, the dispatcher carries the registers of all of them at once: measured slower);
+  // the matrix-core bodies are lean enough to be inlined into the switch -- no call, no callee-saved registers through scratch.
+  static const int inline_env = []() { const char* e = getenv("XSMM_SMMJIT_GROUPED_INLINE"); return (nullptr != e && 0 != *e) ? atoi(e) : 1; }(); // developer knob
+  s += std::string("#define XENTRY_ATTR ") + ((all_mfma && 0 != inline_env) ? "__forceinline__" : "__attribute__((noinline))") + "\n";
   s += SMM_JIT_PRELUDE;
   for (size_t i = 0; i < bodies.size(); ++i) {
     const GroupedBody& b = bodies[i];
@@ -1651,10 +1911,11 @@ std::string gen_smm_grouped_source(int typesize, const std::vector<GroupedBody>&
     s += "#define XWAVES 1\n"; // (wave bodies: a work-group is one wave, see below)
     s += std::string("#define XSCALAR ") + ((b.variant & SMM_JIT_SCALAR) ? "1" : "0") + "\n";
     s += std::string("#define XRUNS ") + ((b.variant & SMM_JIT_WGRUNS) ? "2" : "1") + "\n";
-    s += "#define XDEPTH " + std::to_string(smm_jit_depth(typesize, b.m, b.n, b.k, b.variant)) + "\n";
+    s += "#define XDEPTH " + std::to_string(0 != (b.variant & SMM_JIT_MFMA_RUNS) ? smm_mfma_runs_depth(typesize, b.m, b.n, b.k, b.ldb) : smm_jit_depth(typesize, b.m, b.n, b.k, b.variant)) + "\n";
     s += std::string("#define XSPLIT ") + ((b.variant & SMM_JIT_SPLIT) ? "1" : "0") + "\n";
     s += std::string("#define XHASWG ") + ((b.variant & SMM_JIT_HASWG) ? "1" : "0") + "\n";
-    s += SMM_JIT_SHAPE;
+    if (0 != (b.variant & SMM_JIT_MFMA_RUNS)) { s += SMM_JIT_MFMA_RUNS_CONST; s += SMM_JIT_CHAIN; s += SMM_JIT_MFMA_RUNS_KERNEL; s += "#undef XNROW\n"; }
+    else { s += SMM_JIT_SHAPE; s += SMM_JIT_CHAIN; s += SMM_JIT_SHAPE_KERNELS; }
     s += "#undef XM\n#undef XN\n#undef XK\n#undef XBETA0\n#undef XTRANSB\n#undef XLDA\n#undef XLDB\n#undef XLDC\n#undef XPACK\n#undef XWAVES\n"
          "#undef XSCALAR\n#undef XRUNS\n#undef XDEPTH\n#undef XSPLIT\n#undef XHASWG\n#undef WINDOW_AB\n}\n";
   }
@@ -1664,7 +1925,12 @@ std::string gen_smm_grouped_source(int typesize, const std::vector<GroupedBody>&
   // on the 27 CP2K shapes: 1.37 ms with four waves per work-group).
   // (two waves per SIMD: the bodies are called, not inlined; without the bound the kernel is given the registers of the
   // hungriest body plus its own -- 308 for the 27 CP2K shapes in fp64 -- and one wave per SIMD)
-  static const int grouped_wpe = []() { const char* e = getenv("XSMM_SMMJIT_GROUPED_WPE"); return (nullptr != e && 0 != *e) ? atoi(e) : 2; }(); // developer knob: waves per SIMD the dispatcher is compiled for
+  static const int grouped_wpe_env = []() { const char* e = getenv("XSMM_SMMJIT_GROUPED_WPE"); return (nullptr != e && 0 != *e) ? atoi(e) : 0; }(); // developer knob: waves per SIMD the dispatcher is compiled for
+  // (two waves per SIMD for either kind of body. The matrix-core bodies of 32 x 32 fp64 keep ~155 registers alive -- A fragments,
+  // B's flat image, accumulators -- and would just fit three, but inlined next to 26 others they spill at that bound: 27 CP2K
+  // shapes, 524 288 products, batch order: 0.80-0.81 ms per call with two waves per SIMD, 0.82 ms with three (1.00 ms when the
+  // light bodies keep four products in flight as well), 1.46 ms with four; profiles/r3_cp2k_stacks.txt)
+  const int grouped_wpe = (0 < grouped_wpe_env) ? grouped_wpe_env : 2;
   s += "extern \"C\" __global__ __launch_bounds__(" + std::to_string(threads) + ", " + std::to_string(grouped_wpe) + ") void xsmm_smm_grouped(const GroupEntry* __restrict__ tab, int nentries)\n{\n";
   s += "  extern __shared__ __attribute__((aligned(16))) unsigned char xsmm_dyn_lds[];\n";
   s += "  int e = 0;\n  while (e + 1 < nentries && blockIdx.x >= tab[e + 1].block_begin) ++e;\n";
@@ -1691,8 +1957,8 @@ std::unordered_map<GroupedKey, JitSlot, GroupedKeyHash> g_grouped_cache; // (gua
 // work-groups and LDS bytes one batch needs under a run-form body (the sizing of smm_jit_launch_variant)
 void grouped_geometry(const SmmBatch& s, int variant, long long* blocks, size_t* lds)
 {
-  (void)variant;
-  *lds = smm_jit_wave_lds(s.typesize, s.m, s.n, s.k, s.flags, 1); // one wave per work-group
+  if (0 != (variant & SMM_JIT_MFMA_RUNS)) *lds = smm_mfma_runs_lds(s.typesize, s.m, s.n, s.k, s.ldb);
+  else *lds = smm_jit_wave_lds(s.typesize, s.m, s.n, s.k, s.flags, 1, true); // one wave per work-group (run form)
   // a wave per chunk of 64 items (a wave whose chunk holds no run head leaves at once; if the verdict on the device cuts the
   // batch into shorter segments, a wave takes several). Sized for segments of 8 -- eight times as many work-groups, most of
   // them without work -- the 27 CP2K shapes took 0.95 ms instead of 0.6: the dispatcher, not the chains, set the pace.
@@ -1726,7 +1992,8 @@ bool grouped_plan(const SmmBatch* groups, int ngroups, bool check_eligible, Grou
   for (int g = 0; g < ngroups; ++g) {
     const SmmBatch& s = groups[g];
     if (s.typesize != groups[0].typesize || (check_eligible && !smm_jit_grouped_eligible(s))) return false;
-    const int variant = smm_jit_width_variant(s) | (0 != s.relaxed ? SMM_JIT_SPLIT : 0) | SMM_JIT_RUNS;
+    const int variant = smm_mfma_runs_ok(s) ? (SMM_JIT_SCALAR | (0 != s.relaxed ? SMM_JIT_SPLIT : 0) | SMM_JIT_RUNS | SMM_JIT_MFMA_RUNS)
+                                            : (smm_jit_width_variant(s) | (0 != s.relaxed ? SMM_JIT_SPLIT : 0) | SMM_JIT_RUNS);
     const GroupedBody body = { s.m, s.n, s.k, s.flags & (LIBXSMM_GEMM_FLAG_BETA_0 | LIBXSMM_GEMM_FLAG_TRANS_B), variant, s.lda, s.ldb, s.ldc };
     size_t bi = 0;
     while (bi < plan.key.bodies.size() && !(plan.key.bodies[bi] == body)) ++bi;
@@ -1985,6 +2252,10 @@ int launch_smm_jit(const SmmBatch& s, void* stream, const char** name)
     }
     return smm_jit_launch_variant(s, width, stream);
   }
+  if (smm_mfma_runs_ok(s)) { // shared C on the matrix cores: a wave per run (batch order; segments + atomics if the verdict or a relaxed order say so)
+    const int e = smm_jit_launch_variant(s, SMM_JIT_SCALAR | (0 != s.relaxed ? SMM_JIT_SPLIT : 0) | SMM_JIT_RUNS | SMM_JIT_MFMA_RUNS, stream);
+    if (0 <= e) { *name = f64 ? "smm_f64_mfma_runs_jit" : "smm_f32_mfma_runs_jit"; return e; }
+  }
   static const int wg_env = []() { const char* e = getenv("XSMM_SMMJIT_WG"); return (nullptr != e && 0 != *e) ? atoi(e) : 1; }(); // developer knob
   // the work-group form pays off once a product's operands are large (measured on CP2K stacks: 32^3 f64 yes, 23^3 no)
   const bool tight = (s.lda == s.m && s.ldc == s.m && (0 != (s.flags & LIBXSMM_GEMM_FLAG_TRANS_B) ? (s.ldb == s.n) : (s.ldb == s.k)));
@@ -2055,6 +2326,7 @@ int smm_jit_prebuild(const SmmBatch* shapes, int nshapes, int grouped, int* buil
       const bool wg_fits = (tight && 0 != wg_env && smm_jit_wg_buf(s.typesize, s.m, s.n, s.k, flags) <= 65536
                          && (2 == wg_env || (size_t)s.typesize * ((size_t)s.m * s.k + (size_t)s.k * s.n) >= 12288));
       for (int split = 0; split <= SMM_JIT_SPLIT; split += SMM_JIT_SPLIT) {
+        { SmmBatch r = s; r.use_mfma = 1; if (smm_mfma_runs_ok(r)) one(SMM_JIT_SCALAR | split | SMM_JIT_RUNS | SMM_JIT_MFMA_RUNS); }
         one(SMM_JIT_SCALAR | split | SMM_JIT_RUNS);
         if (wg_fits) { one(SMM_JIT_SCALAR | split | SMM_JIT_RUNS | SMM_JIT_HASWG); one(SMM_JIT_SCALAR | split | SMM_JIT_WGRUNS); }
       }
@@ -2065,6 +2337,7 @@ int smm_jit_prebuild(const SmmBatch* shapes, int nshapes, int grouped, int* buil
       std::vector<SmmBatch> g;
       for (int i = 0; i < nshapes; ++i) {
         SmmBatch s = shapes[i]; s.mode = ADDR_INDEX; s.batch = 1 << 20; s.sync = SYNC_DEVICE; s.relaxed = relaxed; s.jit_always = 1; s.c_atomics = 1;
+        s.use_mfma = 1; // (the default policy; a process that switches the matrix cores off compiles its own)
         if (smm_jit_grouped_eligible(s) && s.typesize == shapes[0].typesize) g.push_back(s);
       }
       if (1 < g.size()) build(gen_smm_grouped_source_for(g.data(), (int)g.size()));

@@ -1,0 +1,217 @@
+"""The run form on the matrix cores (csrc/xsmm_jit_smm.cpp, SMM_JIT_MFMA_RUNS_*): batches whose consecutive products share a C
+block -- CP2K stacks (samples/cp2k/cp2k.cpp:328-360), batch-reduce, blocked GEMM work lists -- with M, N <= 32. A wave owns a
+run and keeps C in the accumulators of v_mfma_{f32,f64}_16x16x4 across its products; both instructions are k-ordered fma
+chains, so C must equal the oracle's sequential chain (products in batch order, k ascending) BIT FOR BIT, exactly as the
+register-tiled run form does. Covered: index and pointer batches, runs that cross the 64-item scan chunks, untouched C blocks,
+odd shapes (K not a multiple of four: the -0 / +0 padding), leading dimensions with gaps, the relaxed order (segments joined
+with atomics: tolerance), and the 27-shape grouped launch of BASELINE config 5 under both policies.
+"""
+import ctypes as C
+import math
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+class _Jit:
+    """small test batches on the run-time specialised kernels, matrix cores on (the default policy) or off"""
+    def __init__(self, xs, mfma=1):
+        self.xs = xs; self.mfma = mfma
+
+    def __enter__(self):
+        self.old_env = os.environ.get("LIBXSMM_AMD_JIT_MINBATCH")
+        os.environ["LIBXSMM_AMD_JIT_MINBATCH"] = "1"
+        self.old = self.xs.lib().libxsmm_amd_set_mfma(self.mfma)
+
+    def __exit__(self, *exc):
+        self.xs.lib().libxsmm_amd_set_mfma(self.old)
+        if self.old_env is None:
+            del os.environ["LIBXSMM_AMD_JIT_MINBATCH"]
+        else:
+            os.environ["LIBXSMM_AMD_JIT_MINBATCH"] = self.old_env
+
+
+SHAPES = [(13, 13, 13), (23, 23, 23), (32, 32, 32), (32, 13, 23), (13, 32, 32), (5, 7, 3), (16, 16, 16), (1, 1, 1), (17, 31, 29), (32, 32, 64), (9, 20, 2),
+          (31, 2, 63)]
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("shape", SHAPES)
+def test_runs_on_the_matrix_cores_bitexact(xs, orc, torch_gpu, dtype, shape):
+    """index batches: (1) permuted operands, every item its own C (index_base 1); (2) runs of 1 ... 200 products with gaps between
+    the C blocks that are used"""
+    torch = torch_gpu
+    m, n, k = shape
+    batch = 777
+    rng = np.random.default_rng(m * 31 + n * 7 + k)
+    prec = xs.F64 if dtype == np.float64 else xs.F32
+    a = rng.uniform(-1, 1, batch * m * k).astype(dtype); b = rng.uniform(-1, 1, batch * k * n).astype(dtype)
+    want = "smm_f%d_mfma_runs_jit" % (64 if dtype == np.float64 else 32)
+    with _Jit(xs):
+        c = rng.uniform(-1, 1, batch * m * n).astype(dtype)
+        sa = (rng.permutation(batch) * m * k + 1).astype(np.int32); sb = (rng.permutation(batch) * k * n + 1).astype(np.int32)
+        sc = (np.arange(batch) * m * n + 1).astype(np.int32)
+        ref = c.copy()
+        assert 0 == orc.gemm_batch_idx(orc.FMA, 0, m, n, k, m, k, m, a, b, ref, 1, sa, sb, sc, batch)
+        da, db, dc = (torch.from_numpy(x).cuda() for x in (a, b, c))
+        xs.gemm_batch(prec, "N", "N", m, n, k, 1.0, da, m, db, k, 1.0, dc, m, 1, 4, sa, sb, sc, batch)
+        torch.cuda.synchronize()
+        assert xs.last_kernel() == want, xs.last_kernel()
+        assert np.array_equal(dc.cpu().numpy().view(np.uint8), ref.view(np.uint8))
+        lens = [1, 1, 2, 3, 64, 65, 130, 1, 7, 200, 1, 1, 1, 1, 1]
+        lens = np.array(lens + [batch - sum(lens)], dtype=np.int64)
+        nc = len(lens)
+        owners = np.sort(rng.choice(np.arange(nc + 5), size=nc, replace=False))
+        cidx = np.repeat(owners, lens)
+        c2 = rng.uniform(-1, 1, (nc + 5) * m * n).astype(dtype)
+        sa0 = (np.arange(batch) * m * k).astype(np.int32); sb0 = (np.arange(batch) * k * n).astype(np.int32); sc0 = (cidx * m * n).astype(np.int32)
+        ref2 = c2.copy()
+        assert 0 == orc.gemm_batch_idx(orc.FMA, 0, m, n, k, m, k, m, a, b, ref2, 0, sa0, sb0, sc0, batch)
+        dc2 = torch.from_numpy(c2).cuda()
+        xs.gemm_batch(prec, "N", "N", m, n, k, 1.0, da, m, db, k, 1.0, dc2, m, 0, 4, sa0, sb0, sc0, batch)
+        torch.cuda.synchronize()
+        assert xs.last_kernel() == want, xs.last_kernel()
+        assert np.array_equal(dc2.cpu().numpy().view(np.uint8), ref2.view(np.uint8))
+
+
+def test_signs_of_zeros_survive_the_k_padding(xs, orc, torch_gpu):
+    """K = 13 is padded to 16 with A = -0, B = +0: the padded products are -0, the identity of the addition for every sum --
+    also for a C that is -0 and stays untouched by real products of zero"""
+    torch = torch_gpu
+    m, n, k = 13, 13, 13
+    batch = 64
+    a = np.zeros(batch * m * k); b = np.zeros(batch * k * n)
+    a[::3] = -0.0
+    c = np.full(batch * m * n, -0.0)  # 0 * 0 = +0 added to -0 gives +0 in the reference's chain as well: whatever comes out must match the oracle's bits
+    sa = (np.arange(batch) * m * k).astype(np.int32); sb = (np.arange(batch) * k * n).astype(np.int32); sc = ((np.arange(batch) // 4) * m * n).astype(np.int32)
+    ref = c.copy()
+    assert 0 == orc.gemm_batch_idx(orc.FMA, 0, m, n, k, m, k, m, a, b, ref, 0, sa, sb, sc, batch)
+    with _Jit(xs):
+        da, db, dc = (torch.from_numpy(x).cuda() for x in (a, b, c))
+        xs.gemm_batch(xs.F64, "N", "N", m, n, k, 1.0, da, m, db, k, 1.0, dc, m, 0, 4, sa, sb, sc, batch)
+        torch.cuda.synchronize()
+        assert xs.last_kernel() == "smm_f64_mfma_runs_jit"
+    assert np.array_equal(dc.cpu().numpy().view(np.uint64), ref.view(np.uint64))
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_pointer_batches_with_runs_on_the_matrix_cores(xs, orc, torch_gpu, dtype):
+    """arrays of pointers (src/libxsmm_gemm.c:1426-1461) with repeated consecutive C pointers"""
+    torch = torch_gpu
+    m, n, k = 23, 13, 32
+    batch, nc = 300, 9
+    ts = np.dtype(dtype).itemsize
+    rng = np.random.default_rng(77)
+    a = rng.uniform(-1, 1, batch * m * k).astype(dtype); b = rng.uniform(-1, 1, batch * k * n).astype(dtype); c = rng.uniform(-1, 1, nc * m * n).astype(dtype)
+    cidx = np.sort(rng.integers(0, nc, batch))
+    ref = c.copy()
+    sa = (np.arange(batch) * m * k).astype(np.int32); sb = (np.arange(batch) * k * n).astype(np.int32); sc = (cidx * m * n).astype(np.int32)
+    assert 0 == orc.gemm_batch_idx(orc.FMA, 0, m, n, k, m, k, m, a, b, ref, 0, sa, sb, sc, batch)
+    da, db, dc = (torch.from_numpy(x).cuda() for x in (a, b, c))
+    pa = (da.data_ptr() + np.arange(batch, dtype=np.uint64) * np.uint64(m * k * ts)).astype(np.uint64)
+    pb = (db.data_ptr() + np.arange(batch, dtype=np.uint64) * np.uint64(k * n * ts)).astype(np.uint64)
+    pc = (dc.data_ptr() + cidx.astype(np.uint64) * np.uint64(m * n * ts)).astype(np.uint64)
+    dpa, dpb, dpc = (torch.from_numpy(x.view(np.int64)).cuda() for x in (pa, pb, pc))
+    ptrsize = np.array([8], dtype=np.int32)
+    prec = xs.F64 if dtype == np.float64 else xs.F32
+    with _Jit(xs):
+        xs.gemm_batch(prec, "N", "N", m, n, k, 1.0, dpa, m, dpb, k, 1.0, dpc, m, 0, 0, ptrsize, ptrsize, ptrsize, batch)
+        torch.cuda.synchronize()
+        assert xs.last_kernel().endswith("_mfma_runs_jit"), xs.last_kernel()
+    assert np.array_equal(dc.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("shape", [(23, 23, 23, 24, 24, 24), (13, 9, 17, 16, 20, 13), (32, 32, 32, 40, 32, 48), (5, 7, 3, 8, 8, 8), (16, 31, 35, 16, 35, 24)])
+def test_runs_with_gaps_in_the_leading_dimensions(xs, orc, torch_gpu, dtype, shape):
+    """lda > m, ldb > k, ldc > m: A's fragments and C are addressed through their leading dimensions, B's span is fetched whole and
+    the gaps are dropped on the way into LDS; elements of C in the gaps stay untouched"""
+    torch = torch_gpu
+    m, n, k, lda, ldb, ldc = shape
+    batch, nc = 500, 23
+    rng = np.random.default_rng(lda + ldb + ldc)
+    a = rng.uniform(-1, 1, batch * lda * k).astype(dtype); b = rng.uniform(-1, 1, batch * ldb * n).astype(dtype)
+    c = rng.uniform(-1, 1, nc * ldc * n).astype(dtype)
+    cidx = np.sort(rng.integers(0, nc, batch))
+    sa = (np.arange(batch) * lda * k).astype(np.int32); sb = (np.arange(batch) * ldb * n).astype(np.int32); sc = (cidx * ldc * n).astype(np.int32)
+    ref = c.copy()
+    assert 0 == orc.gemm_batch_idx(orc.FMA, 0, m, n, k, lda, ldb, ldc, a, b, ref, 0, sa, sb, sc, batch)
+    prec = xs.F64 if dtype == np.float64 else xs.F32
+    with _Jit(xs):
+        da, db, dc = (torch.from_numpy(x).cuda() for x in (a, b, c))
+        xs.gemm_batch(prec, "N", "N", m, n, k, 1.0, da, lda, db, ldb, 1.0, dc, ldc, 0, 4, sa, sb, sc, batch)
+        torch.cuda.synchronize()
+        assert xs.last_kernel().endswith("_mfma_runs_jit"), xs.last_kernel()
+    assert np.array_equal(dc.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("shape", [(23, 23, 23), (13, 5, 7), (32, 32, 32)])
+def test_relaxed_order_on_the_matrix_cores(xs, orc, torch_gpu, dtype, shape):
+    """libxsmm_gemm_batch_omp leaves the order of the sums open: few long runs are cut into segments whose sums join C with
+    floating-point atomics -- tolerance eps * sqrt(terms) * 4 as in tests/test_jit.py; the strict entry point stays bit-exact"""
+    torch = torch_gpu
+    m, n, k = shape
+    rng = np.random.default_rng(5 + m)
+    lens = np.array([1500, 900, 1, 1200, 700], dtype=np.int64)
+    batch = int(lens.sum()); nc = len(lens) + 1
+    cidx = np.repeat(np.array([0, 1, 2, 3, 4]), lens)
+    a = rng.uniform(-1, 1, batch * m * k).astype(dtype); b = rng.uniform(-1, 1, batch * k * n).astype(dtype)
+    c = rng.uniform(-1, 1, nc * m * n).astype(dtype)
+    sa = (rng.permutation(batch) * m * k).astype(np.int32); sb = (np.arange(batch) * k * n).astype(np.int32); sc = (cidx * m * n).astype(np.int32)
+    ref = c.copy()
+    assert 0 == orc.gemm_batch_idx(orc.FMA, 0, m, n, k, m, k, m, a, b, ref, 0, sa, sb, sc, batch)
+    prec = xs.F64 if dtype == np.float64 else xs.F32
+    da, db = (torch.from_numpy(x).cuda() for x in (a, b))
+    with _Jit(xs):
+        dc = torch.from_numpy(c).cuda()
+        xs.gemm_batch(prec, "N", "N", m, n, k, 1.0, da, m, db, k, 1.0, dc, m, 0, 4, sa, sb, sc, batch)
+        torch.cuda.synchronize()
+        assert np.array_equal(dc.cpu().numpy(), ref)
+        dc = torch.from_numpy(c).cuda()
+        xs.gemm_batch(prec, "N", "N", m, n, k, 1.0, da, m, db, k, 1.0, dc, m, 0, 4, sa, sb, sc, batch, omp=True)
+        torch.cuda.synchronize()
+        assert xs.last_kernel().endswith("_mfma_runs_jit"), xs.last_kernel()
+    out = dc.cpu().numpy()
+    tol = np.finfo(dtype).eps * np.sqrt(float(lens.max()) * k) * 4
+    assert np.max(np.abs(out - ref)) <= tol * np.max(np.abs(ref))
+    assert np.array_equal(out[5 * m * n:], c[5 * m * n:])  # the unreferenced block is untouched
+
+
+@pytest.mark.parametrize("mfma", [1, 0])
+@pytest.mark.parametrize("host_indexes", [False, True])
+def test_cp2k_27_shape_grouped_launch_bitexact(xs, orc, torch_gpu, mfma, host_indexes):
+    """The launch BASELINE config 5 is measured on (bench.py, tools/bench_cp2k.py), at a size the oracle finishes in seconds: all
+    27 shapes (M, N, K) in {13, 23, 32}^3 in ONE libxsmm_amd_gemm_batch_groups call, every group a stack whose u = isqrt(s 160 / 240)
+    consecutive products accumulate into one C block (samples/cp2k/cp2k.cpp:155,328-360; reference entry: groups of
+    libxsmm_dgemm_batch, src/libxsmm_gemm.c:1231-1262, src/libxsmm_ext_gemm.c:758-972). One fused multiplication launch -- the
+    27-body code object -- and every C block equal to the oracle's sequential chain bit for bit, matrix cores on and off."""
+    torch = torch_gpu
+    L = xs.lib()
+    shapes = [(m, n, k) for m in (13, 23, 32) for n in (13, 23, 32) for k in (13, 23, 32)]
+    rng = np.random.default_rng(2718)
+    groups, sizes = [], []
+    for gi, (m, n, k) in enumerate(shapes):
+        s = 1500 + 37 * gi  # (group sizes differ: the table of work-group ranges is not uniform)
+        u = max(1, math.isqrt(s * 160 // 240)); nc = (s + u - 1) // u
+        a = rng.uniform(-1, 1, s * m * k); b = rng.uniform(-1, 1, s * k * n); c = rng.uniform(-1, 1, nc * m * n)
+        idx = np.arange(s)
+        sa = (rng.permutation(s) * m * k).astype(np.int32); sb = (idx * k * n).astype(np.int32); sc = ((idx // u) * m * n).astype(np.int32)
+        ref = c.copy()
+        assert 0 == orc.gemm_batch_idx(orc.FMA, 0, m, n, k, m, k, m, a, b, ref, 0, sa, sb, sc, s)
+        da, db, dc = (torch.from_numpy(x).cuda() for x in (a, b, c))
+        ix = (sa, sb, sc) if host_indexes else tuple(torch.from_numpy(x).cuda() for x in (sa, sb, sc))
+        groups.append((da, db, dc, ix, ref)); sizes.append(s)
+    with _Jit(xs, mfma):
+        before = L.libxsmm_amd_launch_count()
+        rc = xs.gemm_batch_groups(xs.F64, shapes, [g[0] for g in groups], [g[1] for g in groups], [g[2] for g in groups],
+                                  [g[3][0] for g in groups], [g[3][1] for g in groups], [g[3][2] for g in groups], sizes)
+        assert rc == 0
+        torch.cuda.synchronize()
+        assert xs.last_kernel() == "smm_f64_jit_shape_runs_grouped", xs.last_kernel()
+        assert L.libxsmm_amd_launch_count() == before + 1  # ONE multiplication launch for the 27 groups
+    for gi, (da, db, dc, ix, ref) in enumerate(groups):
+        assert np.array_equal(dc.cpu().numpy().view(np.uint64), ref.view(np.uint64)), shapes[gi]

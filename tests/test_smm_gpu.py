@@ -390,10 +390,15 @@ def test_pointer_arrays_and_groups(xs, orc, torch_gpu):
     ha, hb, hc = [], [], []
     j = 0
     for (m, n, k, cnt) in groups:
-        for _ in range(cnt):
-            a = rng.uniform(-1, 1, m * k); b = rng.uniform(-1, 1, k * n); c = rng.uniform(-1, 1, m * n)
-            ha.append(a); hb.append(b); hc.append(c)
-            da, db, dc = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), torch.from_numpy(c).cuda()
+        # one pool per operand and group, the matrices of a group at increasing addresses with a gap in between (C blocks that
+        # do not come in increasing order are taken for possible repeats and summed with atomics: tolerance, not bit, parity --
+        # tests/test_smm_gpu.py::test_unsorted_duplicate_c_uses_atomics_within_tolerance)
+        sa_, sb_, sc_ = m * k + 3, k * n + 5, m * n + 7
+        pool_a = rng.uniform(-1, 1, cnt * sa_); pool_b = rng.uniform(-1, 1, cnt * sb_); pool_c = rng.uniform(-1, 1, cnt * sc_)
+        dpa_, dpb_, dpc_ = torch.from_numpy(pool_a).cuda(), torch.from_numpy(pool_b).cuda(), torch.from_numpy(pool_c).cuda()
+        for i in range(cnt):
+            a = pool_a[i * sa_:i * sa_ + m * k]; b = pool_b[i * sb_:i * sb_ + k * n]; c = pool_c[i * sc_:i * sc_ + m * n]
+            da, db, dc = dpa_[i * sa_:i * sa_ + m * k], dpb_[i * sb_:i * sb_ + k * n], dpc_[i * sc_:i * sc_ + m * n]
             mats.append((da, db, dc))
             pa[j], pb[j], pc[j] = da.data_ptr(), db.data_ptr(), dc.data_ptr()
             ref = c.copy(); orc.smm(orc.FMA, 0, m, n, k, m, k, m, a, b, ref); refs.append(ref)

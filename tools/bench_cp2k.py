@@ -24,7 +24,7 @@ HOST_IDX = bool(int(sys.argv[4])) if len(sys.argv) > 4 else False  # index array
 ONLY_GROUPED = bool(int(sys.argv[5])) if len(sys.argv) > 5 else False  # stop after the one-call form (profiling runs)
 torch.cuda.set_device(0)
 g = torch.Generator(device="cuda"); g.manual_seed(1)
-L.libxsmm_amd_set_mfma(0)
+L.libxsmm_amd_set_mfma(int(os.environ.get("CP2K_MFMA", "1")))  # 1 (the default policy): the run form on the matrix cores; 0: register-tiled run form
 
 shapes = [(m, n, k) for m in (13, 23, 32) for n in (13, 23, 32) for k in (13, 23, 32)]
 per = products // len(shapes)
@@ -93,6 +93,18 @@ if not HOST_IDX:
     t = sorted(times)[len(times) // 2]
     print("cp2k stacks%s, ONE grouped call: kernel %s  median %.3f ms (min %.3f)  %.0f GB/s (%.1f%% of 8 TB/s)  %.0f GFLOP/s"
           % (" (relaxed)" if OMP else "", xs.last_kernel(), t, min(times), tot_bytes / t / 1e6, tot_bytes / t / 1e6 / 80.0, tot_flops / t / 1e6))
+    # the same call queued back to back (what bench.py times: the GPU never waits for the host as long as a call costs the host less
+    # than the GPU) and the host's own time per call
+    nq = max(4, reps)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    h0 = _time.perf_counter(); e0.record()
+    for it in range(nq):
+        one_call()
+    e1.record(); h1 = _time.perf_counter(); torch.cuda.synchronize()
+    tq = e0.elapsed_time(e1) / nq
+    print("cp2k stacks%s, %d grouped calls queued back to back: %.3f ms per call on the GPU  %.0f GB/s (%.1f%% of 8 TB/s); host time per call %.3f ms"
+          % (" (relaxed)" if OMP else "", nq, tq, tot_bytes / tq / 1e6, tot_bytes / tq / 1e6 / 80.0, (h1 - h0) / nq * 1e3))
 
 if ONLY_GROUPED:
     sys.exit(0)

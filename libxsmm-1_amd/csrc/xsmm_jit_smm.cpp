@@ -1213,6 +1213,70 @@ __device__ __forceinline__ void acc_store(T* pc, int l16, int lq, const ACC (&ac
       }
 }
 
+#if XSTREAM
+// Every item owns its C (strided batches; index / pointer batches under the caller's promise): a wave per item, walking the batch with
+// a stride of all resident waves. The next item's operands -- B's flat array, C in the layout of the accumulators, A's fragments
+// behind the instructions that free their registers -- are in flight during this item's arithmetic; the stores of an item are
+// issued behind the loads of the next (older loads: the wait for them is not a wait for the stores).
+extern "C" __global__ __launch_bounds__(64 * XWAVES) void xsmm_smm_op(DevAddr ad, long long batch)
+{
+  __shared__ __attribute__((aligned(16))) T lds[XWAVES * WAVE_LDS];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, l16 = lane & 15, lq = lane >> 4;
+  T* const Bs = lds + wave * WAVE_LDS;
+  const long long w = (long long)blockIdx.x * XWAVES + wave, W = (long long)gridDim.x * XWAVES;
+  if (w >= batch) return;
+  if (KP4 > K) { // the padding of B's image (+0): written once, never parked over
+    for (int e = lane; e < N * (KP4 - K); e += 64) Bs[(e / (KP4 - K)) * KSD + K + e % (KP4 - K)] = T(0);
+  }
+  int moff[MI], boff[NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) moff[mi] = clampi(16 * mi + l16, M - 1);
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) boff[ni] = clampi(16 * ni + l16, N - 1) * KSD + lq;
+  T af[KS][MI], rb[NLB];
+  ACC cn[NI][MI];
+  T* pc = resolve<T>(ad.c, ad.ic, ad.sc, ad, w);
+  {
+    const T* const pa0 = resolve<const T>(ad.a, ad.ia, ad.sa, ad, w);
+    load_b_flat(resolve<const T>(ad.b, ad.ib, ad.sb, ad, w), lane, rb);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) af[ks][mi] = load_a_frag(pa0, ks, moff[mi], lq);
+    if (!XBETA0) acc_load(pc, l16, lq, cn);
+  }
+  for (long long item = w; item < batch; item += W) {
+    T* const pc_cur = pc;
+    ACC acc[NI][MI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = XBETA0 ? ACC{ 0, 0, 0, 0 } : cn[ni][mi];
+    park_b(Bs, lane, rb);
+    // (no control flow around the loads: the last item of a wave fetches its own operands once more, never used)
+    const long long next = (item + W < batch) ? (item + W) : item;
+    const T* const pa1 = resolve<const T>(ad.a, ad.ia, ad.sa, ad, next);
+    load_b_flat(resolve<const T>(ad.b, ad.ib, ad.sb, ad, next), lane, rb);
+    pc = resolve<T>(ad.c, ad.ic, ad.sc, ad, next);
+    if (!XBETA0) acc_load(pc, l16, lq, cn);
+    wave_lds_sync();
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      T bf[NI];
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) bf[ni] = Bs[boff[ni] + 4 * ks];
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = xmfma(bf[ni], af[ks][mi], acc[ni][mi]);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) af[ks][mi] = load_a_frag(pa1, ks, moff[mi], lq);
+    }
+    wave_lds_sync(); // (B's image is parked over next)
+    acc_store(pc_cur, l16, lq, acc, false);
+  }
+}
+#else
 #if XGROUPED
 __device__ XENTRY_ATTR void xsmm_entry(const DevAddr& ad, long long batch, unsigned xbid, unsigned xgrid, T* lds)
 {
@@ -1308,6 +1372,7 @@ extern "C" __global__ __launch_bounds__(64 * XWAVES) void xsmm_smm_op(DevAddr ad
     acc_store(pc, l16, lq, acc, 0 != seg);
   }
 }
+#endif
 )XSMM";
 
 // LDS bytes of a wave of that kernel (mirrors the constexpr arithmetic of the source); 0: the shape is not served
@@ -1629,6 +1694,7 @@ std::string gen_smm_source(int typesize, int m, int n, int k, int flags, int var
     s += "#define XLDA " + std::to_string(lda) + "\n#define XLDB " + std::to_string(ldb) + "\n#define XLDC " + std::to_string(ldc) + "\n";
     s += "#define XWAVES " + std::to_string(smm_mfma_runs_waves(smm_mfma_runs_lds(typesize, m, n, k, ldb))) + "\n";
     s += "#define XFLAT 0\n#define XRUNS 1\n#define XHASWG 0\n#define XGROUPED 0\n";
+    s += std::string("#define XSTREAM ") + ((variant & SMM_JIT_RUNS) ? "0" : "1") + "\n"; // (without the run bit: every item owns its C)
     s += "#define XDEPTH " + std::to_string(smm_mfma_runs_depth(typesize, m, n, k, ldb)) + "\n";
     s += std::string("#define XSPLIT ") + ((variant & SMM_JIT_SPLIT) ? "1" : "0") + "\n";
     s += SMM_JIT_PRELUDE; s += SMM_JIT_MFMA_RUNS_CONST; s += SMM_JIT_CHAIN; s += SMM_JIT_MFMA_RUNS_KERNEL;
@@ -1739,10 +1805,11 @@ bool smm_jit_eligible(const SmmBatch& s)
     if (s.k > 64) return false;                                                // 8x8 lanes x (<=4x4) tile, whole K in LDS
     if (0 == smm_jit_waves(s.typesize, s.m, s.n, s.k, s.flags)) return false; // static LDS limit per work-group
   }
-  // (the compiler works on a helper thread and its output is kept on disk, so a modest batch is enough of a reason: below
-  // about a thousand items a launch is bound by its fixed costs whatever the kernel)
+  // (the compiler works on a helper thread and its output is kept on disk, so a small batch is enough of a reason: the
+  // specialised kernel is the faster one at every size measured -- fp64 23^3: 7.9 vs 12.2 us at 32 items, 8.4 vs 13.5 us at 1024,
+  // 50 vs 77 us at 16 384; tools/bench_small_batches.py, profiles/r3_small_batches.txt)
   const char* const env_min = getenv("LIBXSMM_AMD_JIT_MINBATCH");
-  const long long min_batch = (nullptr != env_min && 0 != *env_min) ? atoll(env_min) : 1024LL;
+  const long long min_batch = (nullptr != env_min && 0 != *env_min) ? atoll(env_min) : 16LL;
   if (s.batch < min_batch && 0 == s.jit_always) return false;
   return true;
 }
@@ -1823,9 +1890,11 @@ static int smm_jit_launch_variant(const SmmBatch& s, int variant, void* stream)
     const size_t wlds = smm_mfma_runs_lds(s.typesize, s.m, s.n, s.k, s.ldb);
     const int waves = smm_mfma_runs_waves(wlds);
     if (0 == waves) return -1;
-    const long long units = (nullptr != ad.flags) ? (batch + 7) / 8 : (batch + 63) / 64;
+    const bool stream_form = (0 == (variant & SMM_JIT_RUNS)); // every item owns its C: a wave per item, stride of the resident waves
+    const long long units = stream_form ? batch : ((nullptr != ad.flags) ? (batch + 7) / 8 : (batch + 63) / 64);
     long long blocks = (units + waves - 1) / waves;
     long long per_cu = (long long)((160 * 1024) / (wlds * (size_t)waves)); if (per_cu * waves > 16) per_cu = 16 / waves; if (per_cu < 1) per_cu = 1;
+    if (stream_form) { const int occ = jit_blocks_per_cu(k, 64 * waves); if (0 < occ && occ < per_cu) per_cu = occ; } // (a persistent grid must not exceed what is resident)
     if (0 < bpc_env) per_cu = bpc_env;
     if (blocks > 256 * per_cu) blocks = 256 * per_cu;
     if (blocks < 1) blocks = 1;
@@ -1914,7 +1983,7 @@ std::string gen_smm_grouped_source(int typesize, const std::vector<GroupedBody>&
     s += "#define XDEPTH " + std::to_string(0 != (b.variant & SMM_JIT_MFMA_RUNS) ? smm_mfma_runs_depth(typesize, b.m, b.n, b.k, b.ldb) : smm_jit_depth(typesize, b.m, b.n, b.k, b.variant)) + "\n";
     s += std::string("#define XSPLIT ") + ((b.variant & SMM_JIT_SPLIT) ? "1" : "0") + "\n";
     s += std::string("#define XHASWG ") + ((b.variant & SMM_JIT_HASWG) ? "1" : "0") + "\n";
-    if (0 != (b.variant & SMM_JIT_MFMA_RUNS)) { s += SMM_JIT_MFMA_RUNS_CONST; s += SMM_JIT_CHAIN; s += SMM_JIT_MFMA_RUNS_KERNEL; s += "#undef XNROW\n"; }
+    if (0 != (b.variant & SMM_JIT_MFMA_RUNS)) { s += "#define XSTREAM 0\n"; s += SMM_JIT_MFMA_RUNS_CONST; s += SMM_JIT_CHAIN; s += SMM_JIT_MFMA_RUNS_KERNEL; s += "#undef XNROW\n#undef XSTREAM\n"; }
     else { s += SMM_JIT_SHAPE; s += SMM_JIT_CHAIN; s += SMM_JIT_SHAPE_KERNELS; }
     s += "#undef XM\n#undef XN\n#undef XK\n#undef XBETA0\n#undef XTRANSB\n#undef XLDA\n#undef XLDB\n#undef XLDC\n#undef XPACK\n#undef XWAVES\n"
          "#undef XSCALAR\n#undef XRUNS\n#undef XDEPTH\n#undef XSPLIT\n#undef XHASWG\n#undef WINDOW_AB\n}\n";
@@ -2080,7 +2149,7 @@ int launch_smm_jit_mfma(const SmmBatch& s, void* stream, const char** name)
   else if (SYNC_RUNS == s.sync && 0 < s.uniform_run && 0 == s.batch % s.uniform_run) { units = s.batch / s.uniform_run; runlen = (int)s.uniform_run; }
   if (units < 1) return -1;
   const char* const env_min = getenv("LIBXSMM_AMD_JIT_MINBATCH");
-  if (s.batch < ((nullptr != env_min && 0 != *env_min) ? atoll(env_min) : 1024LL) && 0 == s.jit_always) return -1;
+  if (s.batch < ((nullptr != env_min && 0 != *env_min) ? atoll(env_min) : 16LL) && 0 == s.jit_always) return -1;
   const bool f64 = (8 == s.typesize);
   { // one wave per item: independent items of a strided batch, tight and 16-byte aligned operands, at least four waves per CU
     static const int wave_on = []() { const char* e = getenv("XSMM_SMMJIT_MFMA_WAVE"); return (nullptr != e && 0 != *e) ? atoi(e) : 1; }(); // developer knob
@@ -2187,7 +2256,7 @@ int launch_smm_jit_lowp(const SmmBatch& s, void* stream, const char** name)
     const char* const env_min = getenv("LIBXSMM_AMD_JIT_MINBATCH");
     if (0 != wave_on && 0 != s.use_mfma && (3 == s.lowp || 4 == s.lowp) && (wave_min < s.m || wave_min < s.n) && 0 != wlds && 4 * wlds <= 160u * 1024u
       && 0 == (s.k & 7) && (3 == s.lowp || 0 == (s.m & 7)) && 0 == (bits & 15) && s.lda == s.m && s.ldb == s.k && s.ldc == s.m
-      && s.batch >= ((nullptr != env_min && 0 != *env_min) ? atoll(env_min) : 1024LL))
+      && s.batch >= ((nullptr != env_min && 0 != *env_min) ? atoll(env_min) : 16LL))
     {
       const SmmKey wkey = { 4, s.m, s.n, s.k, s.flags & LIBXSMM_GEMM_FLAG_BETA_0, SMM_JIT_MFMA_WAVE | ((4 == s.lowp ? 2 : 3) << 11), s.lda, s.ldb, s.ldc };
       JitKernel* const wk = smm_jit_get(wkey);
@@ -2215,7 +2284,7 @@ int launch_smm_jit_lowp(const SmmBatch& s, void* stream, const char** name)
   if (s.m > lim || s.n > lim || s.k > 64 || 0 != (s.k & 1) || s.lda != s.m || s.ldb != s.k || s.ldc != s.m) return -1;
   if (s.sa != (long long)s.m * s.k || s.sb != (long long)s.k * s.n || s.sc != (long long)s.m * s.n) return -1;
   const char* const env_min = getenv("LIBXSMM_AMD_JIT_MINBATCH");
-  if (s.batch < ((nullptr != env_min && 0 != *env_min) ? atoll(env_min) : 1024LL)) return -1;
+  if (s.batch < ((nullptr != env_min && 0 != *env_min) ? atoll(env_min) : 16LL)) return -1;
   if (0 == smm_jit_waves(4, s.m, s.n, s.k, s.flags)) return -1;
   SmmBatch j = s;
   j.typesize = 4; j.lowp = 0; j.sync = SYNC_NONE;
@@ -2236,6 +2305,18 @@ int launch_smm_jit(const SmmBatch& s, void* stream, const char** name)
     return smm_jit_launch_variant(s, SMM_JIT_BIG, stream);
   }
   if (SYNC_NONE == s.sync) { // every item owns its C
+    { // leading dimensions with gaps: the matrix-core run form addresses A's fragments and C through their leading dimensions (no
+      // gap element is requested) -- every item is a run of its own there
+      const char* const gaps_env = getenv("XSMM_SMMJIT_GAPS_MFMA"); // developer knob (re-read on every call: tests and tools toggle it): 0 off, 1 gaps only, 2 tight items too
+      // (tools/bench_generic.py, fraction of the HBM peak in algorithmic bytes, register-tiled streaming form -> this one: fp64 23^3 ld 24
+      // 54.1 -> 59.2 %, fp32 32^3 ld 40 42.3 -> 50.5 %, fp64 13^3 ld 16 44.1 -> 51.6 %; tight fp64 23^3 64.5 -> 61.5 %: tight items stay)
+      const int gaps_mfma = (nullptr != gaps_env && 0 != *gaps_env) ? atoi(gaps_env) : 1;
+      const bool tight_ld = (s.lda == s.m && s.ldc == s.m && s.ldb == s.k);
+      if (0 != gaps_mfma && (!tight_ld || 2 == gaps_mfma) && smm_mfma_runs_ok(s)) {
+        const int e = smm_jit_launch_variant(s, SMM_JIT_SCALAR | SMM_JIT_MFMA_RUNS, stream);
+        if (0 <= e) { *name = f64 ? "smm_f64_mfma_stream_jit" : "smm_f32_mfma_stream_jit"; return e; }
+      }
+    }
     *name = f64 ? "smm_f64_jit_shape" : "smm_f32_jit_shape";
     const int pack = smm_jit_pack(s, width);
     if (1 < pack) { // groups of `pack` consecutive items per wave, then the few items that are left

@@ -14,6 +14,11 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 # Tests name the kernel they expect right after the first call of a shape: compile in the calling thread (the product's default
 # is the helper thread, with the pre-compiled kernel serving meanwhile -- tests/test_jit.py::test_jit_never_blocks_a_batch_call)
 os.environ.setdefault("LIBXSMM_AMD_JIT_ASYNC", "0")
+# The product specialises a descriptor from 16 items on (the compiler runs on a helper thread; the pre-compiled generic kernel
+# serves meanwhile, with the same bits). The tests compile in the calling thread (above), and hundreds of small batches of random
+# shapes would each wait for hiprtc: here batches below 1024 items stay on the pre-compiled kernels -- which also keeps those
+# kernels covered -- unless a test asks for the specialised ones itself (LIBXSMM_AMD_JIT_MINBATCH=1 inside the test).
+os.environ.setdefault("LIBXSMM_AMD_JIT_MINBATCH", "1024")
 
 
 def pytest_configure(config):

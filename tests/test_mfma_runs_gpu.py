@@ -215,3 +215,40 @@ def test_cp2k_27_shape_grouped_launch_bitexact(xs, orc, torch_gpu, mfma, host_in
         assert L.libxsmm_amd_launch_count() == before + 1  # ONE multiplication launch for the 27 groups
     for gi, (da, db, dc, ix, ref) in enumerate(groups):
         assert np.array_equal(dc.cpu().numpy().view(np.uint64), ref.view(np.uint64)), shapes[gi]
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("shape", [(23, 23, 23, 24, 24, 24), (13, 13, 13, 16, 16, 16), (32, 32, 32, 40, 40, 40), (5, 7, 3, 8, 8, 8), (16, 31, 35, 16, 35, 24),
+                                   (23, 23, 23, 23, 23, 23), (32, 32, 32, 32, 32, 32), (1, 1, 1, 1, 1, 1), (31, 2, 63, 33, 64, 31)])
+@pytest.mark.parametrize("beta", [1.0, 0.0])
+def test_independent_items_on_the_matrix_core_streaming_form(xs, orc, torch_gpu, dtype, shape, beta):
+    """strided batches whose items own their C (SYNC_NONE), with and without gaps in the leading dimensions, on the streaming form of
+    the matrix-core kernel: a wave per item, A's fragments and C addressed through their leading dimensions. Bit-equal to the
+    oracle's chain; gap elements of C untouched; beta = 0 never reads C (NaN canaries); batches smaller and larger than the grid."""
+    torch = torch_gpu
+    m, n, k, lda, ldb, ldc = shape
+    rng = np.random.default_rng(lda * 3 + ldb + ldc + int(beta))
+    prec = xs.F64 if dtype == np.float64 else xs.F32
+    old_env = os.environ.get("XSMM_SMMJIT_GAPS_MFMA")
+    os.environ["XSMM_SMMJIT_GAPS_MFMA"] = "2"
+    try:
+        with _Jit(xs):
+            for batch in (7, 5000):
+                a = rng.uniform(-1, 1, batch * lda * k).astype(dtype); b = rng.uniform(-1, 1, batch * ldb * n).astype(dtype)
+                c = rng.uniform(-1, 1, batch * ldc * n).astype(dtype)
+                if beta == 0.0:  # the elements a product writes are NaN before: C must not be read
+                    cv = c.reshape(batch, n, ldc); cv[:, :, :m] = np.nan
+                ref = c.copy()
+                orc.gemm_batch_strided(orc.FMA, 0 if beta else 16, m, n, k, lda, ldb, ldc, a, b, ref, lda * k, ldb * n, ldc * n, batch)
+                blob, d = xs.descriptor(prec, m, n, k, lda, ldb, ldc, 1.0, beta)
+                da, db, dc = (torch.from_numpy(x).cuda() for x in (a, b, c))
+                assert 0 == xs.lib().libxsmm_amd_gemm_batch_strided(d, xs.dptr(da), xs.dptr(db), xs.dptr(dc), lda * k, ldb * n, ldc * n, batch)
+                torch.cuda.synchronize()
+                if not (dtype == np.float32 and shape == (32, 32, 32, 32, 32, 32)):  # (tight fp32 32^3 has its hand-tuned kernel, tried first)
+                    assert xs.last_kernel().endswith("_mfma_stream_jit"), xs.last_kernel()
+                assert np.array_equal(dc.cpu().numpy().view(np.uint8), ref.view(np.uint8)), batch
+    finally:
+        if old_env is None:
+            del os.environ["XSMM_SMMJIT_GAPS_MFMA"]
+        else:
+            os.environ["XSMM_SMMJIT_GAPS_MFMA"] = old_env

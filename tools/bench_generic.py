@@ -13,7 +13,7 @@ import torch  # noqa: E402
 xs = importlib.import_module("libxsmm-1_amd")
 L = xs.lib()
 torch.cuda.set_device(0)
-L.libxsmm_amd_set_mfma(0)
+L.libxsmm_amd_set_mfma(int(os.environ.get("XSMM_BENCH_MFMA", "0")))
 
 
 def run(tag, m, n, k, lda, ldb, ldc, batch, dt=torch.float64, jit=True):

@@ -24,7 +24,9 @@ using namespace xsmm;
 
 namespace {
 
-int run_smm(const SmmBatch& s)
+// host_visible: -1 = look at the operands (a driver query each), 0 = the caller knows they are plain device memory, 1 = some
+// operand is memory the CPU addresses as well (the call waits for the stream)
+int run_smm(const SmmBatch& s, int host_visible = -1)
 {
   const char* name = "";
   int e = -1;
@@ -38,6 +40,7 @@ int run_smm(const SmmBatch& s)
   if (SYNC_DEVICE == s.sync) flag_slot_commit(); // the launches that read the verdict are queued
   note_launch(name);
   if (0 != e) fprintf(stderr, "LIBXSMM-AMD ERROR: kernel launch failed (%s, hip error %d)\n", name, e);
+  else if (0 <= host_visible) { if (0 != host_visible) (void)stream_sync(); }
   else if (ADDR_POINTER == s.mode) { // arrays of pointers: look at the first operands if the arrays can be read here
     if (is_host_visible(s.a) && is_host_visible(s.b) && is_host_visible(s.c)) {
       settle(*static_cast<const void* const*>(s.a), *static_cast<const void* const*>(s.b), *static_cast<void* const*>(s.c));
@@ -396,16 +399,18 @@ int single_execute(SmmBatch s, const void* a, const void* b, void* c)
 {
   if (!device_ready()) { fail_no_device("a dispatched SMM kernel"); return EXIT_FAILURE; }
   s.mode = ADDR_STRIDED; s.batch = 1; s.sa = s.sb = s.sc = 0; s.sync = SYNC_NONE;
-  if (is_device_ptr(a) && is_device_ptr(b) && is_device_ptr(c)) {
+  const int ka = pointer_kind(a), kb = pointer_kind(b), kc = pointer_kind(c); // (one driver query per operand: this is the per-call path)
+  if (0 != (ka & kb & kc & 1)) {
+    const int visible = (0 != ((ka | kb | kc) & 2)) ? 1 : 0;
     // one product far outside the SMM domain: the plain library GEMM (what the reference hands to its BLAS)
     if (2.0 * s.m * s.n * s.k >= 2.0 * 256 * 256 * 256 && s.m >= 64 && s.n >= 64 && s.k >= 32) {
       const double al = (0 != s.general ? s.alpha : 1.0), be = (0 != s.general ? s.beta : ((s.flags & LIBXSMM_GEMM_FLAG_BETA_0) ? 0.0 : 1.0));
       const int e = library_gemm(s.typesize, 0 != s.general && 0 != (s.flags & LIBXSMM_GEMM_FLAG_TRANS_A), 0 != (s.flags & LIBXSMM_GEMM_FLAG_TRANS_B),
         s.m, s.n, s.k, al, a, s.lda, b, s.ldb, be, c, s.ldc);
-      if (0 == e) { note_launch(8 == s.typesize ? "rocblas_dgemm" : "rocblas_sgemm"); settle(a, b, c); return EXIT_SUCCESS; }
+      if (0 == e) { note_launch(8 == s.typesize ? "rocblas_dgemm" : "rocblas_sgemm"); if (0 != visible) (void)stream_sync(); return EXIT_SUCCESS; }
     }
     s.a = a; s.b = b; s.c = c;
-    return 0 == run_smm(s) ? EXIT_SUCCESS : EXIT_FAILURE;
+    return 0 == run_smm(s, visible) ? EXIT_SUCCESS : EXIT_FAILURE;
   }
   const int ts = s.typesize;
   const size_t ea = span_a(s), eb = span_b(s), ec = span_c(s);

@@ -1,13 +1,15 @@
 /* Per-call cost of a dispatched kernel on device operands (the reference's canonical usage, samples/smm/specialized.cpp):
- * calls/s of kernel(a_i, b_i, c_i) issued back to back, then one synchronisation.
+ * calls/s of kernel(a_i, b_i, c_i) issued back to back, then one synchronisation. Default: a launch per call (stream order is
+ * call order whatever the caller queues in between); LIBXSMM_AMD_DEFER=1 or libxsmm_amd_defer_begin/end: recorded into bursts.
+ * usage: bench_calls [m n k [calls]]
  * Build: gcc -O2 -I include tools/bench_calls.c -o /tmp/bench_calls -L libxsmm-1_amd/lib -lxsmm -Wl,-rpath,$PWD/libxsmm-1_amd/lib */
 #include <libxsmm.h>
 #include <stdio.h>
 #include <stdlib.h>
 
-int main(void)
+int main(int argc, char* argv[])
 {
-  const int m = 23, n = 23, k = 23, s = 20000;
+  const int m = (1 < argc ? atoi(argv[1]) : 23), n = (2 < argc ? atoi(argv[2]) : m), k = (3 < argc ? atoi(argv[3]) : m), s = (4 < argc ? atoi(argv[4]) : 20000);
   const size_t asz = (size_t)m * k, bsz = (size_t)k * n, csz = (size_t)m * n;
   double *a, *b, *c;
   libxsmm_dmmfunction kernel;
@@ -26,8 +28,8 @@ int main(void)
     for (i = 0; i < s; ++i) kernel(a + i * asz, b + i * bsz, c + i * csz);
     dt = libxsmm_timer_duration(t0, libxsmm_timer_tick());
     libxsmm_amd_synchronize();
-    printf("%d calls issued in %.1f ms: %.2f us per call (%.1f ms until the GPU is done)\n", s, dt * 1e3, dt * 1e6 / s,
-      libxsmm_timer_duration(t0, libxsmm_timer_tick()) * 1e3);
+    printf("%dx%dx%d fp64, %d calls issued in %.1f ms: %.2f us per call (%.1f ms until the GPU is done)%s\n", m, n, k, s, dt * 1e3, dt * 1e6 / s,
+      libxsmm_timer_duration(t0, libxsmm_timer_tick()) * 1e3, libxsmm_amd_defer_active() ? " [recorded into bursts]" : " [a launch per call]");
   }
   libxsmm_amd_device_free(a); libxsmm_amd_device_free(b); libxsmm_amd_device_free(c);
   libxsmm_finalize();

@@ -195,8 +195,9 @@ void smm_generic_kernel(DevAddr ad, int M, int N, int K, int lda, int ldb, int l
 // counter, out[2], which atomicInc wraps back to zero) adds the pairs up and writes the totals.
 // (bid, nblocks: this block's index among the blocks that inspect this batch)
 template<typename T>
-__device__ __forceinline__ void c_order_body(const DevAddr& ad, long long batch, int* out, unsigned bid, unsigned nblocks)
-{
+__device__ __forceinline__ void c_order_body(const DevAddr& ad, long long batch, int* out, unsigned bid, unsigned nblocks, int peers)
+{ // peers: batches that run side by side with this one in one launch (out[3]: the run kernels decide with it whether this batch's few
+  // long runs have to be cut into segments to fill the chip)
   __shared__ int red[2][4];
   __shared__ bool last;
   int eq = 0, dec = 0;
@@ -230,25 +231,26 @@ __device__ __forceinline__ void c_order_body(const DevAddr& ad, long long batch,
   if (0 == threadIdx.x) {
     out[0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
     out[1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    out[3] = peers;
   }
 }
 
 template<typename T>
 __global__ __launch_bounds__(256) void c_order_kernel(DevAddr ad, long long batch, int* out)
 {
-  c_order_body<T>(ad, batch, out, blockIdx.x, gridDim.x);
+  c_order_body<T>(ad, batch, out, blockIdx.x, gridDim.x, 1);
 }
 
 // the same for up to ORDER_GROUPS batches in one launch (one verdict slot each): CP2K-style calls with a batch per shape
 constexpr int ORDER_GROUPS = 32, ORDER_GROUP_BLOCKS = 16;
 struct OrderGroup { DevAddr ad; long long batch; int* out; };
-struct OrderGroups { OrderGroup g[ORDER_GROUPS]; };
+struct OrderGroups { OrderGroup g[ORDER_GROUPS]; int peers; };
 static_assert(sizeof(OrderGroups) <= 4096, "passed by value");
 template<typename T>
 __global__ __launch_bounds__(256) void c_order_groups_kernel(OrderGroups tab)
 {
   const unsigned g = blockIdx.x / ORDER_GROUP_BLOCKS;
-  c_order_body<T>(tab.g[g].ad, tab.g[g].batch, tab.g[g].out, blockIdx.x % ORDER_GROUP_BLOCKS, ORDER_GROUP_BLOCKS);
+  c_order_body<T>(tab.g[g].ad, tab.g[g].batch, tab.g[g].out, blockIdx.x % ORDER_GROUP_BLOCKS, ORDER_GROUP_BLOCKS, tab.peers);
 }
 
 template<typename T, int TM, int TGM, bool GENERAL>
@@ -357,6 +359,7 @@ int launch_c_order_check_groups(const SmmBatch* groups, int ngroups, void* strea
     SmmBatch s = groups[g]; s.sync = SYNC_NONE; // (make_addr: no flags pointer needed here)
     tab.g[g].ad = make_addr(s); tab.g[g].batch = s.batch; tab.g[g].out = const_cast<int*>(groups[g].devflags);
   }
+  tab.peers = ngroups;
   hipStream_t st = (hipStream_t)stream;
   if (8 == groups[0].typesize) hipLaunchKernelGGL((c_order_groups_kernel<double>), dim3((unsigned)(ngroups * ORDER_GROUP_BLOCKS)), dim3(256), 0, st, tab);
   else hipLaunchKernelGGL((c_order_groups_kernel<float>), dim3((unsigned)(ngroups * ORDER_GROUP_BLOCKS)), dim3(256), 0, st, tab);

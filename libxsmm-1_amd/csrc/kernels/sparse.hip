@@ -591,8 +591,13 @@ typedef float spm_f32x4 __attribute__((ext_vector_type(4)));
 #else
 # define SPM_BARRIER() spw_lds_barrier()
 #endif
-// word offset of column k inside a row of the blocked dense slice: (k >> 2) * 64 + (k & 3)
-__device__ __forceinline__ int spm_word(unsigned col) { return (int)(((col >> 2) << 6) | (col & 3)); }
+// Place of column k inside a row's words of the blocked dense slice: block (k >> 2) * 64, and inside the block the word
+// (4 * (row & 15) + (k & 3) + 8 * ((k >> 2) & 3)) mod 64 -- the words of a block are rotated by its index. A block is still exactly one
+// operand fetch of a wave (the fetch applies the same rotation), but the scatter of a row's entries -- sixteen lanes, columns in
+// ascending order -- now spreads over sixteen banks by (k mod 16) instead of four by (k mod 4): ds_write_b32 is served 32 lanes (two
+// rows) at a time over 32 banks, and the two rows' bank sets stay disjoint. Packed: block offset | rotation-and-(k & 3) part (< 64).
+__device__ __forceinline__ int spm_word(unsigned col) { return (int)(((col >> 2) << 6) | ((col & 3) + 8 * ((col >> 2) & 3))); }
+__device__ __forceinline__ int spm_place(int packed, int r15x4) { return (packed & ~63) + ((r15x4 + (packed & 63)) & 63); }
 
 // FULL: M == K == 64 (the whole geometry is then known at compile time: N = 16 * NT on this path anyway)
 template<int NB, int NT, bool FULL>
@@ -722,10 +727,10 @@ void spmdm_compute_mfma_kernel(long long batch, int M_arg, int K_arg, float beta
 #pragma unroll
         for (int ps = 2 * half; ps < 2 * half + 2; ++ps) {
           const int r = 16 * ps + (t >> 4);
-          float* const row = As + (((r >> 4) * 16) << 6) + ((r & 15) << 2); // + (k >> 2) * 64 + (k & 3)
+          float* const row = As + (((r >> 4) * 16) << 6); // + the entry's place among the row's words (spm_place)
 #pragma unroll
           for (int it = 0; it < 4; ++it) {
-            float* const dst = (pb0[ps] + 16 * it < cnt[ps]) ? (row + __float_as_int(ent[ps & 1][it].x)) : spare;
+            float* const dst = (pb0[ps] + 16 * it < cnt[ps]) ? (row + spm_place(__float_as_int(ent[ps & 1][it].x), (r & 15) << 2)) : spare;
             *dst = ent[ps & 1][it].y;
           }
         }
@@ -735,10 +740,10 @@ void spmdm_compute_mfma_kernel(long long batch, int M_arg, int K_arg, float beta
         const float* const va = values + item * cap;
         for (int r = t >> 4; r < M; r += 16) {
           const int p1 = ris[r + 1];
-          float* const row = As + (((r >> 4) * 16) << 6) + ((r & 15) << 2);
+          float* const row = As + (((r >> 4) * 16) << 6);
           int p = (int)ris[r] + q;
           if (p < SPM_META) p += ((SPM_META - p + 15) >> 4) << 4;
-          for (; p < p1; p += 16) { const int col = ci[p]; row[((col >> 2) << 6) + (col & 3)] = va[p]; }
+          for (; p < p1; p += 16) row[spm_place(spm_word(ci[p]), (r & 15) << 2)] = va[p];
         }
       }
     }
@@ -767,9 +772,10 @@ void spmdm_compute_mfma_kernel(long long batch, int M_arg, int K_arg, float beta
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[nt] = beta * acc[nt];
       }
-      const float* const pa = As + ((wave * 16) << 6) + 4 * i + kq;  // + s * 64
+      const float* const pa = As + ((wave * 16) << 6);               // + s * 64 + the lane's word of block s (rotated by 8 * (s & 3))
+      const int aw = 4 * i + kq;
       const float* const pb = Bs + 16 * kq + i;                      // + (s * NT + nt) * 64
-      float bop = pa[0], aop[NT];
+      float bop = pa[aw], aop[NT];
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) aop[nt] = pb[nt << 6];
 #pragma unroll
@@ -778,7 +784,7 @@ void spmdm_compute_mfma_kernel(long long batch, int M_arg, int K_arg, float beta
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acur[nt] = aop[nt];
         if (s + 1 < ksteps) { // operands of the next step travel during this step's matrix instructions
-          bop = pa[(s + 1) << 6];
+          bop = pa[((s + 1) << 6) + ((aw + 8 * ((s + 1) & 3)) & 63)];
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) aop[nt] = pb[((s + 1) * NT + nt) << 6];
         }
@@ -822,11 +828,9 @@ void spmdm_compute_mfma_kernel(long long batch, int M_arg, int K_arg, float beta
 // one per lane and handed round with v_readlane -- 7 cycles per value with a run-time lane select, 2.9 with an immediate --
 // 0.141 ms against 0.123 ms for the broadcast reads; the B panel brought in by global_load_lds into a second buffer
 // (one barrier per column block, no ds_write) 0.163 ms; eight waves per tile 0.167 ms.)
-constexpr int SPT_BK = 64, SPT_TN = 256, SPT_TM = 64, SPT_CAP = 1536, SPT_WAVES = 16, SPT_THREADS = 64 * SPT_WAVES;
-constexpr int SPT_RW = SPT_TM / SPT_WAVES;                        // rows per wave
-constexpr int SPT_NB = SPT_BK * SPT_TN / 4 / SPT_THREADS;         // 16-byte pieces of the B panel per thread
-constexpr size_t SPT_LDS = (size_t)SPT_BK * SPT_TN * 4 + (size_t)SPT_CAP * 8 + 160;
-static_assert(2 * SPT_THREADS >= SPT_CAP, "one pair of entries per thread covers a window");
+constexpr int SPT_BK = 64, SPT_TN = 256, SPT_CAP_MAX = 1536;
+constexpr int SPT_RW = 4;                                         // rows per wave: a tile has 4 * WAVES rows
+constexpr size_t SPT_LDS = (size_t)SPT_BK * SPT_TN * 4 + (size_t)SPT_CAP_MAX * 8 + 160;
 
 // entries [0, cnt) of one row (row_meta: wave-uniform) folded into the row's accumulators, in order
 __device__ __forceinline__ void spt_row(const float2* __restrict__ row_meta, int cnt, const float* __restrict__ brow, sp_f32x4& acc)
@@ -841,13 +845,18 @@ __device__ __forceinline__ void spt_row(const float2* __restrict__ row_meta, int
 }
 
 // VEC: N % 4 == 0 (K % 4 == 0 for a transposed B) and 16-byte aligned B and C: 16-byte global accesses
-template<bool VEC, bool TRANSB>
-__global__ __launch_bounds__(SPT_THREADS)
+// WAVES: 16 (a 64-row tile) or 4 (a 16-row tile, for calls that cover few tiles: a block call of the reference's per-block interface
+// is 64 tiles of 64 rows -- a quarter of the CUs -- but 256 tiles of 16 rows; the column panel of B is then staged four times as often,
+// out of the L2 of the XCD that the panel's tiles share)
+template<bool VEC, bool TRANSB, int WAVES>
+__global__ __launch_bounds__(64 * WAVES)
 void spmdm_tiled_kernel(int M, int N, int K, int bm, int mb_count, int kb_count, int transc, float beta,
                         const uint16_t* __restrict__ rowidx, const uint16_t* __restrict__ colidx, const float* __restrict__ values,
                         long long rstride, long long cap, const float* __restrict__ b, float* __restrict__ c,
                         int mb_begin, int mb_n, int n_begin, int n_end)
 {
+  constexpr int SPT_WAVES = WAVES, SPT_THREADS = 64 * WAVES, SPT_TM = SPT_RW * WAVES, SPT_NB = SPT_BK * SPT_TN / 4 / SPT_THREADS;
+  constexpr int SPT_CAP = (2 * SPT_THREADS < SPT_CAP_MAX) ? 2 * SPT_THREADS : SPT_CAP_MAX; // one pair of entries per thread covers a window
   extern __shared__ __align__(16) unsigned char spt_raw[];
   float* const Bs = reinterpret_cast<float*>(spt_raw);                               // [64][256]
   float2* const meta = reinterpret_cast<float2*>(Bs + SPT_BK * SPT_TN);              // [SPT_CAP] {bitcast(float offset of the B row), value}
@@ -1124,23 +1133,43 @@ int launch_spmdm_compute_tiled(int M, int N, int K, int bm, int bk, int mb, int 
   if (SPT_BK != bk || 0 != (cap & 1) || bm > 65535 / SPT_BK) return -1;
   if (0 >= mb_n || n_end <= n_begin) { *name = "spmdm_compute_noop"; return 0; }
   static const bool attr = []() {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spmdm_tiled_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SPT_LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spmdm_tiled_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SPT_LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spmdm_tiled_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SPT_LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spmdm_tiled_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SPT_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spmdm_tiled_kernel<true, false, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SPT_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spmdm_tiled_kernel<false, false, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SPT_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spmdm_tiled_kernel<true, true, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SPT_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spmdm_tiled_kernel<false, true, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SPT_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spmdm_tiled_kernel<true, false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SPT_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spmdm_tiled_kernel<false, false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SPT_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spmdm_tiled_kernel<true, true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SPT_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spmdm_tiled_kernel<false, true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SPT_LDS);
     return true;
   }();
   (void)attr;
-  const int tiles_per_mb = (bm + SPT_TM - 1) / SPT_TM;
-  const long long total = (long long)mb_n * tiles_per_mb * ((n_end - n_begin + SPT_TN - 1) / SPT_TN);
+  const long long col_tiles = (n_end - n_begin + SPT_TN - 1) / SPT_TN;
+  const long long total64 = (long long)mb_n * ((bm + 63) / 64) * col_tiles;
+  // Tiles of 16 rows, four waves each, for calls that cover few tiles of 64 rows (a per-block call of the reference's interface: 64 tiles)
+  // were measured and are NOT the default: 2048^3 at 15 %, four block calls 0.450 ms against 0.462 ms. A work-group's time is set by
+  // its walk over the 32 column blocks of A -- 3.4 us each, the round trip of the next block's B panel, one block ahead -- whatever the
+  // height of its tile and however many work-groups run beside it (all 256 tiles in one call: 0.131 ms). XSMM_SPMDM_TILE_ROWS=16: developer knob.
+  static const int rows_env = []() { const char* e = getenv("XSMM_SPMDM_TILE_ROWS"); return (nullptr != e && 0 != *e) ? atoi(e) : 0; }();
+  const bool small = (16 == rows_env);
+  (void)total64;
+  const int tile_rows = small ? 16 : 64;
+  const int tiles_per_mb = (bm + tile_rows - 1) / tile_rows;
+  const long long total = (long long)mb_n * tiles_per_mb * col_tiles;
   const unsigned grid = (unsigned)(8 * ((total + 7) / 8));
   const uintptr_t bits = reinterpret_cast<uintptr_t>(b) | (0 == transc ? reinterpret_cast<uintptr_t>(c) : 0); // (a transposed C moves element by element anyway)
   const bool vec = (0 == (bits & 15)) && 0 == (N & 3) && 0 == (n_begin & 3) && (0 == transb || 0 == (K & 3));
-  *name = "spmdm_compute_tiled";
-#define XSMM_SPT(V, TB) hipLaunchKernelGGL((spmdm_tiled_kernel<V, TB>), dim3(grid), dim3(SPT_THREADS), SPT_LDS, (hipStream_t)stream, \
+  *name = small ? "spmdm_compute_tiled16" : "spmdm_compute_tiled";
+#define XSMM_SPT(V, TB, W) hipLaunchKernelGGL((spmdm_tiled_kernel<V, TB, W>), dim3(grid), dim3(64 * W), SPT_LDS, (hipStream_t)stream, \
       M, N, K, bm, mb, kb, transc, beta, rowidx, colidx, values, rowidx_stride, cap, b, c, mb_begin, mb_n, n_begin, n_end)
-  if (vec) { if (0 == transb) XSMM_SPT(true, false); else XSMM_SPT(true, true); }
-  else { if (0 == transb) XSMM_SPT(false, false); else XSMM_SPT(false, true); }
+  if (small) {
+    if (vec) { if (0 == transb) XSMM_SPT(true, false, 4); else XSMM_SPT(true, true, 4); }
+    else { if (0 == transb) XSMM_SPT(false, false, 4); else XSMM_SPT(false, true, 4); }
+  }
+  else {
+    if (vec) { if (0 == transb) XSMM_SPT(true, false, 16); else XSMM_SPT(true, true, 16); }
+    else { if (0 == transb) XSMM_SPT(false, false, 16); else XSMM_SPT(false, true, 16); }
+  }
 #undef XSMM_SPT
   return (int)hipGetLastError();
 }

@@ -315,8 +315,11 @@ void* scratch(int slot, size_t bytes)
   // Launches are asynchronous: whatever was queued on the stream that used this buffer last may still be reading it.
   // (Scratch only serves the staging of host-resident operands -- the compatibility path -- so the wait costs nothing
   // on the device-resident path.)
-  if (s.used) (void)hipStreamSynchronize((hipStream_t)s.stream);
-  s.stream = device().stream; s.used = true;
+  // (a new user on the same stream is ordered behind the old one by the stream itself; only another stream, or a buffer that has to
+  // grow -- hipFree does wait, but on everything -- needs the wait)
+  void* const now = device().stream;
+  if (s.used && (s.stream != now || s.size < bytes)) (void)hipStreamSynchronize((hipStream_t)s.stream);
+  s.stream = now; s.used = true;
   if (s.size < bytes) {
     if (nullptr != s.ptr) (void)hipFree(s.ptr);
     s.ptr = nullptr; s.size = 0;

@@ -273,16 +273,19 @@ int copy_window(float* dev, float* host, int ld, int r0, int nr, int c0, int nc,
 // bfloat16 operands (reference: libxsmm_bfloat16 = the upper half of an IEEE float, src/libxsmm_spmdm_begin.h:69-75) are
 // widened to float in a device scratch buffer; from there on the fp32 kernels run unchanged -- exactly what the reference
 // templates do element by element (EXPAND_BFLOAT16 before the compare / the copy into scratch_B).
-const float* widen_bf16(const libxsmm_bfloat16* p, size_t elems, int slot_raw, int slot_wide, bool* ok)
+// (first, count): the elements a block call needs when they are one contiguous piece of the matrix -- rows of A, rows of a transposed
+// B -- else the whole matrix; the scratch images keep the shape of the whole matrix, so the kernels address them as usual
+const float* widen_bf16(const libxsmm_bfloat16* p, size_t elems, int slot_raw, int slot_wide, bool* ok, size_t first = 0, size_t count = 0)
 {
+  if (0 == count || first + count > elems) { first = 0; count = elems; }
   const libxsmm_bfloat16* src = p;
   if (!is_device_ptr(p)) {
-    void* d = scratch(slot_raw, elems * sizeof(libxsmm_bfloat16));
-    if (nullptr == d || 0 != h2d(d, p, elems * sizeof(libxsmm_bfloat16))) { *ok = false; return nullptr; }
-    src = static_cast<const libxsmm_bfloat16*>(d);
+    char* d = static_cast<char*>(scratch(slot_raw, elems * sizeof(libxsmm_bfloat16)));
+    if (nullptr == d || 0 != h2d(d + first * sizeof(libxsmm_bfloat16), p + first, count * sizeof(libxsmm_bfloat16))) { *ok = false; return nullptr; }
+    src = reinterpret_cast<const libxsmm_bfloat16*>(d);
   }
   float* const wide = static_cast<float*>(scratch(slot_wide, elems * sizeof(float)));
-  if (nullptr == wide || 0 != launch_bf16_widen(src, wide, (long long)elems, device().stream)) { *ok = false; return nullptr; }
+  if (nullptr == wide || 0 != launch_bf16_widen(src + first, wide + first, (long long)count, device().stream)) { *ok = false; return nullptr; }
   note_launch("bf16_widen");
   return wide;
 }
@@ -333,35 +336,40 @@ int spmdm_compute_tiles(const libxsmm_spmdm_handle* handle, int tb, int tc, floa
 bool is_trans(char t) { return 'T' == t || 't' == t; }
 
 // one create call: row block mb0 (mbn == 1) or all of them; a: float (widened already) or the caller's matrix
-void spmdm_create(const libxsmm_spmdm_handle* handle, char transa, const float* a, int mb0, int mbn, bool staged_input)
+// (staged_input: `a` is the engine's widened copy; sync_after: the caller's matrix came from host memory -- the call returns when it is
+// done with, as an unchanged CPU caller expects; device inputs stay asynchronous: the scratch copies are reused in stream order)
+// returns 0, or the error of the failed allocation / copy / launch
+int spmdm_create(const libxsmm_spmdm_handle* handle, char transa, const float* a, int mb0, int mbn, bool staged_input, bool sync_after = true)
 {
   const int ta = is_trans(transa) ? 1 : 0;
   const float* da = a;
   if (!staged_input && !is_device_ptr(a)) { // host matrix: only the rows of these blocks travel
     float* const d = static_cast<float*>(scratch(3, (size_t)handle->m * handle->k * sizeof(float)));
-    if (nullptr == d) return;
+    if (nullptr == d) return -1;
     const int r0 = mb0 * handle->bm, nr = LIBXSMM_MIN(mbn * handle->bm, handle->m - r0);
     const int e = ta ? copy_window(d, const_cast<float*>(a), handle->m, 0, handle->k, r0, nr, true) : copy_window(d, const_cast<float*>(a), handle->k, r0, nr, 0, handle->k, true);
-    if (0 != e) return;
+    if (0 != e) return e;
     da = d; staged_input = true;
   }
-  if (0 != spmdm_create_slices(handle, ta, da, mb0, mbn)) return;
-  if (staged_input) (void)stream_sync(); // the staging buffer is reused by the next call
+  const int e = spmdm_create_slices(handle, ta, da, mb0, mbn);
+  if (0 != e) return e;
+  if (staged_input) { if (sync_after) return stream_sync(); }
   else settle(a);
+  return 0;
 }
 
 // one compute call: row blocks [mb0, mb0 + mbn) x columns [n0, n1) of C
-void spmdm_compute(const libxsmm_spmdm_handle* handle, char transb, const float* b, bool staged_b, char transc, float beta, float* c,
-                   int mb0, int mbn, int n0, int n1)
+int spmdm_compute(const libxsmm_spmdm_handle* handle, char transb, const float* b, bool staged_b, char transc, float beta, float* c,
+                  int mb0, int mbn, int n0, int n1, bool sync_after = true)
 {
   const int tb = is_trans(transb) ? 1 : 0, tc = is_trans(transc) ? 1 : 0;
   const float* db = b;
   if (!staged_b && !is_device_ptr(b)) {
     float* const d = static_cast<float*>(scratch(4, (size_t)handle->k * handle->n * sizeof(float)));
-    if (nullptr == d) return;
+    if (nullptr == d) return -1;
     // columns [n0, n1) of B (all k): B[k][n] resp. rows [n0, n1) of B[n][k]
     const int e = tb ? copy_window(d, const_cast<float*>(b), handle->k, n0, n1 - n0, 0, handle->k, true) : copy_window(d, const_cast<float*>(b), handle->n, 0, handle->k, n0, n1 - n0, true);
-    if (0 != e) return;
+    if (0 != e) return e;
     db = d; staged_b = true;
   }
   const int m0 = mb0 * handle->bm, m1 = LIBXSMM_MIN(m0 + mbn * handle->bm, handle->m);
@@ -369,19 +377,22 @@ void spmdm_compute(const libxsmm_spmdm_handle* handle, char transb, const float*
   const bool c_host = !is_device_ptr(c);
   if (c_host) { // the tile travels in (beta != 0) and out; nothing else of C is touched
     dc = static_cast<float*>(scratch(5, (size_t)handle->m * handle->n * sizeof(float)));
-    if (nullptr == dc) return;
+    if (nullptr == dc) return -1;
     if (0.f != beta) {
       const int e = tc ? copy_window(dc, c, handle->m, n0, n1 - n0, m0, m1 - m0, true) : copy_window(dc, c, handle->n, m0, m1 - m0, n0, n1 - n0, true);
-      if (0 != e) return;
+      if (0 != e) return e;
     }
   }
-  if (0 != spmdm_compute_tiles(handle, tb, tc, beta, db, dc, mb0, mbn, n0, n1)) return;
+  const int e = spmdm_compute_tiles(handle, tb, tc, beta, db, dc, mb0, mbn, n0, n1);
+  if (0 != e) return e;
   if (c_host) {
-    (void)(tc ? copy_window(dc, c, handle->m, n0, n1 - n0, m0, m1 - m0, false) : copy_window(dc, c, handle->n, m0, m1 - m0, n0, n1 - n0, false));
-    (void)stream_sync();
+    const int e2 = tc ? copy_window(dc, c, handle->m, n0, n1 - n0, m0, m1 - m0, false) : copy_window(dc, c, handle->n, m0, m1 - m0, n0, n1 - n0, false);
+    const int e3 = stream_sync();
+    return 0 != e2 ? e2 : e3;
   }
-  else if (staged_b) (void)stream_sync(); // staged inputs are reused by the next call
+  if (staged_b) { if (sync_after) return stream_sync(); } // (host inputs: done with on return; device inputs: stream order)
   else settle(b, c);
+  return 0;
 }
 
 bool spmdm_block_ok(const libxsmm_spmdm_handle* handle, int block_id, int nblocks, const char* what)
@@ -412,9 +423,12 @@ LIBXSMM_API void libxsmm_spmdm_createSparseSlice_bfloat16_thread(const libxsmm_s
   if (!device_ready()) { fail_no_device("libxsmm_spmdm_createSparseSlice_bfloat16_thread"); return; }
   if (!spmdm_block_ok(handle, block_id, handle->mb, "libxsmm_spmdm_createSparseSlice_bfloat16_thread")) return;
   bool ok = true;
-  const float* const da = widen_bf16(a, (size_t)handle->m * handle->k, 6, 3, &ok);
+  // only the rows of this block are widened (A as stored: they are contiguous; a transposed A: the whole matrix)
+  const size_t r0 = (size_t)block_id * handle->bm, nr = (size_t)LIBXSMM_MIN(handle->bm, handle->m - (int)r0);
+  const bool rows_contiguous = !is_trans(transa);
+  const float* const da = widen_bf16(a, (size_t)handle->m * handle->k, 6, 3, &ok, rows_contiguous ? r0 * handle->k : 0, rows_contiguous ? nr * handle->k : 0);
   if (!ok) return;
-  spmdm_create(handle, transa, da, block_id, 1, true);
+  spmdm_create(handle, transa, da, block_id, 1, true, !is_device_ptr(a));
 }
 
 LIBXSMM_API void libxsmm_spmdm_compute_fp32_thread(const libxsmm_spmdm_handle* handle, char transa, char transb,
@@ -440,10 +454,13 @@ LIBXSMM_API void libxsmm_spmdm_compute_bfloat16_thread(const libxsmm_spmdm_handl
   if (!device_ready()) { fail_no_device("libxsmm_spmdm_compute_bfloat16_thread"); return; }
   if (!spmdm_block_ok(handle, block_id, handle->mb * handle->nb, "libxsmm_spmdm_compute_bfloat16_thread")) return;
   bool ok = true;
-  const float* const db = widen_bf16(b, (size_t)handle->k * handle->n, 6, 4, &ok);
-  if (!ok) return;
   const int mb = block_id / handle->nb, nb = block_id % handle->nb;
-  spmdm_compute(handle, transb, db, true, transc, (float)(*beta), c, mb, 1, nb * handle->bn, LIBXSMM_MIN((nb + 1) * handle->bn, handle->n));
+  const int n0 = nb * handle->bn, n1 = LIBXSMM_MIN((nb + 1) * handle->bn, handle->n);
+  // only the columns [n0, n1) of B are widened where they are one piece (a transposed B: rows of B^T; one column block: all of B)
+  const bool piece = is_trans(transb);
+  const float* const db = widen_bf16(b, (size_t)handle->k * handle->n, 6, 4, &ok, piece ? (size_t)n0 * handle->k : 0, piece ? (size_t)(n1 - n0) * handle->k : 0);
+  if (!ok) return;
+  spmdm_compute(handle, transb, db, true, transc, (float)(*beta), c, mb, 1, n0, n1, !is_device_ptr(b));
 }
 
 // ---- the whole problem in one call (extension) -------------------------------------------------------------------------
@@ -454,8 +471,7 @@ LIBXSMM_API int libxsmm_amd_spmdm_createSparseSlice_all(const libxsmm_spmdm_hand
 {
   if (nullptr == handle || nullptr == a || nullptr == libxsmm_output_csr_a || nullptr == handle->base_ptr_scratch_A) return EXIT_FAILURE;
   if (!device_ready()) { fail_no_device("libxsmm_amd_spmdm_createSparseSlice_all"); return EXIT_FAILURE; }
-  spmdm_create(handle, transa, a, 0, handle->mb, false);
-  return EXIT_SUCCESS;
+  return 0 == spmdm_create(handle, transa, a, 0, handle->mb, false) ? EXIT_SUCCESS : EXIT_FAILURE;
 }
 
 LIBXSMM_API int libxsmm_amd_spmdm_compute_all(const libxsmm_spmdm_handle* handle, char transa, char transb, const float* alpha,
@@ -464,8 +480,7 @@ LIBXSMM_API int libxsmm_amd_spmdm_compute_all(const libxsmm_spmdm_handle* handle
   (void)transa; (void)alpha;
   if (nullptr == handle || nullptr == a_sparse || nullptr == b || nullptr == c || nullptr == beta) return EXIT_FAILURE;
   if (!device_ready()) { fail_no_device("libxsmm_amd_spmdm_compute_all"); return EXIT_FAILURE; }
-  spmdm_compute(handle, transb, b, false, transc, *beta, c, 0, handle->mb, 0, handle->n);
-  return EXIT_SUCCESS;
+  return 0 == spmdm_compute(handle, transb, b, false, transc, *beta, c, 0, handle->mb, 0, handle->n) ? EXIT_SUCCESS : EXIT_FAILURE;
 }
 
 LIBXSMM_API int libxsmm_amd_spmdm_createSparseSlice_bfloat16_all(const libxsmm_spmdm_handle* handle, char transa, const libxsmm_bfloat16* a,
@@ -476,8 +491,7 @@ LIBXSMM_API int libxsmm_amd_spmdm_createSparseSlice_bfloat16_all(const libxsmm_s
   bool ok = true;
   const float* const da = widen_bf16(a, (size_t)handle->m * handle->k, 6, 3, &ok);
   if (!ok) return EXIT_FAILURE;
-  spmdm_create(handle, transa, da, 0, handle->mb, true);
-  return EXIT_SUCCESS;
+  return 0 == spmdm_create(handle, transa, da, 0, handle->mb, true, !is_device_ptr(a)) ? EXIT_SUCCESS : EXIT_FAILURE;
 }
 
 LIBXSMM_API int libxsmm_amd_spmdm_compute_bfloat16_all(const libxsmm_spmdm_handle* handle, char transa, char transb, const libxsmm_bfloat16* alpha,
@@ -489,8 +503,7 @@ LIBXSMM_API int libxsmm_amd_spmdm_compute_bfloat16_all(const libxsmm_spmdm_handl
   bool ok = true;
   const float* const db = widen_bf16(b, (size_t)handle->k * handle->n, 6, 4, &ok);
   if (!ok) return EXIT_FAILURE;
-  spmdm_compute(handle, transb, db, true, transc, (float)(*beta), c, 0, handle->mb, 0, handle->n);
-  return EXIT_SUCCESS;
+  return 0 == spmdm_compute(handle, transb, db, true, transc, (float)(*beta), c, 0, handle->mb, 0, handle->n, !is_device_ptr(b)) ? EXIT_SUCCESS : EXIT_FAILURE;
 }
 
 // ---------------------------------------------------------------------------------------------------------------

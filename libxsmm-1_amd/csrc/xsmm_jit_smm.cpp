@@ -692,15 +692,16 @@ extern "C" __global__ __launch_bounds__(64 * XWAVES) void xsmm_smm_op(DevAddr ad
 #else
   T rc[NLC][VC];
 #endif
-  load_pairs<VPA, NPA, PA>(resolve<const unsigned>(ad.a, ad.ia, ad.sa, ad, w), lane, ra);
-  load_pairs<VPB, NPB, PB>(resolve<const unsigned>(ad.b, ad.ib, ad.sb, ad, w), lane, rb);
+  // (the batch addresses 16-bit operands in elements of 16 bits -- strides, index arrays -- whichever the addressing mode)
+  load_pairs<VPA, NPA, PA>((const unsigned*)resolve<const unsigned short>(ad.a, ad.ia, ad.sa, ad, w), lane, ra);
+  load_pairs<VPB, NPB, PB>((const unsigned*)resolve<const unsigned short>(ad.b, ad.ib, ad.sb, ad, w), lane, rb);
 #else
   T ra[NLA][VA], rb[NLB][VB], rc[NLC][VC];
   load_flat<VA, NLA, AE>(resolve<const T>(ad.a, ad.ia, ad.sa, ad, w), lane, ra);
   load_flat<VB, NLB, BE>(resolve<const T>(ad.b, ad.ib, ad.sb, ad, w), lane, rb);
 #endif
 #if (2 == XLOWP)
-  if (!XBETA0) load_pairs<VPC, NPC, PC>(resolve<const unsigned>(ad.c, ad.ic, ad.sc, ad, w), lane, rc);
+  if (!XBETA0) load_pairs<VPC, NPC, PC>((const unsigned*)resolve<const unsigned short>(ad.c, ad.ic, ad.sc, ad, w), lane, rc);
 #else
   if (!XBETA0) load_flat<VC, NLC, CE>(resolve<const T>(ad.c, ad.ic, ad.sc, ad, w), lane, rc);
 #endif
@@ -709,7 +710,7 @@ extern "C" __global__ __launch_bounds__(64 * XWAVES) void xsmm_smm_op(DevAddr ad
 #endif
   for (long long item = w; item < batch; item += W) {
 #if (2 == XLOWP)
-    unsigned* const pc = resolve<unsigned>(ad.c, ad.ic, ad.sc, ad, item);
+    unsigned* const pc = (unsigned*)resolve<unsigned short>(ad.c, ad.ic, ad.sc, ad, item);
 #else
     T* const pc = resolve<T>(ad.c, ad.ic, ad.sc, ad, item);
     if (XDEFER) {
@@ -731,14 +732,14 @@ extern "C" __global__ __launch_bounds__(64 * XWAVES) void xsmm_smm_op(DevAddr ad
     const long long next = item + W;
     if (next < batch) {
 #if XLOWP
-      load_pairs<VPA, NPA, PA>(resolve<const unsigned>(ad.a, ad.ia, ad.sa, ad, next), lane, ra);
-      load_pairs<VPB, NPB, PB>(resolve<const unsigned>(ad.b, ad.ib, ad.sb, ad, next), lane, rb);
+      load_pairs<VPA, NPA, PA>((const unsigned*)resolve<const unsigned short>(ad.a, ad.ia, ad.sa, ad, next), lane, ra);
+      load_pairs<VPB, NPB, PB>((const unsigned*)resolve<const unsigned short>(ad.b, ad.ib, ad.sb, ad, next), lane, rb);
 #else
       load_flat<VA, NLA, AE>(resolve<const T>(ad.a, ad.ia, ad.sa, ad, next), lane, ra);
       load_flat<VB, NLB, BE>(resolve<const T>(ad.b, ad.ib, ad.sb, ad, next), lane, rb);
 #endif
 #if (2 == XLOWP)
-      if (!XBETA0) load_pairs<VPC, NPC, PC>(resolve<const unsigned>(ad.c, ad.ic, ad.sc, ad, next), lane, rc);
+      if (!XBETA0) load_pairs<VPC, NPC, PC>((const unsigned*)resolve<const unsigned short>(ad.c, ad.ic, ad.sc, ad, next), lane, rc);
 #else
       if (!XBETA0) load_flat<VC, NLC, CE>(resolve<const T>(ad.c, ad.ic, ad.sc, ad, next), lane, rc);
 #endif
@@ -836,6 +837,17 @@ constexpr int CA = (NCA + 63) / 64, CB = (NCB + 63) / 64, CC = (NCC + 63) / 64;
 __device__ __forceinline__ int clampi(int v, int hi) { return v < hi ? v : hi; }
 // row of C a lane's accumulator register r belongs to (the fp32 and fp64 instructions differ)
 #define XNROW(r) (F64 ? (lq + 4 * (r)) : (4 * lq + (r)))
+// what the batch's strides and index arrays count: elements of the operands' types (16-bit inputs, and a bf16 result, in 16-bit elements)
+#if XLOWP
+typedef unsigned short XOPI;
+#if (2 == XLOWP)
+typedef unsigned short XOPC;
+#else
+typedef T XOPC;
+#endif
+#else
+typedef T XOPI; typedef T XOPC;
+#endif
 
 #if (2 != XNSPLIT)
 extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(XWPE))) void xsmm_smm_op(DevAddr ad, long long batch, int runlen)
@@ -849,20 +861,20 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(X
   (void)runlen;
   UV ra[CA], rb[CB], rc[CC]; // (strides of the batch are in 32-bit words: the host halves those of 16-bit operands)
   auto load_ab = [&](long long item) {
-    const XGLOBAL UV* const pa = (const XGLOBAL UV*)resolve<const T>(ad.a, ad.ia, ad.sa, ad, item);
-    const XGLOBAL UV* const pb = (const XGLOBAL UV*)resolve<const T>(ad.b, ad.ib, ad.sb, ad, item);
+    const XGLOBAL UV* const pa = (const XGLOBAL UV*)resolve<const XOPI>(ad.a, ad.ia, ad.sa, ad, item);
+    const XGLOBAL UV* const pb = (const XGLOBAL UV*)resolve<const XOPI>(ad.b, ad.ib, ad.sb, ad, item);
 #pragma unroll
     for (int j = 0; j < CA; ++j) ra[j] = __builtin_nontemporal_load(pa + clampi(64 * j + lane, NCA - 1));
 #pragma unroll
     for (int j = 0; j < CB; ++j) rb[j] = __builtin_nontemporal_load(pb + clampi(64 * j + lane, NCB - 1));
   };
   auto load_c = [&](long long item) {
-    const XGLOBAL UV* const pc = (const XGLOBAL UV*)resolve<const T>(ad.c, ad.ic, ad.sc, ad, item);
+    const XGLOBAL UV* const pc = (const XGLOBAL UV*)resolve<const XOPC>(ad.c, ad.ic, ad.sc, ad, item);
 #pragma unroll
     for (int j = 0; j < CC; ++j) rc[j] = __builtin_nontemporal_load(pc + clampi(64 * j + lane, NCC - 1));
   };
   auto store_c = [&](long long item) { // the image of C -> memory, whole lines
-    XGLOBAL UV* const pc = (XGLOBAL UV*)resolve<T>(ad.c, ad.ic, ad.sc, ad, item);
+    XGLOBAL UV* const pc = (XGLOBAL UV*)resolve<XOPC>(ad.c, ad.ic, ad.sc, ad, item);
 #pragma unroll
     for (int j = 0; j < CC; ++j) {
       const int ch = clampi(64 * j + lane, NCC - 1);
@@ -1150,12 +1162,17 @@ typedef float ACC32 __attribute__((ext_vector_type(4)));
 typedef double ACC64 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ ACC32 xmfma(float a, float b, ACC32 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ ACC64 xmfma(double a, double b, ACC64 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
-constexpr int MI = (M + 15) / 16, NI = (N + 15) / 16, KS = (K + 3) / 4, KP4 = 4 * KS;
+// K goes through the registers and B's image in NCH chunks of KC (a multiple of four) -- one chunk up to K = 64; beyond that only the
+// streaming form (the run form keeps a whole product's fragments of A in flight)
+// (beyond 64 in chunks of at most 32: two chunk variants of fragments and address arithmetic alive at once cost registers)
+constexpr int NCH = (XSTREAM && K > 64) ? (K + 31) / 32 : 1;
+constexpr int KC = 4 * (((K + NCH - 1) / NCH + 3) / 4);
+constexpr int MI = (M + 15) / 16, NI = (N + 15) / 16, KS = KC / 4, KP4 = KC;
 // row stride of B's image: fp64 fragments are fetched sixteen lanes (one k, sixteen n) at a time -- an odd stride spreads them
 // over all bank pairs; fp32 fragments thirty-two lanes (two k) at a time -- a stride of 2 mod 4 keeps the two k apart as well
 constexpr int KSD = F64 ? (KP4 + 1) : (KP4 + 2);
 constexpr int BE = LDB * (N - 1) + K;                  // span of B in memory
-constexpr int NLB = (BE + 63) / 64;
+constexpr int NLB = (1 == NCH) ? (BE + 63) / 64 : (N * KC + 63) / 64; // one chunk: the flat span; several: N x KC elements per chunk
 constexpr int WAVE_LDS = ((N * KSD + 3) / 4) * 4;      // elements
 #define XNROW(r) (F64 ? (lq + 4 * (r)) : (4 * lq + (r)))
 __device__ __forceinline__ int clampi(int v, int hi) { return v < hi ? v : hi; }
@@ -1165,11 +1182,11 @@ __device__ __forceinline__ void xatomic_add(float* p, float v) { (void)__builtin
 
 const char* const SMM_JIT_MFMA_RUNS_KERNEL = R"XSMM(
 // fragment of A for k step ks, tile mi (rows beyond M repeat row M - 1: they only reach rows of C that are never stored)
-__device__ __forceinline__ T load_a_frag(const T* pa, int ks, int moff, int lq)
-{
-  const int k = 4 * ks + lq;
+__device__ __forceinline__ T load_a_frag(const T* pa, int ks, int moff, int lq, int k0 = 0)
+{ // (k0: first k of the chunk, a constant after unrolling)
+  const int k = k0 + 4 * ks + lq;
   const XGLOBAL T* const g = (const XGLOBAL T*)pa;
-  if (4 * ks + 3 < K) return __builtin_nontemporal_load(g + k * LDA + moff);
+  if (k0 + 4 * ks + 3 < K) return __builtin_nontemporal_load(g + k * LDA + moff);
   const T v = __builtin_nontemporal_load(g + clampi(k, K - 1) * LDA + moff); // (no divergent control flow around the load)
   return (k < K) ? v : -T(0);
 }
@@ -1185,6 +1202,26 @@ __device__ __forceinline__ void park_b(T* Bs, int lane, const T (&rb)[NLB])
   for (int j = 0; j < NLB; ++j) {
     const int e = 64 * j + lane, n = e / LDB, k = e - n * LDB;
     if (e < BE && k < K) Bs[n * KSD + k] = rb[j];
+  }
+}
+// chunk c of B (several chunks: K > 64): the KC x N window, lanes along k -- runs of KC elements of a column; k beyond K: +0
+__device__ __forceinline__ void load_b_chunk(const T* pb, int c, int lane, T (&rb)[NLB])
+{
+  const XGLOBAL T* const g = (const XGLOBAL T*)pb;
+  asm volatile("" : "+v"(lane)); // (the places are recomputed per chunk: hoisted out of the loop over the items they cost a register each)
+#pragma unroll
+  for (int j = 0; j < NLB; ++j) {
+    const int e = 64 * j + lane, n = e / KC, kk = e - n * KC, k = c * KC + kk;
+    const T v = __builtin_nontemporal_load(g + clampi(n, N - 1) * LDB + clampi(k, K - 1)); // (no control flow around the load)
+    rb[j] = (k < K) ? v : T(0);
+  }
+}
+__device__ __forceinline__ void park_b_chunk(T* Bs, int lane, const T (&rb)[NLB])
+{
+#pragma unroll
+  for (int j = 0; j < NLB; ++j) {
+    const int e = 64 * j + lane, n = e / KC, kk = e - n * KC;
+    if (e < N * KC) Bs[n * KSD + kk] = rb[j];
   }
 }
 __device__ __forceinline__ void acc_load(const T* pc, int l16, int lq, ACC (&acc)[NI][MI])
@@ -1228,7 +1265,7 @@ extern "C" __global__ __launch_bounds__(64 * XWAVES) void xsmm_smm_op(DevAddr ad
   T* const Bs = lds + wave * WAVE_LDS;
   const long long w = (long long)blockIdx.x * XWAVES + wave, W = (long long)gridDim.x * XWAVES;
   if (w >= batch) return;
-  if (KP4 > K) { // the padding of B's image (+0): written once, never parked over
+  if (1 == NCH && KP4 > K) { // the padding of B's image (+0): written once, never parked over (several chunks: the loads deliver it)
     for (int e = lane; e < N * (KP4 - K); e += 64) Bs[(e / (KP4 - K)) * KSD + K + e % (KP4 - K)] = T(0);
   }
   int moff[MI], boff[NI];
@@ -1239,15 +1276,14 @@ extern "C" __global__ __launch_bounds__(64 * XWAVES) void xsmm_smm_op(DevAddr ad
   T af[KS][MI], rb[NLB];
   ACC cn[NI][MI];
   T* pc = resolve<T>(ad.c, ad.ic, ad.sc, ad, w);
-  {
-    const T* const pa0 = resolve<const T>(ad.a, ad.ia, ad.sa, ad, w);
-    load_b_flat(resolve<const T>(ad.b, ad.ib, ad.sb, ad, w), lane, rb);
+  const T* pa_cur = resolve<const T>(ad.a, ad.ia, ad.sa, ad, w);
+  const T* pb_cur = resolve<const T>(ad.b, ad.ib, ad.sb, ad, w);
+  if (1 == NCH) load_b_flat(pb_cur, lane, rb); else load_b_chunk(pb_cur, 0, lane, rb);
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
+  for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) af[ks][mi] = load_a_frag(pa0, ks, moff[mi], lq);
-    if (!XBETA0) acc_load(pc, l16, lq, cn);
-  }
+    for (int mi = 0; mi < MI; ++mi) af[ks][mi] = load_a_frag(pa_cur, ks, moff[mi], lq);
+  if (!XBETA0) acc_load(pc, l16, lq, cn);
   for (long long item = w; item < batch; item += W) {
     T* const pc_cur = pc;
     ACC acc[NI][MI];
@@ -1255,27 +1291,37 @@ extern "C" __global__ __launch_bounds__(64 * XWAVES) void xsmm_smm_op(DevAddr ad
     for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = XBETA0 ? ACC{ 0, 0, 0, 0 } : cn[ni][mi];
-    park_b(Bs, lane, rb);
     // (no control flow around the loads: the last item of a wave fetches its own operands once more, never used)
     const long long next = (item + W < batch) ? (item + W) : item;
-    const T* const pa1 = resolve<const T>(ad.a, ad.ia, ad.sa, ad, next);
-    load_b_flat(resolve<const T>(ad.b, ad.ib, ad.sb, ad, next), lane, rb);
-    pc = resolve<T>(ad.c, ad.ic, ad.sc, ad, next);
-    if (!XBETA0) acc_load(pc, l16, lq, cn);
-    wave_lds_sync();
+    const T* const pa_next = resolve<const T>(ad.a, ad.ia, ad.sa, ad, next);
+    const T* const pb_next = resolve<const T>(ad.b, ad.ib, ad.sb, ad, next);
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      T bf[NI];
+    for (int c = 0; c < NCH; ++c) { // (unrolled: which chunk comes next, and where K ends, are constants)
+      if (1 == NCH) park_b(Bs, lane, rb); else park_b_chunk(Bs, lane, rb);
+      const bool last = (c + 1 == NCH);
+      const T* const pan = last ? pa_next : pa_cur;
+      const int cnext = last ? 0 : c + 1;
+      if (1 == NCH) load_b_flat(pb_next, lane, rb); else load_b_chunk(last ? pb_next : pb_cur, cnext, lane, rb);
+      if (last) {
+        pc = resolve<T>(ad.c, ad.ic, ad.sc, ad, next);
+        if (!XBETA0) acc_load(pc, l16, lq, cn);
+      }
+      wave_lds_sync();
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) bf[ni] = Bs[boff[ni] + 4 * ks];
+      for (int ks = 0; ks < KS; ++ks) {
+        T bf[NI];
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni)
+        for (int ni = 0; ni < NI; ++ni) bf[ni] = Bs[boff[ni] + 4 * ks];
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = xmfma(bf[ni], af[ks][mi], acc[ni][mi]);
+        for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) af[ks][mi] = load_a_frag(pa1, ks, moff[mi], lq);
+          for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = xmfma(bf[ni], af[ks][mi], acc[ni][mi]);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) af[ks][mi] = load_a_frag(pan, ks, moff[mi], lq, cnext * KC);
+      }
+      wave_lds_sync(); // (B's image is parked over next)
     }
-    wave_lds_sync(); // (B's image is parked over next)
+    pa_cur = pa_next; pb_cur = pb_next;
     acc_store(pc_cur, l16, lq, acc, false);
   }
 }
@@ -1422,12 +1468,13 @@ static int smm_mfma_wave_wpe(size_t lds, int typesize = 0, int m = 0, int n = 0,
 }
 
 // ---- the run form on the matrix cores (SMM_JIT_MFMA_RUNS_*): LDS bytes of a wave (mirrors the source); 0: shape not served
-static size_t smm_mfma_runs_lds(int typesize, int m, int n, int k, int ldb)
-{
-  if (m < 1 || n < 1 || k < 1 || m > 32 || n > 32 || k > 64 || (4 != typesize && 8 != typesize)) return 0;
+static size_t smm_mfma_runs_lds(int typesize, int m, int n, int k, int ldb, bool stream = false)
+{ // stream: the streaming form (every item owns its C), which takes K beyond 64 in chunks
+  if (m < 1 || n < 1 || k < 1 || m > 32 || n > 32 || k > (stream ? 256 : 64) || (4 != typesize && 8 != typesize)) return 0;
   if (ldb < k) ldb = k;
-  if ((long long)ldb * (n - 1) + k > 64 * 40) return 0; // B's span travels through registers, an element per lane and load
-  const int kp4 = 4 * ((k + 3) / 4), ksd = (8 == typesize) ? kp4 + 1 : kp4 + 2;
+  const int nch = (stream && k > 64) ? (k + 31) / 32 : 1;
+  if (1 == nch && (long long)ldb * (n - 1) + k > 64 * 40) return 0; // B's span travels through registers, an element per lane and load
+  const int kc = 4 * (((k + nch - 1) / nch + 3) / 4), ksd = (8 == typesize) ? kc + 1 : kc + 2;
   return (size_t)(((n * ksd + 3) / 4) * 4) * typesize;
 }
 // products in flight per wave (register sets): as many as fit ~80 registers, four at most
@@ -1448,6 +1495,14 @@ static bool smm_mfma_runs_ok(const SmmBatch& s)
   if (0 == on || 0 == s.use_mfma || 0 != s.lowp || 0 != s.general || 0 != (s.flags & LIBXSMM_GEMM_FLAG_TRANS_B)) return false;
   if (s.lda < s.m || s.ldb < s.k || s.ldc < s.m) return false;
   return 0 != smm_mfma_runs_lds(s.typesize, s.m, s.n, s.k, s.ldb);
+}
+// ... the streaming form (items that own their C; K up to 256)
+static bool smm_mfma_stream_ok(const SmmBatch& s)
+{
+  static const int on = []() { const char* e = getenv("XSMM_SMMJIT_MFMA_RUNS"); return (nullptr != e && 0 != *e) ? atoi(e) : 1; }();
+  if (0 == on || 0 == s.use_mfma || 0 != s.lowp || 0 != s.general || 0 != (s.flags & LIBXSMM_GEMM_FLAG_TRANS_B) || SYNC_NONE != s.sync) return false;
+  if (s.lda < s.m || s.ldb < s.k || s.ldc < s.m) return false;
+  return 0 != smm_mfma_runs_lds(s.typesize, s.m, s.n, s.k, s.ldb, true);
 }
 
 // ---- shapes with 32 < M or N <= 64: one work-group (256 threads, 16 x 16) per item, K in chunks of KC through LDS ------
@@ -1695,7 +1750,7 @@ std::string gen_smm_source(int typesize, int m, int n, int k, int flags, int var
   s += std::string("#define XTRANSB ") + ((flags & LIBXSMM_GEMM_FLAG_TRANS_B) ? "1" : "0") + "\n";
   if (0 != (variant & SMM_JIT_MFMA_RUNS)) { // run form on the matrix cores (a wave per run)
     s += "#define XLDA " + std::to_string(lda) + "\n#define XLDB " + std::to_string(ldb) + "\n#define XLDC " + std::to_string(ldc) + "\n";
-    s += "#define XWAVES " + std::to_string(smm_mfma_runs_waves(smm_mfma_runs_lds(typesize, m, n, k, ldb))) + "\n";
+    s += "#define XWAVES " + std::to_string(smm_mfma_runs_waves(smm_mfma_runs_lds(typesize, m, n, k, ldb, 0 == (variant & SMM_JIT_RUNS)))) + "\n";
     s += "#define XFLAT 0\n#define XRUNS 1\n#define XHASWG 0\n#define XGROUPED 0\n";
     s += std::string("#define XSTREAM ") + ((variant & SMM_JIT_RUNS) ? "0" : "1") + "\n"; // (without the run bit: every item owns its C)
     s += "#define XDEPTH " + std::to_string(smm_mfma_runs_depth(typesize, m, n, k, ldb)) + "\n";
@@ -1793,13 +1848,15 @@ bool smm_jit_eligible(const SmmBatch& s)
   if (SYNC_DEVICE == s.sync && 0 == s.c_atomics) return false;  // C in host memory the GPU maps: the generic kernel adds by compare-and-swap (cas_add, kernels/smm_generic.hip)
   const bool tight = (s.lda == s.m && s.ldc == s.m && (0 != (s.flags & LIBXSMM_GEMM_FLAG_TRANS_B) ? (s.ldb == s.n) : (s.ldb == s.k)));
   if (!tight) { // leading dimensions with gaps: the wave forms fetch an operand's whole span -- as long as the gaps stay moderate
-    if (s.m > 32 || s.n > 32 || s.k > 64) return false;
+    if (s.m > 32 || s.n > 32 || (s.k > 64 && !smm_mfma_stream_ok(s))) return false;
     const long long span = (long long)s.lda * (s.k - 1) + s.m + (long long)s.ldb * ((0 != (s.flags & LIBXSMM_GEMM_FLAG_TRANS_B) ? s.k : s.n) - 1)
                          + (0 != (s.flags & LIBXSMM_GEMM_FLAG_TRANS_B) ? s.n : s.k) + (long long)s.ldc * (s.n - 1) + s.m;
     const long long used = (long long)s.m * s.k + (long long)s.k * s.n + (long long)s.m * s.n;
-    if (2 * used < span || span * s.typesize > 40960) return false;
+    if (2 * used < span) return false;
+    if (span * s.typesize > 40960 && !(s.k > 64 && smm_mfma_stream_ok(s))) return false; // (a long K in chunks: no whole operand is ever on chip)
   }
-  if (s.m > 32 || s.n > 32 || s.k > 64) { // work-group-per-item form: 16x16 threads x (<=4x4) tile, K chunked (also small M, N with a long K)
+  if (s.m <= 32 && s.n <= 32 && s.k > 64 && smm_mfma_stream_ok(s)) { /* the matrix-core streaming form takes K in chunks of up to 64 */ }
+  else if (s.m > 32 || s.n > 32 || s.k > 64) { // work-group-per-item form: 16x16 threads x (<=4x4) tile, K chunked (also small M, N with a long K)
     if (s.m > 64 || s.n > 64 || s.k > 1024) return false;
     if (SYNC_NONE != s.sync && !(0 < s.uniform_run && 0 == s.batch % s.uniform_run)) return false; // shared C only as runs of a known, uniform length
     if (0 == smm_jit_big_kc(s.typesize, s.m, s.n, s.k, s.flags)) return false;
@@ -1890,10 +1947,10 @@ static int smm_jit_launch_variant(const SmmBatch& s, int variant, void* stream)
     return jit_launch_raw(k, (unsigned)blocks, 256u, &ad, sizeof(ad), &batch, stream);
   }
   if (0 != (variant & SMM_JIT_MFMA_RUNS)) { // a wave per run on the matrix cores, dealt chunks of 64 items (segments of 8 and more if the verdict cuts the batch up)
-    const size_t wlds = smm_mfma_runs_lds(s.typesize, s.m, s.n, s.k, s.ldb);
+    const bool stream_form = (0 == (variant & SMM_JIT_RUNS)); // every item owns its C: a wave per item, stride of the resident waves
+    const size_t wlds = smm_mfma_runs_lds(s.typesize, s.m, s.n, s.k, s.ldb, stream_form);
     const int waves = smm_mfma_runs_waves(wlds);
     if (0 == waves) return -1;
-    const bool stream_form = (0 == (variant & SMM_JIT_RUNS)); // every item owns its C: a wave per item, stride of the resident waves
     const long long units = stream_form ? batch : ((nullptr != ad.flags) ? (batch + 7) / 8 : (batch + 63) / 64);
     long long blocks = (units + waves - 1) / waves;
     long long per_cu = (long long)((160 * 1024) / (wlds * (size_t)waves)); if (per_cu * waves > 16) per_cu = 16 / waves; if (per_cu < 1) per_cu = 1;
@@ -2247,16 +2304,19 @@ int launch_smm_jit_lowp(const SmmBatch& s, void* stream, const char** name)
 {
   const char* const env_jit = getenv("LIBXSMM_AMD_JIT");
   if (nullptr != env_jit && 0 == atoi(env_jit)) return -1;
-  if ((1 != s.lowp && 3 != s.lowp && 4 != s.lowp) || ADDR_STRIDED != s.mode || 0 != (s.flags & LIBXSMM_GEMM_FLAG_TRANS_B)) return -1;
+  if ((1 != s.lowp && 3 != s.lowp && 4 != s.lowp) || 0 != (s.flags & LIBXSMM_GEMM_FLAG_TRANS_B)) return -1;
   if (4 == s.lowp && 0 != (s.m & 1)) return -1;
+  const bool strided = (ADDR_STRIDED == s.mode); // (index and pointer batches: the streaming form with element-wide -- one k pair -- accesses, below)
   { // bf16 inputs beyond 32: the one-wave-per-item matrix-core kernel (fp32 instruction on the widened operands: the gold
     // loop's product-then-add bit for bit)
     static const int wave_on = []() { const char* e = getenv("XSMM_SMMJIT_MFMA_WAVE"); return (nullptr != e && 0 != *e) ? atoi(e) : 1; }();
     static const int wave_min = []() { const char* e = getenv("XSMM_SMMJIT_LOWP_WAVE_MIN"); return (nullptr != e && 0 != *e) ? atoi(e) : 31; }(); // developer knob (32^3: 73.8 vs 67.9 % for the fp32 result, 67.9 vs 49.5 % for bf16; 16^3 is better off on the streaming form)
     const size_t wlds = smm_mfma_wave_lds(4, s.m, s.n, s.k);
-    const uintptr_t bits = reinterpret_cast<uintptr_t>(s.a) | reinterpret_cast<uintptr_t>(s.b) | reinterpret_cast<uintptr_t>(s.c)
-                         | (uintptr_t)(s.sa * 2) | (uintptr_t)(s.sb * 2) | (uintptr_t)(s.sc * (4 == s.lowp ? 2 : 4));
+    const uintptr_t bits = strided ? (reinterpret_cast<uintptr_t>(s.a) | reinterpret_cast<uintptr_t>(s.b) | reinterpret_cast<uintptr_t>(s.c)
+                         | (uintptr_t)(s.sa * 2) | (uintptr_t)(s.sb * 2) | (uintptr_t)(s.sc * (4 == s.lowp ? 2 : 4))) : 0;
     const char* const env_min = getenv("LIBXSMM_AMD_JIT_MINBATCH");
+    // (index and pointer batches as well: their items are whole numbers of 16-byte chunks long -- M % 4 == 0, K % 8 == 0 -- so callers
+    // that lay items out back to back keep the chunks aligned; an item that does not start on 16 bytes costs speed, not correctness)
     if (0 != wave_on && 0 != s.use_mfma && (3 == s.lowp || 4 == s.lowp) && (wave_min < s.m || wave_min < s.n) && 0 != wlds && 4 * wlds <= 160u * 1024u
       && 0 == (s.k & 7) && (3 == s.lowp || 0 == (s.m & 7)) && 0 == (bits & 15) && s.lda == s.m && s.ldb == s.k && s.ldc == s.m
       && s.batch >= ((nullptr != env_min && 0 != *env_min) ? atoll(env_min) : 16LL))
@@ -2265,9 +2325,9 @@ int launch_smm_jit_lowp(const SmmBatch& s, void* stream, const char** name)
       JitKernel* const wk = smm_jit_get(wkey);
       if (nullptr != wk) {
         struct { const char* a; const char* b; char* c; const char* ia; const char* ib; const char* ic; long long sa, sb, sc; int index_base, index_stride, mode; const int* flags; } wad;
-        wad.a = (const char*)s.a; wad.b = (const char*)s.b; wad.c = (char*)s.c; wad.ia = wad.ib = wad.ic = nullptr;
-        wad.sa = s.sa / 2; wad.sb = s.sb / 2; wad.sc = (4 == s.lowp ? s.sc / 2 : s.sc); // in 32-bit words
-        wad.index_base = 0; wad.index_stride = 0; wad.mode = 0; wad.flags = nullptr;
+        wad.a = (const char*)s.a; wad.b = (const char*)s.b; wad.c = (char*)s.c; wad.ia = (const char*)s.ia; wad.ib = (const char*)s.ib; wad.ic = (const char*)s.ic;
+        wad.sa = s.sa; wad.sb = s.sb; wad.sc = s.sc; // (in elements of the operands' types, as the kernel counts them)
+        wad.index_base = s.index_base; wad.index_stride = s.index_stride; wad.mode = s.mode; wad.flags = nullptr;
         long long wbatch = s.batch; int one = 1;
         int per_cu = (int)((160u * 1024u) / wlds);
         const int by_regs = 4 * smm_mfma_wave_wpe(wlds);
@@ -2285,16 +2345,16 @@ int launch_smm_jit_lowp(const SmmBatch& s, void* stream, const char** name)
   static const int big_i16 = []() { const char* e = getenv("XSMM_SMMJIT_LOWP_BIG"); return (nullptr != e && 0 != *e) ? atoi(e) : 1; }();
   const int lim = (0 != big_i16) ? 64 : 32; // (bf16 shapes the matrix-core form above does not take -- M or K not a multiple of 4 / 8 -- come here as well)
   if (s.m > lim || s.n > lim || s.k > 64 || 0 != (s.k & 1) || s.lda != s.m || s.ldb != s.k || s.ldc != s.m) return -1;
-  if (s.sa != (long long)s.m * s.k || s.sb != (long long)s.k * s.n || s.sc != (long long)s.m * s.n) return -1;
+  // strided batches of items laid out back to back take 16-byte accesses; every other batch (other strides, index arrays -- in
+  // elements of 16 bits, as the reference's libxsmm_mmbatch_kernel counts them --, arrays of pointers) one k pair per access
+  const bool back_to_back = strided && s.sa == (long long)s.m * s.k && s.sb == (long long)s.k * s.n && s.sc == (long long)s.m * s.n;
   const char* const env_min = getenv("LIBXSMM_AMD_JIT_MINBATCH");
   if (s.batch < ((nullptr != env_min && 0 != *env_min) ? atoll(env_min) : 16LL)) return -1;
   if (0 == smm_jit_waves(4, s.m, s.n, s.k, s.flags)) return -1;
   SmmBatch j = s;
-  j.typesize = 4; j.lowp = 0; j.sync = SYNC_NONE;
-  j.sa = s.sa / 2; j.sb = s.sb / 2; // the kernel addresses A and B as 32-bit k pairs
-  if (4 == s.lowp) j.sc = s.sc / 2;   // ... and a bf16 C as pairs along m
+  j.typesize = 4; j.lowp = 0; j.sync = SYNC_NONE; // (the kernel itself addresses A and B -- and a bf16 C -- in elements of 16 bits)
   const uintptr_t bits = reinterpret_cast<uintptr_t>(s.a) | reinterpret_cast<uintptr_t>(s.b) | reinterpret_cast<uintptr_t>(s.c);
-  const int variant = ((0 == (bits & 15)) ? 0 : SMM_JIT_SCALAR) | ((4 == s.lowp ? 2 : s.lowp) << 11); // XLOWP: 1 i16 -> i32, 2 bf16 -> bf16, 3 bf16 -> f32
+  const int variant = ((back_to_back && 0 == (bits & 15)) ? 0 : SMM_JIT_SCALAR) | ((4 == s.lowp ? 2 : s.lowp) << 11); // XLOWP: 1 i16 -> i32, 2 bf16 -> bf16, 3 bf16 -> f32
   *name = (1 == s.lowp) ? "smm_i16i32_jit_shape_lowp" : (4 == s.lowp ? "smm_bf16_jit_shape_lowp" : "smm_bf16f32_jit_shape_lowp");
   return smm_jit_launch_variant(j, variant, stream);
 }
@@ -2303,7 +2363,12 @@ int launch_smm_jit(const SmmBatch& s, void* stream, const char** name)
 { // returns -1 when no specialised kernel is available
   const int width = smm_jit_width_variant(s);
   const bool f64 = (8 == s.typesize);
+  if (s.m <= 32 && s.n <= 32 && s.k > 64 && smm_mfma_stream_ok(s)) { // long K, small M and N, every item its own C: K in chunks on the matrix cores
+    const int e = smm_jit_launch_variant(s, SMM_JIT_SCALAR | SMM_JIT_MFMA_RUNS, stream);
+    if (0 <= e) { *name = f64 ? "smm_f64_mfma_stream_jit" : "smm_f32_mfma_stream_jit"; return e; }
+  }
   if (s.m > 32 || s.n > 32 || s.k > 64) { // (eligibility made sure of SYNC_NONE, or of runs of a uniform length)
+    if (0 == smm_jit_big_kc(s.typesize, s.m, s.n, s.k, s.flags) || (SYNC_NONE != s.sync && !(0 < s.uniform_run && 0 == s.batch % s.uniform_run))) return -1;
     *name = f64 ? "smm_f64_jit_shape_wg" : "smm_f32_jit_shape_wg";
     return smm_jit_launch_variant(s, SMM_JIT_BIG, stream);
   }

@@ -171,26 +171,38 @@ def test_low_precision_batches(xs, orc, torch_gpu, kind):
     assert fn
     da, db = (torch.from_numpy(x.view(np.int16)).cuda() for x in (a, b))
     csize = 2 if kind == 3 else 4
-    # index arrays, index_base 1
-    dc = torch.from_numpy(c.view(np.int16) if kind == 3 else c).cuda()
-    sa = (pa * m * k + 1).astype(np.int32); sb = (pb * k * n + 1).astype(np.int32); sc = (np.arange(batch) * m * n + 1).astype(np.int32)
+    import os
     kern = C.c_void_p(fn)
-    rc = L.libxsmm_mmbatch_kernel(kern, 1, 4, xs.dptr(sa), xs.dptr(sb), xs.dptr(sc), da.data_ptr(), db.data_ptr(), dc.data_ptr(), batch, 0, 1, 2, csize, 0)
-    assert rc == 0
-    torch.cuda.synchronize()
-    got = dc.cpu().numpy(); got = got.view(np.uint16) if kind == 3 else got
-    assert np.array_equal(got.view(np.uint8), ref.view(np.uint8))
-    # arrays of pointers (device arrays)
-    dc = torch.from_numpy(c.view(np.int16) if kind == 3 else c).cuda()
-    qa = torch.from_numpy((da.data_ptr() + pa.astype(np.int64) * m * k * 2).astype(np.int64)).cuda()
-    qb = torch.from_numpy((db.data_ptr() + pb.astype(np.int64) * k * n * 2).astype(np.int64)).cuda()
-    qc = torch.from_numpy((dc.data_ptr() + np.arange(batch, dtype=np.int64) * m * n * csize).astype(np.int64)).cuda()
+    sa = (pa * m * k + 1).astype(np.int32); sb = (pb * k * n + 1).astype(np.int32); sc = (np.arange(batch) * m * n + 1).astype(np.int32)
     ptrsize = np.array([8], dtype=np.int32)
-    rc = L.libxsmm_mmbatch_kernel(kern, 0, 0, xs.dptr(ptrsize), xs.dptr(ptrsize), xs.dptr(ptrsize), qa.data_ptr(), qb.data_ptr(), qc.data_ptr(), batch, 0, 1, 2, csize, 0)
-    assert rc == 0
-    torch.cuda.synchronize()
-    got = dc.cpu().numpy(); got = got.view(np.uint16) if kind == 3 else got
-    assert np.array_equal(got.view(np.uint8), ref.view(np.uint8))
+    for forced in (False, True):  # forced: the hiprtc-specialised streaming form, one k pair per access (the product takes it from 16 items on)
+        old_min = os.environ.get("LIBXSMM_AMD_JIT_MINBATCH")
+        os.environ["LIBXSMM_AMD_JIT_MINBATCH"] = "1" if forced else "100000"
+        try:
+            # index arrays (in elements of the operand's type, as the reference counts them), index_base 1
+            dc = torch.from_numpy(c.view(np.int16) if kind == 3 else c).cuda()
+            rc = L.libxsmm_mmbatch_kernel(kern, 1, 4, xs.dptr(sa), xs.dptr(sb), xs.dptr(sc), da.data_ptr(), db.data_ptr(), dc.data_ptr(), batch, 0, 1, 2, csize, 0)
+            assert rc == 0
+            torch.cuda.synchronize()
+            assert ("_jit_shape_lowp" in xs.last_kernel()) == forced, xs.last_kernel()
+            got = dc.cpu().numpy(); got = got.view(np.uint16) if kind == 3 else got
+            assert np.array_equal(got.view(np.uint8), ref.view(np.uint8)), forced
+            # arrays of pointers (device arrays)
+            dc = torch.from_numpy(c.view(np.int16) if kind == 3 else c).cuda()
+            qa = torch.from_numpy((da.data_ptr() + pa.astype(np.int64) * m * k * 2).astype(np.int64)).cuda()
+            qb = torch.from_numpy((db.data_ptr() + pb.astype(np.int64) * k * n * 2).astype(np.int64)).cuda()
+            qc = torch.from_numpy((dc.data_ptr() + np.arange(batch, dtype=np.int64) * m * n * csize).astype(np.int64)).cuda()
+            rc = L.libxsmm_mmbatch_kernel(kern, 0, 0, xs.dptr(ptrsize), xs.dptr(ptrsize), xs.dptr(ptrsize), qa.data_ptr(), qb.data_ptr(), qc.data_ptr(), batch, 0, 1, 2, csize, 0)
+            assert rc == 0
+            torch.cuda.synchronize()
+            assert ("_jit_shape_lowp" in xs.last_kernel()) == forced, xs.last_kernel()
+            got = dc.cpu().numpy(); got = got.view(np.uint16) if kind == 3 else got
+            assert np.array_equal(got.view(np.uint8), ref.view(np.uint8)), forced
+        finally:
+            if old_min is None:
+                os.environ.pop("LIBXSMM_AMD_JIT_MINBATCH", None)
+            else:
+                os.environ["LIBXSMM_AMD_JIT_MINBATCH"] = old_min
     # contiguous items: libxsmm_amd_gemm_batch_strided on a low-precision descriptor (strides in elements of each operand's type)
     dc = torch.from_numpy(c.view(np.int16) if kind == 3 else c).cuda()
     ident = (np.arange(batch) * m * k).astype(np.int64)  # (reference values for unpermuted operands)
@@ -407,3 +419,54 @@ def test_i16_streaming_form_beyond_32(xs, orc, torch_gpu, shape):
             os.environ.pop("LIBXSMM_AMD_JIT_MINBATCH", None)
         else:
             os.environ["LIBXSMM_AMD_JIT_MINBATCH"] = old_env
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", [2, 3])
+@pytest.mark.parametrize("shape", [(48, 48, 48), (64, 40, 56), (32, 32, 32)])
+def test_low_precision_index_and_pointer_batches_on_the_wave_kernel(xs, orc, torch_gpu, kind, shape):
+    """libxsmm_mmbatch_kernel (index arrays in elements of 16 bits, arrays of pointers) with bf16 inputs from 32 x 32 up: the
+    one-wave-per-item matrix-core kernel, as for strided batches -- the gold loop bit for bit (parity unpinned beyond it: no
+    reference-held vector). Operands shuffled, every item its own C."""
+    import os
+    torch = torch_gpu
+    L = xs.lib()
+    m, n, k = shape
+    batch = 600
+    rng = np.random.default_rng(kind * 7 + m)
+    a = _bf16(rng.uniform(-1, 1, batch * m * k)); b = _bf16(rng.uniform(-1, 1, batch * k * n))
+    c = rng.uniform(-1, 1, batch * m * n).astype(np.float32) if kind == 2 else _bf16(rng.uniform(-1, 1, batch * m * n))
+    pa, pb = rng.permutation(batch), rng.permutation(batch)
+    ref = c.copy()
+    for i in range(batch):
+        assert 0 == orc.gemm_lowp(kind, 0, m, n, k, m, k, m, a[pa[i] * m * k:(pa[i] + 1) * m * k], b[pb[i] * k * n:(pb[i] + 1) * k * n], ref[i * m * n:(i + 1) * m * n], 1.0)
+    fn = getattr(L, DISPATCH[kind])(m, n, k, None, None, None, None, None, None, None)
+    assert fn
+    kern = C.c_void_p(fn)
+    da, db = (torch.from_numpy(x.view(np.int16)).cuda() for x in (a, b))
+    csize = 2 if kind == 3 else 4
+    sa = (pa * m * k).astype(np.int32); sb = (pb * k * n).astype(np.int32); sc = (np.arange(batch) * m * n).astype(np.int32)
+    ptrsize = np.array([8], dtype=np.int32)
+    old_min = os.environ.get("LIBXSMM_AMD_JIT_MINBATCH")
+    os.environ["LIBXSMM_AMD_JIT_MINBATCH"] = "1"
+    try:
+        dc = torch.from_numpy(c.view(np.int16) if kind == 3 else c).cuda()
+        assert 0 == L.libxsmm_mmbatch_kernel(kern, 0, 4, xs.dptr(sa), xs.dptr(sb), xs.dptr(sc), da.data_ptr(), db.data_ptr(), dc.data_ptr(), batch, 0, 1, 2, csize, 0)
+        torch.cuda.synchronize()
+        assert "_mfma_wave_jit_lowp" in xs.last_kernel(), xs.last_kernel()
+        got = dc.cpu().numpy(); got = got.view(np.uint16) if kind == 3 else got
+        assert np.array_equal(got.view(np.uint8), ref.view(np.uint8))
+        dc = torch.from_numpy(c.view(np.int16) if kind == 3 else c).cuda()
+        qa = torch.from_numpy((da.data_ptr() + pa.astype(np.int64) * m * k * 2).astype(np.int64)).cuda()
+        qb = torch.from_numpy((db.data_ptr() + pb.astype(np.int64) * k * n * 2).astype(np.int64)).cuda()
+        qc = torch.from_numpy((dc.data_ptr() + np.arange(batch, dtype=np.int64) * m * n * csize).astype(np.int64)).cuda()
+        assert 0 == L.libxsmm_mmbatch_kernel(kern, 0, 0, xs.dptr(ptrsize), xs.dptr(ptrsize), xs.dptr(ptrsize), qa.data_ptr(), qb.data_ptr(), qc.data_ptr(), batch, 0, 1, 2, csize, 0)
+        torch.cuda.synchronize()
+        assert "_mfma_wave_jit_lowp" in xs.last_kernel(), xs.last_kernel()
+        got = dc.cpu().numpy(); got = got.view(np.uint16) if kind == 3 else got
+        assert np.array_equal(got.view(np.uint8), ref.view(np.uint8))
+    finally:
+        if old_min is None:
+            os.environ.pop("LIBXSMM_AMD_JIT_MINBATCH", None)
+        else:
+            os.environ["LIBXSMM_AMD_JIT_MINBATCH"] = old_min

@@ -219,7 +219,9 @@ def test_cp2k_27_shape_grouped_launch_bitexact(xs, orc, torch_gpu, mfma, host_in
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("shape", [(23, 23, 23, 24, 24, 24), (13, 13, 13, 16, 16, 16), (32, 32, 32, 40, 40, 40), (5, 7, 3, 8, 8, 8), (16, 31, 35, 16, 35, 24),
-                                   (23, 23, 23, 23, 23, 23), (32, 32, 32, 32, 32, 32), (1, 1, 1, 1, 1, 1), (31, 2, 63, 33, 64, 31)])
+                                   (23, 23, 23, 23, 23, 23), (32, 32, 32, 32, 32, 32), (1, 1, 1, 1, 1, 1), (31, 2, 63, 33, 64, 31),
+                                   # K beyond 64: through the registers and B's image in chunks of at most 32 (the last chunk padded with -0 / +0)
+                                   (23, 23, 70, 23, 70, 23), (32, 32, 128, 32, 128, 32), (13, 17, 200, 16, 203, 20), (5, 3, 65, 5, 65, 5), (16, 16, 256, 16, 256, 16)])
 @pytest.mark.parametrize("beta", [1.0, 0.0])
 def test_independent_items_on_the_matrix_core_streaming_form(xs, orc, torch_gpu, dtype, shape, beta):
     """strided batches whose items own their C (SYNC_NONE), with and without gaps in the leading dimensions, on the streaming form of

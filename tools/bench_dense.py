@@ -75,6 +75,24 @@ def run_lowp(kind, m, n, k):
     t = min(times); gbs = batch * per_item / t / 1e6
     print("%-7s %2dx%2dx%2d beta=1 %-22s batch=%8d  %.3f ms  %6.0f GB/s (%4.1f%% of 8 TB/s)  %7.0f GFLOP/s"
           % (kind, m, n, k, xs.last_kernel(), batch, t, gbs, gbs / 80.0, 2.0 * m * n * k * batch / t / 1e6))
+    # the same batch through the reference's libxsmm_mmbatch_kernel with index arrays (in elements of each operand's type; device arrays)
+    L.libxsmm_xmmdispatch.restype = C.c_void_p; L.libxsmm_xmmdispatch.argtypes = [C.c_void_p]
+    kern = L.libxsmm_xmmdispatch(C.c_void_p(desc))
+    if kern:
+        idx = torch.arange(batch, device="cuda", dtype=torch.int64)
+        ia, ib, ic = (idx * (m * k)).to(torch.int32), (idx * (k * n)).to(torch.int32), (idx * (m * n)).to(torch.int32)
+        L.libxsmm_mmbatch_kernel.restype = C.c_int
+        L.libxsmm_mmbatch_kernel.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_ubyte, C.c_ubyte, C.c_int]
+        times = []
+        for it in range(reps + 2):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            assert 0 == L.libxsmm_mmbatch_kernel(kern, 0, 4, xs.dptr(ia), xs.dptr(ib), xs.dptr(ic), xs.dptr(a), xs.dptr(b), xs.dptr(c), batch, 0, 1, 2, osz, 0)
+            e1.record(); torch.cuda.synchronize()
+            if it >= 2:
+                times.append(e0.elapsed_time(e1))
+        t = min(times); gbs = batch * per_item / t / 1e6
+        print("%-7s %2dx%2dx%2d  index arrays (libxsmm_mmbatch_kernel) %-22s  %.3f ms  %6.0f GB/s (%4.1f%% of 8 TB/s)" % (kind, m, n, k, xs.last_kernel(), t, gbs, gbs / 80.0))
 
 
 if which == "lowp":

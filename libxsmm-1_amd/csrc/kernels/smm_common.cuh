@@ -42,6 +42,23 @@ __device__ __forceinline__ T* resolve(const char* base, const char* idx, long lo
   return *(T* const*)(base + i * stride); // ADDR_POINTER
 }
 
+// The same in two steps, for kernels that look the addresses of an item up one iteration before they request its operands:
+// raw_of issues the load an index / pointer batch needs (nothing depends on it yet), cooked turns what arrived into the address.
+// Done in one step (resolve), the index load is a full memory round trip in front of every operand request.
+__device__ __forceinline__ long long raw_of(const char* base, const char* idx, long long stride, const DevAddr& ad, long long i)
+{
+  if (ADDR_STRIDED == ad.mode) return i * stride;
+  if (ADDR_INDEX == ad.mode) return (nullptr == idx) ? (long long)ad.index_base : (long long)*(const int*)(idx + i * (long long)ad.index_stride);
+  return *(const long long*)(base + i * stride); // ADDR_POINTER
+}
+template<typename T>
+__device__ __forceinline__ T* cooked(const char* base, const DevAddr& ad, long long raw)
+{
+  if (ADDR_STRIDED == ad.mode) return (T*)base + raw;
+  if (ADDR_INDEX == ad.mode) return (T*)base + (raw - ad.index_base);
+  return (T*)raw;
+}
+
 template<typename T> __device__ __forceinline__ const T* addr_a(const DevAddr& ad, long long i) { return resolve<const T>(ad.a, ad.ia, ad.sa, ad, i); }
 template<typename T> __device__ __forceinline__ const T* addr_b(const DevAddr& ad, long long i) { return resolve<const T>(ad.b, ad.ib, ad.sb, ad, i); }
 template<typename T> __device__ __forceinline__ T* addr_c(const DevAddr& ad, long long i) { return resolve<T>(ad.c, ad.ic, ad.sc, ad, i); }

@@ -161,11 +161,22 @@ void smm32_f32_mfma_kernel(DevAddr ad, long long batch, int runlen)
   };
   long long unit = w;
   int r0 = 0; // position inside the run
+  // what follows (unit, r0) in this wave's walk
+  auto step = [&](long long u, int r, long long& u1, int& r1) { r1 = RUNS ? r + 1 : 0; u1 = u; if (!RUNS || r1 == runlen) { r1 = 0; u1 += W; } };
+  float* pc_cur; float* pc_nxt = nullptr; // C of the current / the next item
   {
     const long long first = RUNS ? unit * runlen : unit;
     load_mat32<NT, GLB>(addr_a<float>(ad, first), lane, ra);
     load_mat32<NT, GLB>(addr_b<float>(ad, first), lane, rb);
-    if (!BETA0) load_c(addr_c<float>(ad, first) + coff);
+    pc_cur = addr_c<float>(ad, first);
+    if (!BETA0) load_c(pc_cur + coff);
+  }
+  // Addresses are looked up one item further ahead than the operands: an index (or pointer) batch needs a load per operand
+  // before the operand can be requested, and looked up on the spot that load is a memory round trip in front of every item's
+  // requests (1 M items through libxsmm_gemm_batch with index arrays: 63 % of the HBM peak against 72 % for the strided form).
+  long long raw_a = 0, raw_b = 0, raw_c = 0;
+  if (!RUNS && unit + W < nunits) {
+    raw_a = raw_of(ad.a, ad.ia, ad.sa, ad, unit + W); raw_b = raw_of(ad.b, ad.ib, ad.sb, ad, unit + W); raw_c = raw_of(ad.c, ad.ic, ad.sc, ad, unit + W);
   }
   f32x16 acc;
   // The result of an item leaves at the top of the next iteration, *before* that iteration issues its loads: the counter a
@@ -179,7 +190,6 @@ void smm32_f32_mfma_kernel(DevAddr ad, long long batch, int runlen)
     for (int r = 0; r < 16; ++r) st1<NT, GLB>(pend_pc + ((r & 3) + 8 * (r >> 2)) * 32, pend[r]);
   };
   for (;;) {
-    const long long item = RUNS ? unit * runlen + r0 : unit;
     __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): the operands of this item (nothing younger is in flight)
     if (nullptr != pend_pc) { store_pend(); pend_pc = nullptr; }
     park_ab<1>(As, Bs, lane, ra, rb);
@@ -187,14 +197,23 @@ void smm32_f32_mfma_kernel(DevAddr ad, long long batch, int runlen)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = BETA0 ? 0.f : rc[r];
     }
-    int r1 = RUNS ? r0 + 1 : 0; long long unit1 = unit;
-    if (!RUNS || r1 == runlen) { r1 = 0; unit1 += W; }
+    int r1; long long unit1; step(unit, r0, unit1, r1);
     const bool more = unit1 < nunits;
     if (more) {
-      const long long next = RUNS ? unit1 * runlen + r1 : unit1;
-      load_mat32<NT, GLB>(addr_a<float>(ad, next), lane, ra);
-      load_mat32<NT, GLB>(addr_b<float>(ad, next), lane, rb);
-      if (!BETA0 && (!RUNS || 0 == r1)) load_c(addr_c<float>(ad, next) + coff);
+      if (RUNS) { // (blocked GEMM work lists: looked up on the spot -- the two-step form was measured 6 % slower there, 4096^3 in 32^3 blocks)
+        const long long next = unit1 * runlen + r1;
+        load_mat32<NT, GLB>(addr_a<float>(ad, next), lane, ra);
+        load_mat32<NT, GLB>(addr_b<float>(ad, next), lane, rb);
+        if (0 == r1) { pc_nxt = addr_c<float>(ad, next); if (!BETA0) load_c(pc_nxt + coff); } else pc_nxt = pc_cur;
+      }
+      else { // the next item's operands, at the addresses looked up during the previous item
+        load_mat32<NT, GLB>(cooked<const float>(ad.a, ad, raw_a), lane, ra);
+        load_mat32<NT, GLB>(cooked<const float>(ad.b, ad, raw_b), lane, rb);
+        pc_nxt = cooked<float>(ad.c, ad, raw_c);
+        if (!BETA0) load_c(pc_nxt + coff);
+        const long long next2 = unit1 + W; // ... and the addresses of the item after it
+        if (next2 < nunits) { raw_a = raw_of(ad.a, ad.ia, ad.sa, ad, next2); raw_b = raw_of(ad.b, ad.ib, ad.sb, ad, next2); raw_c = raw_of(ad.c, ad.ic, ad.sc, ad, next2); }
+      }
     }
     wave_lds_sync();
     // The instruction is a k-ordered fmaf chain (one rounding per product): with the two k of step s being 2s and 2s + 1 every
@@ -208,10 +227,10 @@ void smm32_f32_mfma_kernel(DevAddr ad, long long batch, int runlen)
       const float bv = (0 != hi) ? bt[s >> 1][2 * (s & 1) + 1] : bt[s >> 1][2 * (s & 1)]; // B[k = 2s + hi][n = lo]
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bv, av, acc, 0, 0, 0);
     }
-    if (!RUNS || r0 + 1 == runlen) { pend = acc; pend_pc = addr_c<float>(ad, item) + coff; }
+    if (!RUNS || r0 + 1 == runlen) { pend = acc; pend_pc = pc_cur + coff; }
     wave_lds_sync();
     if (!more) break;
-    unit = unit1; r0 = r1;
+    unit = unit1; r0 = r1; pc_cur = pc_nxt;
   }
   if (nullptr != pend_pc) store_pend();
 }

@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--mode", default="strided", choices=["strided", "index"])
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-variants", action="store_true", help="skip headline_variants (profiling runs: the variants launch the same kernel)")
     ap.add_argument("--cpu-items", type=int, default=131072, help="bounded CPU-baseline sample (items)")
     ap.add_argument("--config", type=int, default=2, choices=[2, 4, 5], help="BASELINE configuration (2: the headline)")
     ap.add_argument("--chunks", type=int, default=4, help="config 4: chunks of the per-GPU shard (gather of chunk i overlaps compute of chunk i+1)")
@@ -212,7 +213,7 @@ def main():
         out["roofline"]["guide_achievable_gbs"] = 6300.0  # /opt/skills/guides/MI355X_MICROARCH.md: ~6.3 TB/s achievable of the 8 TB/s peak
         out["roofline"]["frac_of_guide_achievable"] = round(achieved / 6300.0, 4)
         out["roofline"]["operands"] = "A, B, C cut from one allocation, B and C 8 / 16 KiB off the spacing of the arrays (see headline_variants for three separate allocations)"
-    if rank == 0 and world == 1 and not args.no_secondary and args.mode == "strided":
+    if rank == 0 and world == 1 and not args.no_secondary and not args.no_variants and args.mode == "strided":
         # The same workload (a) through the reference's own entry point, libxsmm_gemm_batch with index arrays (src/libxsmm_gemm.c:1878;
         # negative batchsize: no two items share a C), and (b) with A, B, C as three separate allocations -- what
         # samples/smm/specialized.cpp:143-146 does -- where the arrays may land at the same offset modulo the memory interleave.

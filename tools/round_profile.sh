@@ -8,5 +8,5 @@ timeout -k 10 900 python -m pytest tests -q -m gpu -x > gpurun_out/gpu_tests.log
 tail -n 3 gpurun_out/gpu_tests.log
 timeout -k 10 600 python bench.py --steps 10 --warmup 2 > gpurun_out/bench_n1.json 2> gpurun_out/bench_n1.err || { tail gpurun_out/bench_n1.err; exit 1; }
 cat gpurun_out/bench_n1.json
-(cd /tmp && timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/prof" -o smm32 -- python3 "$GRAFT_REPO_ROOT/bench.py" --steps 10 --warmup 2 --no-cpu > "$GRAFT_REPO_ROOT/gpurun_out/prof_bench.json" 2> "$GRAFT_REPO_ROOT/gpurun_out/prof_bench.err") || { tail gpurun_out/prof_bench.err; exit 1; }
+(cd /tmp && timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/prof" -o smm32 -- python3 "$GRAFT_REPO_ROOT/bench.py" --steps 10 --warmup 2 --no-cpu --no-variants > "$GRAFT_REPO_ROOT/gpurun_out/prof_bench.json" 2> "$GRAFT_REPO_ROOT/gpurun_out/prof_bench.err") || { tail gpurun_out/prof_bench.err; exit 1; }
 ls gpurun_out/prof

@@ -254,3 +254,36 @@ def test_independent_items_on_the_matrix_core_streaming_form(xs, orc, torch_gpu,
             del os.environ["XSMM_SMMJIT_GAPS_MFMA"]
         else:
             os.environ["XSMM_SMMJIT_GAPS_MFMA"] = old_env
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_streaming_form_with_index_and_pointer_batches(xs, orc, torch_gpu, dtype):
+    """the caller's promise of a negative batchsize (no two items share a C, reference src/libxsmm_gemm.c:1338,1430) puts index and
+    pointer batches with gaps in the leading dimensions on the streaming form as well: every wave looks its item's addresses up"""
+    torch = torch_gpu
+    m, n, k, lda, ldb, ldc = 23, 17, 29, 24, 32, 28
+    batch = 3000
+    ts = np.dtype(dtype).itemsize
+    rng = np.random.default_rng(41)
+    a = rng.uniform(-1, 1, batch * lda * k).astype(dtype); b = rng.uniform(-1, 1, batch * ldb * n).astype(dtype)
+    c = rng.uniform(-1, 1, batch * ldc * n).astype(dtype)
+    pa, pb, pc = rng.permutation(batch), rng.permutation(batch), rng.permutation(batch)
+    sa = (pa * lda * k).astype(np.int32); sb = (pb * ldb * n).astype(np.int32); sc = (pc * ldc * n).astype(np.int32)
+    ref = c.copy()
+    assert 0 == orc.gemm_batch_idx(orc.FMA, 0, m, n, k, lda, ldb, ldc, a, b, ref, 0, sa, sb, sc, batch)
+    prec = xs.F64 if dtype == np.float64 else xs.F32
+    with _Jit(xs):
+        da, db, dc = (torch.from_numpy(x).cuda() for x in (a, b, c))
+        xs.gemm_batch(prec, "N", "N", m, n, k, 1.0, da, lda, db, ldb, 1.0, dc, ldc, 0, 4, sa, sb, sc, -batch)
+        torch.cuda.synchronize()
+        assert xs.last_kernel().endswith("_mfma_stream_jit"), xs.last_kernel()
+        assert np.array_equal(dc.cpu().numpy(), ref)
+        dc = torch.from_numpy(c).cuda()
+        qa = torch.from_numpy((da.data_ptr() + sa.astype(np.int64) * ts).astype(np.int64)).cuda()
+        qb = torch.from_numpy((db.data_ptr() + sb.astype(np.int64) * ts).astype(np.int64)).cuda()
+        qc = torch.from_numpy((dc.data_ptr() + sc.astype(np.int64) * ts).astype(np.int64)).cuda()
+        ptrsize = np.array([8], dtype=np.int32)
+        xs.gemm_batch(prec, "N", "N", m, n, k, 1.0, qa, lda, qb, ldb, 1.0, qc, ldc, 0, 0, ptrsize, ptrsize, ptrsize, -batch)
+        torch.cuda.synchronize()
+        assert xs.last_kernel().endswith("_mfma_stream_jit"), xs.last_kernel()
+        assert np.array_equal(dc.cpu().numpy(), ref)

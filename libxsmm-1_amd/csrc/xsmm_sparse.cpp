@@ -125,7 +125,8 @@ int fsspmdm_run(const H* h, const T* B, T* C, long long batch)
     return e;
   };
   // one panel per call on device memory (the PyFR driver's loop, samples/pyfr/pyfr_driver_asp_reg.c:300-308): consecutive calls
-  // that walk along the rows are recorded into a burst instead of costing a launch each (xsmm_defer.cpp)
+  // that walk along the rows are, inside the caller's opt-in bracket (libxsmm_amd_defer_begin/end), recorded into a burst instead of
+  // costing a launch each (xsmm_defer.cpp)
   if (1 == batch && nullptr != h->jit && 0 == (h->N % h->jit_vec)
     && defer_panels(h, h->jit, B, C, h->typesize, h->M, h->N, h->K, h->ldb, h->ldc, h->jit_vec)) return EXIT_SUCCESS;
   if (is_device_ptr(B) && is_device_ptr(C)) { const int e = launch(B, C); if (0 == e) settle(B, C); return 0 == e ? EXIT_SUCCESS : EXIT_FAILURE; }

@@ -1253,6 +1253,47 @@ __device__ __forceinline__ void acc_store(T* pc, int l16, int lq, const ACC (&ac
       }
 }
 
+#if XHANDWAIT
+// The compiler's own wait counts are useless for the software pipeline of the run form: in front of the first matrix instruction
+// of a product it waits for ALL of the product's A fragments (vmcnt(#B loads just issued)) -- the ones requested at the very end of
+// the previous product included: a memory round trip per product, 1.8 us for a 32^3 fp64 product whose matrix instructions take 0.9.
+// The loads whose results live across iterations are therefore issued as inline assembly -- invisible to the compiler's
+// scoreboard -- and waited for by hand: vmcnt retires in the order of issue, and the number of loads issued after the ones a step
+// needs is a constant of the pipeline (below). Loads the compiler does see (C at a run head, address windows) are drained inside
+// their branch, so that nothing pending escapes into the loop.
+__device__ __forceinline__ T xload_nt(const XGLOBAL T* p, int off)
+{ // off: bytes, a constant below 4096 after unrolling (the instruction's immediate: one address register pair serves a 4 KiB window)
+  T v;
+  if constexpr (F64) asm volatile("global_load_dwordx2 %0, %1, off offset:%2 nt" : "=v"(v) : "v"(p), "n"(off));
+  else asm volatile("global_load_dword %0, %1, off offset:%2 nt" : "=v"(v) : "v"(p), "n"(off));
+  return v;
+}
+// B's flat span, 64 elements per load; the last load of a span that does not end on 64 elements repeats the span's last element
+__device__ __forceinline__ void xload_b(const T* pb, int lane, T (&rb)[NLB])
+{
+  const XGLOBAL T* const b0 = (const XGLOBAL T*)pb + lane;
+#pragma unroll
+  for (int jj = 0; jj < NLB; ++jj) {
+    const int byte = jj * 64 * TS;
+    if (64 * jj + 63 < BE) rb[jj] = xload_nt(b0 + (byte / 4096) * (4096 / TS), byte % 4096);
+    else rb[jj] = xload_nt((const XGLOBAL T*)pb + clampi(64 * jj + lane, BE - 1), 0);
+  }
+}
+// A's fragments of k step ks (rows beyond M repeat row M - 1, k beyond K repeats k = K - 1: replaced by -0 when used)
+__device__ __forceinline__ void xload_a(const T* pa, int ks, const int (&moff)[MI], int lq, T (&af)[MI])
+{
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int byte = 4 * ks * LDA * TS;
+    if (4 * ks + 3 < K) af[mi] = xload_nt((const XGLOBAL T*)pa + lq * LDA + moff[mi] + (byte / 4096) * (4096 / TS), byte % 4096);
+    else af[mi] = xload_nt((const XGLOBAL T*)pa + clampi(4 * ks + lq, K - 1) * LDA + moff[mi], 0);
+  }
+}
+constexpr int vmc(int n) { return n < 63 ? n : 63; } // (the counter has six bits; fewer is stricter, never wrong)
+template<int CNT> __device__ __forceinline__ void wait_on(T& a) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(a) : "n"(CNT)); }
+template<int CNT> __device__ __forceinline__ void wait_on(T& a, T& b) { asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(CNT)); }
+#endif
+
 #if XSTREAM
 // Every item owns its C (strided batches; index / pointer batches under the caller's promise): a wave per item, walking the batch with
 // a stride of all resident waves. The next item's operands -- B's flat array, C in the layout of the accumulators, A's fragments
@@ -1365,15 +1406,26 @@ extern "C" __global__ __launch_bounds__(64 * XWAVES) void xsmm_smm_op(DevAddr ad
     // D products in flight (register sets; the walk is unrolled over them so that every index is a constant): a light product's
     // arithmetic is over in a tenth of a microsecond -- one product ahead, a run of 13^3 products is a chain of memory round trips
     T af[D][KS][MI], rb[D][NLB];
+#if XHANDWAIT
+    constexpr int LSET = NLB + KS * MI;                                   // loads per product
+    constexpr int CNT_B = vmc(KS * MI + (D - 1) * LSET);                  // issued after a product's B when it is parked
+    constexpr int CNT_A = vmc((KS - 1) * MI + NLB + (D - 1) * LSET);      // issued after the fragments of k step ks when they are used (any ks)
+#endif
 #pragma unroll
     for (int s = 0; s < D; ++s) {
       const long long j = (first + s < end) ? (first + s) : (end - 1);
       WINDOW_AB(win, j, pa0, pb0);
+#if XHANDWAIT
+      xload_b(pb0, lane, rb[s]);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) xload_a(pa0, ks, moff, lq, af[s][ks]);
+#else
       load_b_flat(pb0, lane, rb[s]);
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) af[s][ks][mi] = load_a_frag(pa0, ks, moff[mi], lq);
+#endif
     }
     ACC acc[NI][MI];
     T* pc = nullptr;
@@ -1391,8 +1443,24 @@ extern "C" __global__ __launch_bounds__(64 * XWAVES) void xsmm_smm_op(DevAddr ad
 #pragma unroll
               for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = ACC{ 0, 0, 0, 0 };
           }
-          else acc_load(pc, l16, lq, acc);
+          else {
+            acc_load(pc, l16, lq, acc);
+#if XHANDWAIT
+            // (C has arrived before the branch ends: a load left pending here would make the compiler wait for everything in
+            // front of the first matrix instruction of EVERY product, head or not)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+              for (int mi = 0; mi < MI; ++mi) asm volatile("" : "+v"(acc[ni][mi]));
+#endif
+          }
         }
+#if XHANDWAIT
+#pragma unroll
+        for (int jj = 0; jj + 1 < NLB; jj += 2) wait_on<CNT_B>(rb[s][jj], rb[s][jj + 1]);
+        if (NLB & 1) wait_on<CNT_B>(rb[s][NLB - 1]);
+#endif
         park_b(Bs, lane, rb[s]);
         // The operands of the product D ahead take this set's place: B right away, A behind the instructions that free its
         // registers. No control flow around the loads -- the last D products of a walk fetch the last one's operands again (never
@@ -1401,19 +1469,35 @@ extern "C" __global__ __launch_bounds__(64 * XWAVES) void xsmm_smm_op(DevAddr ad
         // for 13^3).
         const long long inext = (i + D < end) ? (i + D) : (end - 1);
         WINDOW_AB(win, inext, pa1, pb1);
+#if XHANDWAIT
+        xload_b(pb1, lane, rb[s]);
+#else
         load_b_flat(pb1, lane, rb[s]);
+#endif
         wave_lds_sync();
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           T bf[NI];
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni) bf[ni] = Bs[boff[ni] + 4 * ks];
+#if XHANDWAIT
+          if (1 == MI) wait_on<CNT_A>(af[s][ks][0]); else wait_on<CNT_A>(af[s][ks][0], af[s][ks][MI - 1]);
+          T av[MI];
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) av[mi] = (4 * ks + 3 < K || 4 * ks + lq < K) ? af[s][ks][mi] : -T(0); // (K padded to four: A = -0)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = xmfma(bf[ni], av[mi], acc[ni][mi]);
+          xload_a(pa1, ks, moff, lq, af[s][ks]);
+#else
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = xmfma(bf[ni], af[s][ks][mi], acc[ni][mi]);
 #pragma unroll
           for (int mi = 0; mi < MI; ++mi) af[s][ks][mi] = load_a_frag(pa1, ks, moff[mi], lq);
+#endif
         }
         wave_lds_sync(); // (B's image is parked over next)
       }
@@ -1486,6 +1570,12 @@ static int smm_mfma_runs_depth(int typesize, int m, int n, int k, int ldb)
   const int regs = (typesize / 4) * (((k + 3) / 4) * ((m + 15) / 16) + (ldb * (n - 1) + k + 63) / 64);
   const int d = 80 / (regs > 0 ? regs : 1);
   return d < 1 ? 1 : (d > 4 ? 4 : d);
+}
+// hand-counted waits in the software pipeline of the run form (XSMM_SMMJIT_HANDWAIT=0: the compiler's: developer knob)
+static int smm_mfma_handwait()
+{
+  static const int env = []() { const char* e = getenv("XSMM_SMMJIT_HANDWAIT"); return (nullptr != e && 0 != *e) ? atoi(e) : 1; }();
+  return 0 != env ? 1 : 0;
 }
 static int smm_mfma_runs_waves(size_t lds) { return (0 == lds) ? 0 : ((4 * lds <= 65536) ? 4 : ((2 * lds <= 65536) ? 2 : 1)); }
 // may batch s (shared C: runs) take that form?
@@ -1753,6 +1843,7 @@ std::string gen_smm_source(int typesize, int m, int n, int k, int flags, int var
     s += "#define XWAVES " + std::to_string(smm_mfma_runs_waves(smm_mfma_runs_lds(typesize, m, n, k, ldb, 0 == (variant & SMM_JIT_RUNS)))) + "\n";
     s += "#define XFLAT 0\n#define XRUNS 1\n#define XHASWG 0\n#define XGROUPED 0\n";
     s += std::string("#define XSTREAM ") + ((variant & SMM_JIT_RUNS) ? "0" : "1") + "\n"; // (without the run bit: every item owns its C)
+    s += "#define XHANDWAIT " + std::to_string(smm_mfma_handwait()) + "\n";
     s += "#define XDEPTH " + std::to_string(smm_mfma_runs_depth(typesize, m, n, k, ldb)) + "\n";
     s += std::string("#define XSPLIT ") + ((variant & SMM_JIT_SPLIT) ? "1" : "0") + "\n";
     s += SMM_JIT_PRELUDE; s += SMM_JIT_MFMA_RUNS_CONST; s += SMM_JIT_CHAIN; s += SMM_JIT_MFMA_RUNS_KERNEL;
@@ -2043,7 +2134,7 @@ std::string gen_smm_grouped_source(int typesize, const std::vector<GroupedBody>&
     s += "#define XDEPTH " + std::to_string(0 != (b.variant & SMM_JIT_MFMA_RUNS) ? smm_mfma_runs_depth(typesize, b.m, b.n, b.k, b.ldb) : smm_jit_depth(typesize, b.m, b.n, b.k, b.variant)) + "\n";
     s += std::string("#define XSPLIT ") + ((b.variant & SMM_JIT_SPLIT) ? "1" : "0") + "\n";
     s += std::string("#define XHASWG ") + ((b.variant & SMM_JIT_HASWG) ? "1" : "0") + "\n";
-    if (0 != (b.variant & SMM_JIT_MFMA_RUNS)) { s += "#define XSTREAM 0\n"; s += SMM_JIT_MFMA_RUNS_CONST; s += SMM_JIT_CHAIN; s += SMM_JIT_MFMA_RUNS_KERNEL; s += "#undef XNROW\n#undef XSTREAM\n"; }
+    if (0 != (b.variant & SMM_JIT_MFMA_RUNS)) { s += "#define XSTREAM 0\n#define XHANDWAIT " + std::to_string(smm_mfma_handwait()) + "\n"; s += SMM_JIT_MFMA_RUNS_CONST; s += SMM_JIT_CHAIN; s += SMM_JIT_MFMA_RUNS_KERNEL; s += "#undef XNROW\n#undef XSTREAM\n#undef XHANDWAIT\n"; }
     else { s += SMM_JIT_SHAPE; s += SMM_JIT_CHAIN; s += SMM_JIT_SHAPE_KERNELS; }
     s += "#undef XM\n#undef XN\n#undef XK\n#undef XBETA0\n#undef XTRANSB\n#undef XLDA\n#undef XLDB\n#undef XLDC\n#undef XPACK\n#undef XWAVES\n"
          "#undef XSCALAR\n#undef XRUNS\n#undef XDEPTH\n#undef XSPLIT\n#undef XHASWG\n#undef WINDOW_AB\n}\n";

@@ -36,7 +36,13 @@ LIBXSMM_API void* libxsmm_amd_get_stream(void);
  *  on the thread is ordered behind all recorded calls (an idle burst is also sealed by a helper thread after a few
  *  microseconds, so a caller's hipStreamSynchronize inside the bracket never hangs). Calls that depend on each other
  *  (a C read as A by a later call, a C written again later) are detected from the operand addresses and keep the call
- *  order. libxsmm_amd_defer_active(): 1 if calls of this thread are being recorded. */
+ *  order. libxsmm_amd_defer_active(): 1 if calls of this thread are being recorded.
+ *  Inside a bracket (not with the environment variable alone) the block calls of the spmdm interface on device operands,
+ *  libxsmm_spmdm_createSparseSlice_*_thread / libxsmm_spmdm_compute_*_thread (samples/spmdm/spmdm.c:99-109), are recorded
+ *  as well: consecutive calls of one kind on one handle with the same operands merge into rectangles of blocks, launched
+ *  -- one kernel per rectangle, one for a full sweep -- by whatever ends the record (a call of another kind or with other
+ *  operands, libxsmm_amd_flush / libxsmm_amd_defer_end, any other entry point of the library on the thread). They run at
+ *  the stream position of THAT moment; every block still touches only its own slices / C tile. */
 LIBXSMM_API void libxsmm_amd_defer_begin(void);
 LIBXSMM_API void libxsmm_amd_defer_end(void);
 LIBXSMM_API int libxsmm_amd_defer_active(void);

@@ -1147,9 +1147,13 @@ int launch_spmdm_compute_tiled(int M, int N, int K, int bm, int bk, int mb, int 
   const long long col_tiles = (n_end - n_begin + SPT_TN - 1) / SPT_TN;
   const long long total64 = (long long)mb_n * ((bm + 63) / 64) * col_tiles;
   // Tiles of 16 rows, four waves each, for calls that cover few tiles of 64 rows (a per-block call of the reference's interface: 64 tiles)
-  // were measured and are NOT the default: 2048^3 at 15 %, four block calls 0.450 ms against 0.462 ms. A work-group's time is set by
-  // its walk over the 32 column blocks of A -- 3.4 us each, the round trip of the next block's B panel, one block ahead -- whatever the
-  // height of its tile and however many work-groups run beside it (all 256 tiles in one call: 0.131 ms). XSMM_SPMDM_TILE_ROWS=16: developer knob.
+  // were measured and are NOT the default: 2048^3 at 15 %, four block calls 0.438 ms against 0.454 ms. A work-group walks the 32 column
+  // blocks of A, 3.4 us each. Taking the step apart (builds with the rows' work resp. the fetch compiled out): 64-row tiles, 64 work-groups: barriers + parking B 1.0 us, the
+  // panel's fetch + 0.4 us, the rows' entries + 2.1 us (a wave's 4 rows x ~10 entries as ~20 dependent LDS round trips; the FMA issue
+  // alone is 1.0 us at 16 waves per CU) -- a CU does the same work per step whether 64 or 256 work-groups run, so a block call takes as
+  // long as the whole problem (0.113 vs 0.125 ms). 16-row tiles: 0.9 + 0.7 + 1.8 us, and every panel of B is staged four times as often
+  // (2 GB through L2 for the whole problem: 0.265 ms). The caller's remedy is the bracket (xsmm_sparse.cpp:record_block): the block
+  // calls of a sweep become one launch, 0.125 ms. XSMM_SPMDM_TILE_ROWS=16: developer knob.
   static const int rows_env = []() { const char* e = getenv("XSMM_SPMDM_TILE_ROWS"); return (nullptr != e && 0 != *e) ? atoi(e) : 0; }();
   const bool small = (16 == rows_env);
   (void)total64;

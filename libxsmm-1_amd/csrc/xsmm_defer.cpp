@@ -246,8 +246,11 @@ bool open_burst(Ring& r, Kernel* k)
 
 } // namespace
 
+bool defer_bracket_open() { return 0 < tl_defer_bracket; }
+
 void defer_flush()
 {
+  if (tl_spmdm_open) spmdm_flush_record();
   if (!tl_defer_open || nullptr == tl_ring.ring) { tl_defer_open = false; return; }
   close_burst(*tl_ring.ring);
 }

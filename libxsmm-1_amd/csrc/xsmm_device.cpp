@@ -28,7 +28,7 @@ thread_local Scratch tl_scratch[8];
 // (Whoever asks for the stream is about to queue work or to wait for it: a burst of deferred per-call kernels that is still
 // open on this thread is sealed first, so that everything stays in the order of the calls -- xsmm_defer.cpp)
 Device& device_raw() { thread_local Device tl_device; tl_device.count = g_device.count; return tl_device; }
-Device& device() { if (tl_defer_open) defer_flush(); return device_raw(); }
+Device& device() { if (tl_defer_open || tl_spmdm_open) defer_flush(); return device_raw(); }
 
 bool device_ready()
 {

@@ -90,6 +90,9 @@ struct JitKernel;
 // per-panel calls of a fixed operator (libxsmm_?fsspmdm_execute) that walk along the rows of B and C: recorded like per-product calls
 bool defer_panels(const void* handle, JitKernel* jit, const void* B, void* C, int typesize, int M, int N, int K, long long ldb, long long ldc, int vec);                                                  // seal the calling thread's open burst
 extern thread_local bool tl_defer_open;
+extern thread_local bool tl_spmdm_open;   // spmdm block calls recorded inside a bracket (xsmm_sparse.cpp)
+void spmdm_flush_record();                // launches them
+bool defer_bracket_open();                // the calling thread is inside libxsmm_amd_defer_begin/end
 
 // CSR "register" kernel family (fsspmdm sparse path, libxsmm_create_?csr_reg): row-major
 // C[m*ldc+n] = (beta? C:0) + sum_p val[p]*B[col[p]*ldb+n], rows without nnz untouched.

@@ -248,6 +248,7 @@ LIBXSMM_API void libxsmm_spmdm_init(int M, int N, int K, int max_threads,
 LIBXSMM_API void libxsmm_spmdm_destroy(libxsmm_spmdm_handle* handle)
 {
   if (nullptr == handle) return;
+  spmdm_flush_record();
   if (device_ready()) (void)stream_sync();
   dev_free(handle->base_ptr_scratch_A); handle->base_ptr_scratch_A = nullptr;
   free(handle->base_ptr_scratch_B_scratch_C); handle->base_ptr_scratch_B_scratch_C = nullptr;
@@ -404,6 +405,117 @@ bool spmdm_block_ok(const libxsmm_spmdm_handle* handle, int block_id, int nblock
   (void)handle;
   return false;
 }
+
+// ---- a block call's work, for the row blocks [mb0, mb0 + mbn) resp. the C tiles [mb0, mb0 + mbn) x [n0, n1) ------------------------
+int create_blocks_f32(const libxsmm_spmdm_handle* handle, char transa, const float* a, int mb0, int mbn)
+{
+  return spmdm_create(handle, transa, a, mb0, mbn, false);
+}
+
+int create_blocks_bf16(const libxsmm_spmdm_handle* handle, char transa, const libxsmm_bfloat16* a, int mb0, int mbn)
+{ // only the rows of these blocks are widened (A as stored: they are contiguous; a transposed A: the whole matrix)
+  bool ok = true;
+  const size_t r0 = (size_t)mb0 * handle->bm, nr = (size_t)LIBXSMM_MIN(mbn * handle->bm, handle->m - (int)r0);
+  const bool rows_contiguous = !is_trans(transa);
+  const float* const da = widen_bf16(a, (size_t)handle->m * handle->k, 6, 3, &ok, rows_contiguous ? r0 * handle->k : 0, rows_contiguous ? nr * handle->k : 0);
+  if (!ok) return -1;
+  return spmdm_create(handle, transa, da, mb0, mbn, true, !is_device_ptr(a));
+}
+
+int compute_tiles_bf16(const libxsmm_spmdm_handle* handle, char transb, const libxsmm_bfloat16* b, char transc, float beta, float* c,
+                       int mb0, int mbn, int n0, int n1)
+{ // only the columns [n0, n1) of B are widened where they are one piece (a transposed B: rows of B^T; else: all of B)
+  bool ok = true;
+  const bool piece = is_trans(transb);
+  const float* const db = widen_bf16(b, (size_t)handle->k * handle->n, 6, 4, &ok, piece ? (size_t)n0 * handle->k : 0, piece ? (size_t)(n1 - n0) * handle->k : 0);
+  if (!ok) return -1;
+  return spmdm_compute(handle, transb, db, true, transc, beta, c, mb0, mbn, n0, n1, !is_device_ptr(b));
+}
+
+// ---- block calls inside a libxsmm_amd_defer_begin/end bracket ----------------------------------------------------------------------
+// The reference's caller walks the block ids (samples/spmdm/spmdm.c:99-109), one call per block; a call is a launch that covers a
+// fraction of the chip (2048^3: four of each kind, a quarter of the tiles each). Inside the bracket -- the caller's promise that it
+// queues nothing of its own on the stream that touches the operands before the bracket ends or libxsmm_amd_flush() is called -- calls of
+// one kind on one handle with the same operands (pure device memory) are only recorded: the blocks merge into rectangles of blocks, and
+// whatever ends the record (another kind of call, other operands, any other entry point of the library on this thread,
+// libxsmm_amd_flush / libxsmm_amd_defer_end) launches one kernel per rectangle -- one for a full sweep. Every block still touches only
+// its own slices / its own C tile; results are the same bits (the kernels are the ones a block call launches, on a wider range).
+// Outside a bracket, and for operands the CPU addresses, a call is a launch (and a copy) of its own, as before.
+struct SpmdmRect { int mb0, mbn, n0, n1; };
+struct SpmdmRecord {
+  int kind = 0;                         // 0: none, 1: createSparseSlice, 2: compute
+  libxsmm_spmdm_handle handle;          // (a copy: the caller's struct may be a temporary; the scratch pointers identify it)
+  const void* src = nullptr; bool bf16 = false; char trans = 'N', transc = 'N'; float beta = 0.f; float* c = nullptr;
+  std::vector<SpmdmRect> rects;
+};
+thread_local SpmdmRecord tl_record;
+
+bool pure_device(const void* p) { return is_device_ptr(p) && !is_host_visible(p); }
+
+// the new rectangle joins the last one when the two form a rectangle again (block ids ascend: row-major over (mb, nb))
+void add_rect(std::vector<SpmdmRect>& rects, SpmdmRect r)
+{
+  rects.push_back(r);
+  while (rects.size() >= 2) {
+    SpmdmRect& u = rects[rects.size() - 2]; const SpmdmRect& v = rects.back();
+    if (u.mb0 == v.mb0 && u.mbn == v.mbn && u.n1 == v.n0) u.n1 = v.n1;                 // next to it
+    else if (u.n0 == v.n0 && u.n1 == v.n1 && u.mb0 + u.mbn == v.mb0) u.mbn += v.mbn;   // below it
+    else break;
+    rects.pop_back();
+  }
+}
+
+bool record_block(int kind, const libxsmm_spmdm_handle* handle, const void* src, bool bf16, char trans, char transc, float beta, float* c, SpmdmRect r)
+{
+  if (!defer_bracket_open() || !pure_device(src) || (2 == kind && !pure_device(c))) return false;
+  SpmdmRecord& p = tl_record;
+  if (tl_spmdm_open && !(p.kind == kind && p.handle.base_ptr_scratch_A == handle->base_ptr_scratch_A && p.src == src && p.bf16 == bf16
+      && is_trans(p.trans) == is_trans(trans) && is_trans(p.transc) == is_trans(transc) && p.beta == beta && p.c == c)) spmdm_flush_record();
+  if (!tl_spmdm_open) {
+    p.kind = kind; p.handle = *handle; p.src = src; p.bf16 = bf16; p.trans = trans; p.transc = transc; p.beta = beta; p.c = c; p.rects.clear();
+    tl_spmdm_open = true;
+  }
+  for (const SpmdmRect& q : p.rects) { // a block that is recorded already (beta != 0: it must run twice): launch what is there first
+    if (q.mb0 < r.mb0 + r.mbn && r.mb0 < q.mb0 + q.mbn && q.n0 < r.n1 && r.n0 < q.n1) { spmdm_flush_record(); return record_block(kind, handle, src, bf16, trans, transc, beta, c, r); }
+  }
+  add_rect(p.rects, r);
+  return true;
+}
+}
+
+namespace xsmm {
+thread_local bool tl_spmdm_open = false;
+void spmdm_flush_record()
+{
+  if (!tl_spmdm_open) return;
+  tl_spmdm_open = false; // (first: the launches below ask for the stream, which flushes what is open)
+  SpmdmRecord& p = tl_record;
+  const libxsmm_spmdm_handle* const h = &p.handle;
+  if (1 == p.kind) {
+    for (const SpmdmRect& r : p.rects) {
+      if (0 == r.mb0 && r.mbn == h->mb) { // every row block: one launch
+        (void)(p.bf16 ? create_blocks_bf16(h, p.trans, static_cast<const libxsmm_bfloat16*>(p.src), 0, h->mb) : create_blocks_f32(h, p.trans, static_cast<const float*>(p.src), 0, h->mb));
+      }
+      else for (int mb = r.mb0; mb < r.mb0 + r.mbn; ++mb) { // (a slice range that is not every slice: a launch per row block)
+        (void)(p.bf16 ? create_blocks_bf16(h, p.trans, static_cast<const libxsmm_bfloat16*>(p.src), mb, 1) : create_blocks_f32(h, p.trans, static_cast<const float*>(p.src), mb, 1));
+      }
+    }
+  }
+  else if (2 == p.kind) {
+    const float* wide = nullptr;
+    if (p.bf16 && 1 < p.rects.size()) { // several rectangles: B is widened once
+      bool ok = true;
+      wide = widen_bf16(static_cast<const libxsmm_bfloat16*>(p.src), (size_t)h->k * h->n, 6, 4, &ok);
+      if (!ok) { p.rects.clear(); p.kind = 0; return; }
+    }
+    for (const SpmdmRect& r : p.rects) {
+      if (!p.bf16) (void)spmdm_compute(h, p.trans, static_cast<const float*>(p.src), false, p.transc, p.beta, p.c, r.mb0, r.mbn, r.n0, r.n1);
+      else if (nullptr != wide) (void)spmdm_compute(h, p.trans, wide, true, p.transc, p.beta, p.c, r.mb0, r.mbn, r.n0, r.n1, false);
+      else (void)compute_tiles_bf16(h, p.trans, static_cast<const libxsmm_bfloat16*>(p.src), p.transc, p.beta, p.c, r.mb0, r.mbn, r.n0, r.n1);
+    }
+  }
+  p.rects.clear(); p.kind = 0;
+}
 }
 
 LIBXSMM_API void libxsmm_spmdm_createSparseSlice_fp32_thread(const libxsmm_spmdm_handle* handle, char transa,
@@ -413,7 +525,8 @@ LIBXSMM_API void libxsmm_spmdm_createSparseSlice_fp32_thread(const libxsmm_spmdm
   if (nullptr == handle || nullptr == a || nullptr == libxsmm_output_csr_a || nullptr == handle->base_ptr_scratch_A) return;
   if (!device_ready()) { fail_no_device("libxsmm_spmdm_createSparseSlice_fp32_thread"); return; }
   if (!spmdm_block_ok(handle, block_id, handle->mb, "libxsmm_spmdm_createSparseSlice_fp32_thread")) return;
-  spmdm_create(handle, transa, a, block_id, 1, false);
+  if (record_block(1, handle, a, false, transa, 'N', 0.f, nullptr, SpmdmRect{ block_id, 1, 0, handle->n })) return;
+  (void)create_blocks_f32(handle, transa, a, block_id, 1);
 }
 
 LIBXSMM_API void libxsmm_spmdm_createSparseSlice_bfloat16_thread(const libxsmm_spmdm_handle* handle, char transa,
@@ -423,13 +536,8 @@ LIBXSMM_API void libxsmm_spmdm_createSparseSlice_bfloat16_thread(const libxsmm_s
   if (nullptr == handle || nullptr == a || nullptr == libxsmm_output_csr_a || nullptr == handle->base_ptr_scratch_A) return;
   if (!device_ready()) { fail_no_device("libxsmm_spmdm_createSparseSlice_bfloat16_thread"); return; }
   if (!spmdm_block_ok(handle, block_id, handle->mb, "libxsmm_spmdm_createSparseSlice_bfloat16_thread")) return;
-  bool ok = true;
-  // only the rows of this block are widened (A as stored: they are contiguous; a transposed A: the whole matrix)
-  const size_t r0 = (size_t)block_id * handle->bm, nr = (size_t)LIBXSMM_MIN(handle->bm, handle->m - (int)r0);
-  const bool rows_contiguous = !is_trans(transa);
-  const float* const da = widen_bf16(a, (size_t)handle->m * handle->k, 6, 3, &ok, rows_contiguous ? r0 * handle->k : 0, rows_contiguous ? nr * handle->k : 0);
-  if (!ok) return;
-  spmdm_create(handle, transa, da, block_id, 1, true, !is_device_ptr(a));
+  if (record_block(1, handle, a, true, transa, 'N', 0.f, nullptr, SpmdmRect{ block_id, 1, 0, handle->n })) return;
+  (void)create_blocks_bf16(handle, transa, a, block_id, 1);
 }
 
 LIBXSMM_API void libxsmm_spmdm_compute_fp32_thread(const libxsmm_spmdm_handle* handle, char transa, char transb,
@@ -441,7 +549,9 @@ LIBXSMM_API void libxsmm_spmdm_compute_fp32_thread(const libxsmm_spmdm_handle* h
   if (!device_ready()) { fail_no_device("libxsmm_spmdm_compute_fp32_thread"); return; }
   if (!spmdm_block_ok(handle, block_id, handle->mb * handle->nb, "libxsmm_spmdm_compute_fp32_thread")) return;
   const int mb = block_id / handle->nb, nb = block_id % handle->nb; // compute tpl :38-39
-  spmdm_compute(handle, transb, b, false, transc, *beta, c, mb, 1, nb * handle->bn, LIBXSMM_MIN((nb + 1) * handle->bn, handle->n));
+  const int n0 = nb * handle->bn, n1 = LIBXSMM_MIN((nb + 1) * handle->bn, handle->n);
+  if (record_block(2, handle, b, false, transb, transc, *beta, c, SpmdmRect{ mb, 1, n0, n1 })) return;
+  (void)spmdm_compute(handle, transb, b, false, transc, *beta, c, mb, 1, n0, n1);
 }
 
 LIBXSMM_API void libxsmm_spmdm_compute_bfloat16_thread(const libxsmm_spmdm_handle* handle, char transa, char transb,
@@ -454,14 +564,10 @@ LIBXSMM_API void libxsmm_spmdm_compute_bfloat16_thread(const libxsmm_spmdm_handl
   if (nullptr == handle || nullptr == a_sparse || nullptr == b || nullptr == c || nullptr == beta) return;
   if (!device_ready()) { fail_no_device("libxsmm_spmdm_compute_bfloat16_thread"); return; }
   if (!spmdm_block_ok(handle, block_id, handle->mb * handle->nb, "libxsmm_spmdm_compute_bfloat16_thread")) return;
-  bool ok = true;
   const int mb = block_id / handle->nb, nb = block_id % handle->nb;
   const int n0 = nb * handle->bn, n1 = LIBXSMM_MIN((nb + 1) * handle->bn, handle->n);
-  // only the columns [n0, n1) of B are widened where they are one piece (a transposed B: rows of B^T; one column block: all of B)
-  const bool piece = is_trans(transb);
-  const float* const db = widen_bf16(b, (size_t)handle->k * handle->n, 6, 4, &ok, piece ? (size_t)n0 * handle->k : 0, piece ? (size_t)(n1 - n0) * handle->k : 0);
-  if (!ok) return;
-  spmdm_compute(handle, transb, db, true, transc, (float)(*beta), c, mb, 1, n0, n1, !is_device_ptr(b));
+  if (record_block(2, handle, b, true, transb, transc, (float)(*beta), c, SpmdmRect{ mb, 1, n0, n1 })) return;
+  (void)compute_tiles_bf16(handle, transb, b, transc, (float)(*beta), c, mb, 1, n0, n1);
 }
 
 // ---- the whole problem in one call (extension) -------------------------------------------------------------------------

@@ -480,6 +480,161 @@ def test_spmdm_block_contract(xs, orc, torch_gpu):
     L.libxsmm_spmdm_destroy(C.byref(h))
 
 
+def test_spmdm_block_calls_inside_a_bracket(xs, orc, torch_gpu):
+    """Block calls on device operands inside libxsmm_amd_defer_begin/end are recorded and launched as rectangles of blocks
+    (samples/spmdm/spmdm.c:99-109 is the loop; xsmm_sparse.cpp:record_block): same bits as a launch per call, the block contract
+    (compute tpl :38-39, createSparseSlice tpl :47-141) unchanged. (i) a full sweep = one create launch + one compute launch,
+    equal to the oracle; (ii) a subset of the blocks: every other tile keeps its canary; (iii) libxsmm_amd_flush, then B rewritten
+    in place on the stream, then the next block: the second call sees the new B; (iv) other operands per block, and a block
+    recorded twice with beta = 1: nothing merges that must not; (v) the bfloat16 twins; (vi) host operands inside a bracket are
+    served at once."""
+    torch = torch_gpu
+    M, N, K = 1100, 2300, 150   # mb = 3, nb = 2, kb = 3 with the engine's geometry
+    a, b, c = spmdm_inputs(M, N, K, 0.85, 3, orc)
+    L = xs.lib()
+    h = xs.SpmdmHandle(); slices = C.POINTER(xs.CSRSlice)()
+    L.libxsmm_spmdm_init(M, N, K, 1, C.byref(h), C.byref(slices))
+    ncreate, ncomp = L.libxsmm_spmdm_get_num_createSparseSlice_blocks(C.byref(h)), L.libxsmm_spmdm_get_num_compute_blocks(C.byref(h))
+    assert ncreate == 3 and ncomp == 6 and h.nb == 2
+    geom = lambda: orc.spmdm_geometry(M, N, K, h.bm, h.bn, h.bk)
+    da, db, dc = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), torch.from_numpy(c).cuda()
+    alpha = C.c_float(1.0)
+
+    def create(blocks, src):
+        for blk in blocks:
+            L.libxsmm_spmdm_createSparseSlice_fp32_thread(C.byref(h), b"N", xs.dptr(src), slices, blk, 0, 1)
+
+    def compute(blk, beta, bsrc, cdst):
+        be = C.c_float(beta)
+        L.libxsmm_spmdm_compute_fp32_thread(C.byref(h), b"N", b"N", C.byref(alpha), slices, xs.dptr(bsrc), b"N", C.byref(be), xs.dptr(cdst), blk, 0, 1)
+
+    # (i) the sample's two loops inside one bracket
+    launches = L.libxsmm_amd_launch_count()
+    L.libxsmm_amd_defer_begin()
+    create(range(ncreate), da)
+    for blk in range(ncomp):
+        compute(blk, 0.5, db, dc)
+    assert L.libxsmm_amd_launch_count() <= launches + 1  # (the creates are launched when the first compute call arrives)
+    L.libxsmm_amd_defer_end()
+    assert L.libxsmm_amd_launch_count() == launches + 2
+    torch.cuda.synchronize()
+    ref = c.copy()
+    orc.spmdm_compute_blocks(orc.FMA, geom(), "N", "N", "N", 0.5, a, b, ref, list(range(ncomp)))
+    assert np.array_equal(dc.cpu().numpy(), ref)
+    # descending block ids: nothing merges, same result
+    dc.copy_(torch.from_numpy(c))
+    L.libxsmm_amd_defer_begin()
+    for blk in reversed(range(ncomp)):
+        compute(blk, 0.5, db, dc)
+    L.libxsmm_amd_defer_end()
+    torch.cuda.synchronize()
+    assert np.array_equal(dc.cpu().numpy(), ref)
+    # (ii) a subset: the other tiles keep their canaries bit for bit
+    canary = np.full(M * N, np.nan, dtype=np.float32)
+    canary.view(np.uint32)[:] = 0x7FC00000 + (np.arange(M * N, dtype=np.uint32) & 0xFFFF)
+    subset = [1, 2, 3, ncomp - 1]
+    dc.copy_(torch.from_numpy(canary))
+    launches = L.libxsmm_amd_launch_count()
+    L.libxsmm_amd_defer_begin()
+    for blk in subset:
+        compute(blk, 0.0, db, dc)
+    L.libxsmm_amd_defer_end()
+    assert L.libxsmm_amd_launch_count() == launches + 3   # (0,1) | (1,0)+(1,1) | (2,1)
+    torch.cuda.synchronize()
+    ref = canary.copy()
+    orc.spmdm_compute_blocks(orc.FMA, geom(), "N", "N", "N", 0.0, a, b, ref, subset)
+    out = dc.cpu().numpy()
+    assert np.array_equal(out.view(np.uint32), ref.view(np.uint32))
+    assert np.isnan(out).sum() == np.isnan(ref).sum() > 0
+    # (iii) the contract of the bracket: flush before own work on the stream that touches the operands
+    dc.copy_(torch.from_numpy(c)); dbm = torch.from_numpy(b).cuda()
+    b2 = (b * 0.5 + 0.25).astype(np.float32); db2 = torch.from_numpy(b2).cuda()
+    L.libxsmm_amd_defer_begin()
+    compute(0, 0.0, dbm, dc)
+    L.libxsmm_amd_flush()
+    dbm.copy_(db2)
+    compute(1, 0.0, dbm, dc)
+    L.libxsmm_amd_defer_end()
+    torch.cuda.synchronize()
+    ref = c.copy()
+    orc.spmdm_compute_blocks(orc.FMA, geom(), "N", "N", "N", 0.0, a, b, ref, [0])
+    orc.spmdm_compute_blocks(orc.FMA, geom(), "N", "N", "N", 0.0, a, b2, ref, [1])
+    assert np.array_equal(dc.cpu().numpy(), ref)
+    # (iv) other operands per call; one block twice (beta = 1: it must run twice)
+    dc.copy_(torch.from_numpy(c))
+    bs = [(b * (1.0 + 0.25 * i) + 0.125 * i).astype(np.float32) for i in range(ncomp)]
+    dbs = [torch.from_numpy(x).cuda() for x in bs]
+    L.libxsmm_amd_defer_begin()
+    for i in range(ncomp):
+        compute(i, 1.0, dbs[i], dc)
+    compute(2, 1.0, dbs[ncomp - 1], dc)
+    compute(2, 1.0, dbs[ncomp - 1], dc)
+    L.libxsmm_amd_defer_end()
+    torch.cuda.synchronize()
+    ref = c.copy()
+    for i in range(ncomp):
+        orc.spmdm_compute_blocks(orc.FMA, geom(), "N", "N", "N", 1.0, a, bs[i], ref, [i])
+    for _ in range(2):
+        orc.spmdm_compute_blocks(orc.FMA, geom(), "N", "N", "N", 1.0, a, bs[ncomp - 1], ref, [2])
+    assert np.array_equal(dc.cpu().numpy(), ref)
+    # create blocks of a changed A, two of three inside a bracket: exactly those slices change
+    before = _device_slices(xs, h, slices)
+    a2 = a.copy(); a2[::7] = 0.0; a2[3::11] *= 2.0; a2[a2 == 0.0] = 0.0
+    da2 = torch.from_numpy(a2).cuda()
+    redo = [0, ncreate - 1]
+    L.libxsmm_amd_defer_begin()
+    create(redo, da2)
+    L.libxsmm_amd_defer_end()
+    torch.cuda.synchronize()
+    after = _device_slices(xs, h, slices)
+    _, o2 = orc.spmdm_slices(M, N, K, 48, "N", a2, handle=geom())
+    for blk in range(h.mb * h.kb):
+        want = o2[blk] if (blk % h.mb) in redo else before[blk]
+        for x, y in zip(after[blk], want):
+            assert np.array_equal(x.view(np.uint16 if x.dtype == np.uint16 else np.uint32), y.view(np.uint16 if y.dtype == np.uint16 else np.uint32)), blk
+    # (vi) host operands inside the bracket: done on return
+    hc = c.copy()
+    L.libxsmm_amd_defer_begin()
+    create(range(ncreate), a)
+    for blk in range(ncomp):
+        compute(blk, 0.5, b, hc)
+        if blk == 0:
+            snapshot = hc.copy()
+    L.libxsmm_amd_defer_end()
+    ref = c.copy()
+    orc.spmdm_compute_blocks(orc.FMA, geom(), "N", "N", "N", 0.5, a, b, ref, [0])
+    assert np.array_equal(snapshot, ref)
+    orc.spmdm_compute_blocks(orc.FMA, geom(), "N", "N", "N", 0.5, a, b, ref, list(range(1, ncomp)))
+    assert np.array_equal(hc, ref)
+    L.libxsmm_spmdm_destroy(C.byref(h))
+    # (v) the bfloat16 twins, transposed and not: bracket == launch per call, bit for bit
+    for ta, tb, tc in (("N", "N", "N"), ("T", "T", "T")):
+        a16 = (a.view(np.uint32) >> 16).astype(np.uint16); b16 = (b.view(np.uint32) >> 16).astype(np.uint16)
+        outs = []
+        for bracket in (False, True):
+            h2 = xs.SpmdmHandle(); sl2 = C.POINTER(xs.CSRSlice)()
+            L.libxsmm_spmdm_init(M, N, K, 1, C.byref(h2), C.byref(sl2))
+            xa, xb, xc = torch.from_numpy(a16.view(np.int16)).cuda(), torch.from_numpy(b16.view(np.int16)).cuda(), torch.from_numpy(c).cuda()
+            al, be = C.c_ushort(0x3F80), C.c_ushort(1)
+            launches = L.libxsmm_amd_launch_count()
+            if bracket:
+                L.libxsmm_amd_defer_begin()
+            for blk in range(ncreate):
+                L.libxsmm_spmdm_createSparseSlice_bfloat16_thread(C.byref(h2), ta.encode(), xs.dptr(xa), sl2, blk, 0, 1)
+            for blk in range(ncomp):
+                L.libxsmm_spmdm_compute_bfloat16_thread(C.byref(h2), ta.encode(), tb.encode(), C.byref(al), sl2, xs.dptr(xb), tc.encode(),
+                                                        C.byref(be), xs.dptr(xc), blk, 0, 1)
+            if bracket:
+                L.libxsmm_amd_defer_end()
+                assert L.libxsmm_amd_launch_count() == launches + 4   # widen + create, widen + compute
+            torch.cuda.synchronize()
+            outs.append(xc.cpu().numpy())
+            L.libxsmm_spmdm_destroy(C.byref(h2))
+        ref = c.copy()
+        orc.spmdm_exec_bf16(orc.FMA, M, N, K, 48, ta, tb, tc, 1, a16, b16, ref)
+        assert np.array_equal(outs[0], ref) and np.array_equal(outs[1], ref), (ta, tb, tc)
+
+
 @pytest.mark.parametrize("case", [
     # M, N, K, keep-threshold, (ta, tb, tc), beta
     (700, 515, 330, 0.85, ("N", "N", "N"), 1.0),     # N % 4 != 0: element-wide global accesses

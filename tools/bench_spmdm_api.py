@@ -59,12 +59,37 @@ def compute_all():
     L.libxsmm_amd_spmdm_compute_all(C.byref(h), b"N", b"N", C.byref(alpha), slices, xs.dptr(b), b"N", C.byref(beta), xs.dptr(c))
 
 
+def bracketed(fn):
+    """the same block calls inside libxsmm_amd_defer_begin/end: recorded, launched as one range when the bracket ends"""
+    def run():
+        L.libxsmm_amd_defer_begin(); fn(); L.libxsmm_amd_defer_end()
+    return run
+
+
+# the bfloat16 twins of the two loops (include/libxsmm_spmdm.h:98-133): operands are upper halves of floats
+a16 = (a.view(torch.int32) >> 16).to(torch.int16); b16 = (b.view(torch.int32) >> 16).to(torch.int16)
+alpha16, beta16 = C.c_ushort(0x3F80), C.c_ushort(0)
+
+
+def create_blocks_bf16():
+    for blk in range(nc):
+        L.libxsmm_spmdm_createSparseSlice_bfloat16_thread(C.byref(h), b"N", xs.dptr(a16), slices, blk, 0, 1)
+
+
+def compute_blocks_bf16():
+    for blk in range(nx):
+        L.libxsmm_spmdm_compute_bfloat16_thread(C.byref(h), b"N", b"N", C.byref(alpha16), slices, xs.dptr(b16), b"N", C.byref(beta16), xs.dptr(c), blk, 0, 1)
+
+
 L.libxsmm_amd_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream))
 nnz = float((a != 0).sum().item())
 print("spmdm %d^3 density %.2f: bm=%d bn=%d bk=%d, %d create blocks, %d compute blocks" % (n, density, h.bm, h.bn, h.bk, nc, nx))
 for name, fn, flops in (("createSparseSlice per block", create_blocks, 0.0), ("createSparseSlice_all", create_all, 0.0),
-                        ("compute per block", compute_blocks, 2.0 * nnz * N), ("compute_all", compute_all, 2.0 * nnz * N)):
+                        ("compute per block", compute_blocks, 2.0 * nnz * N), ("compute_all", compute_all, 2.0 * nnz * N),
+                        ("create per block, bracket", bracketed(create_blocks), 0.0), ("compute per block, bracket", bracketed(compute_blocks), 2.0 * nnz * N),
+                        ("bf16 create per block", create_blocks_bf16, 0.0), ("bf16 compute per block", compute_blocks_bf16, 2.0 * nnz * N),
+                        ("bf16 create per block, bracket", bracketed(create_blocks_bf16), 0.0), ("bf16 compute per block, bracket", bracketed(compute_blocks_bf16), 2.0 * nnz * N)):
     ms = timed(fn, reps)
     extra = ("  %.0f GFLOP/s (sparse flops), %.0f GFLOP/s dense-equivalent" % (flops / ms / 1e6, 2.0 * M * N * K / ms / 1e6)) if flops else ("  %.0f GB/s of A" % (4.0 * M * K / ms / 1e6))
-    print("  %-30s %8.3f ms  [%s]%s" % (name, ms, xs.last_kernel(), extra))
+    print("  %-34s %8.3f ms  [%s]%s" % (name, ms, xs.last_kernel(), extra))
 L.libxsmm_spmdm_destroy(C.byref(h))

@@ -112,10 +112,20 @@ def main():
             time.sleep(2.0)  # (the launcher ends the other ranks as soon as one has failed: let each say why first)
         raise SystemExit(1)
     dist = None
+    # BENCH_SHARED_GPU=1: a rehearsal of the N-rank path on a box with ONE card (launcher, barriers, max over ranks, the summed
+    # value): every rank runs on cuda:0 and the ranks meet over gloo -- RCCL refuses two ranks on one device. Not a measurement.
+    shared = (world > 1 and "1" == os.environ.get("BENCH_SHARED_GPU", ""))
+    if shared:
+        if args.config in (4, 5):
+            raise SystemExit("BENCH_SHARED_GPU rehearses the headline configuration only (configs 4/5 exchange data over RCCL)")
+        local = 0
     if world > 1:
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist_mod.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        if shared:
+            dist_mod.init_process_group(backend="gloo")
+        else:
+            dist_mod.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
         dist = dist_mod
     torch.cuda.set_device(local)
     xs = importlib.import_module("libxsmm-1_amd")

@@ -133,7 +133,8 @@ enum { SMM_JIT_SCALAR = 1, SMM_JIT_RUNS = 2, SMM_JIT_WGRUNS = 4, SMM_JIT_HASWG =
        SMM_JIT_MFMA = 64 /* matrix-core work-group kernel (kernels/smm_mfma_wg.inc) with the shape baked in; + 128: tight fp32 operands as 16-byte chunks */, SMM_JIT_MFMA_TIGHT = 128, SMM_JIT_MFMA_TIGHTC = 8192 /* fp32: C as a contiguous array through LDS */,
        SMM_JIT_MFMA_WAVE = 16384 /* matrix-core kernel with one wave per item (16x16x4 tiles) */,
        SMM_JIT_MFMA_WAVE2 = 32768 /* ... the columns of C in two halves against one image of A (fp64 56^3: the images of a whole item leave no room for four waves per CU) */,
-       SMM_JIT_MFMA_RUNS = 65536 /* run form on the matrix cores: a wave per run, A fragments straight from memory, B through LDS (M, N <= 32) */ }; // variant bits of the generated dense kernel
+       SMM_JIT_MFMA_RUNS = 65536 /* run form on the matrix cores: a wave per run, A fragments straight from memory, B through LDS (M, N <= 32) */,
+       SMM_JIT_DEEP = 131072 /* grouped bodies of a batch split into tiles of C: few waves on the chip, as many products in flight per wave as the wait counter allows */ }; // variant bits of the generated dense kernel
 std::string gen_smm_source(int typesize, int m, int n, int k, int flags, int variant, int lda = 0, int ldb = 0, int ldc = 0); // (0: tight)
 bool smm_jit_eligible(const SmmBatch& s);
 int launch_smm_jit(const SmmBatch& s, void* stream, const char** name); // -1: not available
@@ -141,7 +142,7 @@ int launch_smm_jit_mfma(const SmmBatch& s, void* stream, const char** name); // 
 int launch_smm_jit_lowp(const SmmBatch& s, void* stream, const char** name); // 16-bit inputs on the specialised streaming form; -1: not applicable
 bool smm_jit_grouped_eligible(const SmmBatch& s);
 int smm_jit_prebuild(const SmmBatch* shapes, int nshapes, int grouped, int* built); // code objects into the cache on disk; returns failures
-std::string gen_smm_grouped_source_for(const SmmBatch* groups, int ngroups);
+std::string gen_smm_grouped_source_for(const SmmBatch* groups, int ngroups, bool tiles = false);
 int launch_smm_jit_grouped(const SmmBatch* groups, int ngroups, void* stream, const char** name); // several batches, one launch; -1: not available
 int launch_c_order_check_groups(const SmmBatch* groups, int ngroups, void* stream); // one check launch for up to 32 batches (each with its devflags slot)
 int jit_launch_dyn(JitKernel* k, unsigned blocks, unsigned threads, unsigned lds_bytes, void** args, void* stream);

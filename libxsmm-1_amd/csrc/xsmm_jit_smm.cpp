@@ -1562,13 +1562,13 @@ static size_t smm_mfma_runs_lds(int typesize, int m, int n, int k, int ldb, bool
   return (size_t)(((n * ksd + 3) / 4) * 4) * typesize;
 }
 // products in flight per wave (register sets): as many as fit ~80 registers, four at most
-static int smm_mfma_runs_depth(int typesize, int m, int n, int k, int ldb)
-{
+static int smm_mfma_runs_depth(int typesize, int m, int n, int k, int ldb, bool deep = false)
+{ // deep: the tiles of a batch of few runs (smm_tile_split) -- a wave or two per SIMD, the registers are there
   static const int env = []() { const char* e = getenv("XSMM_SMMJIT_MFMA_RUNS_DEPTH"); return (nullptr != e && 0 != *e) ? atoi(e) : 0; }(); // developer knob
   if (0 < env) return env > 4 ? 4 : env;
   if (ldb < k) ldb = k;
   const int regs = (typesize / 4) * (((k + 3) / 4) * ((m + 15) / 16) + (ldb * (n - 1) + k + 63) / 64);
-  const int d = 80 / (regs > 0 ? regs : 1);
+  const int d = (deep ? 128 : 80) / (regs > 0 ? regs : 1);
   return d < 1 ? 1 : (d > 4 ? 4 : d);
 }
 // hand-counted waits in the software pipeline of the run form (XSMM_SMMJIT_HANDWAIT=0: the compiler's: developer knob)
@@ -2131,7 +2131,7 @@ std::string gen_smm_grouped_source(int typesize, const std::vector<GroupedBody>&
     s += "#define XWAVES 1\n"; // (wave bodies: a work-group is one wave, see below)
     s += std::string("#define XSCALAR ") + ((b.variant & SMM_JIT_SCALAR) ? "1" : "0") + "\n";
     s += std::string("#define XRUNS ") + ((b.variant & SMM_JIT_WGRUNS) ? "2" : "1") + "\n";
-    s += "#define XDEPTH " + std::to_string(0 != (b.variant & SMM_JIT_MFMA_RUNS) ? smm_mfma_runs_depth(typesize, b.m, b.n, b.k, b.ldb) : smm_jit_depth(typesize, b.m, b.n, b.k, b.variant)) + "\n";
+    s += "#define XDEPTH " + std::to_string(0 != (b.variant & SMM_JIT_MFMA_RUNS) ? smm_mfma_runs_depth(typesize, b.m, b.n, b.k, b.ldb, 0 != (b.variant & SMM_JIT_DEEP)) : smm_jit_depth(typesize, b.m, b.n, b.k, b.variant)) + "\n";
     s += std::string("#define XSPLIT ") + ((b.variant & SMM_JIT_SPLIT) ? "1" : "0") + "\n";
     s += std::string("#define XHASWG ") + ((b.variant & SMM_JIT_HASWG) ? "1" : "0") + "\n";
     if (0 != (b.variant & SMM_JIT_MFMA_RUNS)) { s += "#define XSTREAM 0\n#define XHANDWAIT " + std::to_string(smm_mfma_handwait()) + "\n"; s += SMM_JIT_MFMA_RUNS_CONST; s += SMM_JIT_CHAIN; s += SMM_JIT_MFMA_RUNS_KERNEL; s += "#undef XNROW\n#undef XSTREAM\n#undef XHANDWAIT\n"; }
@@ -2206,13 +2206,13 @@ struct GroupedPlan { GroupedKey key; std::vector<GroupedEntry> entries; size_t l
 // work-group form (four waves share a product; better for a batch of large shapes on its own) as a second kernel beside
 // the first was measured slower -- 27 CP2K shapes, fp64: 1.36 ms with it (its kernel took 0.94 ms next to the wave kernel,
 // 0.32 ms alone), 1.18 ms with all chains on the wave form.
-bool grouped_plan(const SmmBatch* groups, int ngroups, bool check_eligible, GroupedPlan& plan)
-{
+bool grouped_plan(const SmmBatch* groups, int ngroups, bool check_eligible, GroupedPlan& plan, bool tiles = false)
+{ // tiles: the groups are the tiles of one batch of few runs (smm_tile_split)
   plan.key.typesize = groups[0].typesize; plan.key.threads = 64; plan.key.bodies.clear(); plan.entries.clear(); plan.lds_max = 0;
   for (int g = 0; g < ngroups; ++g) {
     const SmmBatch& s = groups[g];
     if (s.typesize != groups[0].typesize || (check_eligible && !smm_jit_grouped_eligible(s))) return false;
-    const int variant = smm_mfma_runs_ok(s) ? (SMM_JIT_SCALAR | (0 != s.relaxed ? SMM_JIT_SPLIT : 0) | SMM_JIT_RUNS | SMM_JIT_MFMA_RUNS)
+    const int variant = smm_mfma_runs_ok(s) ? (SMM_JIT_SCALAR | (0 != s.relaxed ? SMM_JIT_SPLIT : 0) | SMM_JIT_RUNS | SMM_JIT_MFMA_RUNS | (tiles ? SMM_JIT_DEEP : 0))
                                             : (smm_jit_width_variant(s) | (0 != s.relaxed ? SMM_JIT_SPLIT : 0) | SMM_JIT_RUNS);
     const GroupedBody body = { s.m, s.n, s.k, s.flags & (LIBXSMM_GEMM_FLAG_BETA_0 | LIBXSMM_GEMM_FLAG_TRANS_B), variant, s.lda, s.ldb, s.ldc };
     size_t bi = 0;
@@ -2248,18 +2248,24 @@ JitKernel* grouped_kernel(const GroupedKey& key)
 }
 
 // the text a grouped launch of these batches compiles (tests: valid gfx950 code without a device)
-std::string gen_smm_grouped_source_for(const SmmBatch* groups, int ngroups)
+std::string gen_smm_grouped_source_for(const SmmBatch* groups, int ngroups, bool tiles)
 {
   GroupedPlan plan;
-  if (ngroups < 1 || !grouped_plan(groups, ngroups, false, plan)) return std::string();
+  if (ngroups < 1 || !grouped_plan(groups, ngroups, false, plan, tiles)) return std::string();
   return gen_smm_grouped_source(plan.key.typesize, plan.key.bodies, plan.key.threads);
 }
 
+static int launch_smm_jit_grouped_checked(const SmmBatch* groups, int ngroups, bool check_eligible, void* stream, const char** name);
 int launch_smm_jit_grouped(const SmmBatch* groups, int ngroups, void* stream, const char** name)
+{
+  return launch_smm_jit_grouped_checked(groups, ngroups, true, stream, name);
+}
+
+static int launch_smm_jit_grouped_checked(const SmmBatch* groups, int ngroups, bool check_eligible, void* stream, const char** name)
 {
   if (ngroups < 1) return -1;
   GroupedPlan plan;
-  if (!grouped_plan(groups, ngroups, true, plan) || plan.lds_max > 65536) return -1;
+  if (!grouped_plan(groups, ngroups, check_eligible, plan, !check_eligible) || plan.lds_max > 65536) return -1;
   JitKernel* const kern = grouped_kernel(plan.key);
   if (nullptr == kern) return -1;
   struct DevAddrH { const char* a; const char* b; char* c; const char* ia; const char* ib; const char* ic; long long sa, sb, sc; int index_base, index_stride, mode; const int* flags; };
@@ -2450,6 +2456,42 @@ int launch_smm_jit_lowp(const SmmBatch& s, void* stream, const char** name)
   return smm_jit_launch_variant(j, variant, stream);
 }
 
+// A batch of few runs whose C has several 16 x 16 tiles (one call per CP2K stack: 19 418 products of 32^3 are 172 runs -- 172 waves on
+// a chip that holds thousands, each a chain of ~110 dependent products): every tile of C becomes a batch of its own -- the sub-matrices
+// A(16 mi.., :), B(:, 16 ni..), C(16 mi.., 16 ni..) under the same leading dimensions, index arrays and ordering verdict -- and the
+// tiles run as the groups of one grouped launch: a wave per run AND tile, a quarter of the matrix instructions and half of the
+// operand loads per product and wave. Every element of C still receives its own chain in batch order: the same bits.
+// Returns the number of tile batches written to out[<= 4] (0: not split).
+static int smm_tile_split(const SmmBatch& s, SmmBatch* out)
+{
+  const char* const on_env = getenv("XSMM_SMMJIT_TILESPLIT"); // developer knob (re-read on every call: the tests toggle it)
+  const int on = (nullptr != on_env && 0 != *on_env) ? atoi(on_env) : 1;
+  static const int max_waves = []() { const char* e = getenv("XSMM_SMMJIT_TILESPLIT_WAVES"); return (nullptr != e && 0 != *e) ? atoi(e) : 1280; }(); // developer knob
+  const int mi = (s.m + 15) / 16, ni = (s.n + 15) / 16;
+  if (0 == on || mi * ni < 2 || mi * ni > 4 || SYNC_DEVICE != s.sync || (ADDR_STRIDED != s.mode && ADDR_INDEX != s.mode)) return 0;
+  // Every tile's wave fetches its rows of A and its columns of B: twice the requests of a wave per product. Measured (tools/bench_tile_split.py,
+  // profiles/r3_tile_split.txt; fp64 32^3, ms split / not split): 2 000 items 0.08-0.16 / 0.12-0.31, 8 000 items 0.08-0.16 / 0.12-0.31, 16 000 items
+  // equal for runs up to 32 and 0.17 / 0.31 for runs of 256, 30 000 items 0.20-0.28 / 0.13-0.27 for runs up to 32 (0.19 / 0.31 for runs of
+  // 256), 60 000 items 0.37-0.61 / 0.18-0.37: split while the batch cannot fill the chip anyway (the run lengths are known on the device only).
+  if (((s.batch + 63) / 64) * mi * ni > max_waves) return 0;
+  int n = 0;
+  for (int j = 0; j < ni; ++j) {
+    for (int i = 0; i < mi; ++i) {
+      SmmBatch t = s;
+      t.m = (s.m - 16 * i < 16) ? (s.m - 16 * i) : 16; t.n = (s.n - 16 * j < 16) ? (s.n - 16 * j) : 16;
+      t.a = static_cast<const char*>(s.a) + (size_t)16 * i * s.typesize;
+      t.b = static_cast<const char*>(s.b) + (size_t)16 * j * s.ldb * s.typesize;
+      t.c = static_cast<char*>(s.c) + ((size_t)16 * j * s.ldc + (size_t)16 * i) * s.typesize;
+      // (the batch as a whole has passed smm_jit_eligible; its rule about leading dimensions with gaps -- an operand's whole span is
+      // fetched -- does not apply to a tile: the matrix-core form requests A and C element by element through their leading dimensions,
+      // and B's span of a tile is the tile's columns)
+      if (!smm_mfma_runs_ok(t)) return 0;
+      out[n++] = t;
+    }
+  }
+  return n;
+}
+
 int launch_smm_jit(const SmmBatch& s, void* stream, const char** name)
 { // returns -1 when no specialised kernel is available
   const int width = smm_jit_width_variant(s);
@@ -2493,6 +2535,18 @@ int launch_smm_jit(const SmmBatch& s, void* stream, const char** name)
     return smm_jit_launch_variant(s, width, stream);
   }
   if (smm_mfma_runs_ok(s)) { // shared C on the matrix cores: a wave per run (batch order; segments + atomics if the verdict or a relaxed order say so)
+    { SmmBatch tiles[4];
+      int nt = smm_tile_split(s, tiles);
+      if (1 < nt) { // (the table of a grouped launch travels through a pinned staging buffer that later calls reuse: not inside a stream capture)
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipSuccess != hipStreamIsCapturing((hipStream_t)stream, &cap)) { (void)hipGetLastError(); cap = hipStreamCaptureStatusActive; }
+        if (hipStreamCaptureStatusNone != cap) nt = 0;
+      }
+      if (1 < nt) {
+        const int e = launch_smm_jit_grouped_checked(tiles, nt, false, stream, name);
+        if (0 <= e) { *name = f64 ? "smm_f64_mfma_runs_tiles_jit" : "smm_f32_mfma_runs_tiles_jit"; return e; }
+      }
+    }
     const int e = smm_jit_launch_variant(s, SMM_JIT_SCALAR | (0 != s.relaxed ? SMM_JIT_SPLIT : 0) | SMM_JIT_RUNS | SMM_JIT_MFMA_RUNS, stream);
     if (0 <= e) { *name = f64 ? "smm_f64_mfma_runs_jit" : "smm_f32_mfma_runs_jit"; return e; }
   }
@@ -2581,6 +2635,13 @@ int smm_jit_prebuild(const SmmBatch* shapes, int nshapes, int grouped, int* buil
         if (smm_jit_grouped_eligible(s) && s.typesize == shapes[0].typesize) g.push_back(s);
       }
       if (1 < g.size()) build(gen_smm_grouped_source_for(g.data(), (int)g.size()));
+    }
+    // one call per shape with few runs: the tiles of C as groups (smm_tile_split)
+    for (int i = 0; i < nshapes; ++i) {
+      SmmBatch s = shapes[i]; s.mode = ADDR_INDEX; s.batch = 64; s.sync = SYNC_DEVICE; s.relaxed = 0; s.jit_always = 1; s.c_atomics = 1; s.use_mfma = 1;
+      SmmBatch tiles[4];
+      const int nt = (0 == (s.flags & LIBXSMM_GEMM_FLAG_BETA_0)) ? smm_tile_split(s, tiles) : 0;
+      if (1 < nt) build(gen_smm_grouped_source_for(tiles, nt, true));
     }
   }
   if (nullptr != built) *built = done;

@@ -161,7 +161,7 @@ def test_blocked_gemm_on_the_specialised_run_kernels(xs, torch_gpu, dtype, geom,
         elif mfma and ts == 4 and (bm, bn, bk) == (32, 32, 32):
             expect = "smm_f32_32x32x32_mfma_runs"
         elif mfma:  # blocks up to 32: the run form on the matrix cores (a wave per C block, C in the accumulators across its k blocks)
-            expect = "_mfma_runs_jit"
+            expect = "_mfma_runs_"  # (_jit: a wave per run; _tiles_jit: small lists -- a wave per run and 16 x 16 tile of C)
         assert expect in xs.last_kernel(), xs.last_kernel()
         out = torch.empty_like(dc)
         assert 0 == L.libxsmm_blocked_gemm_copyout_c(h, xs.dptr(bc), C.byref(ldm), xs.dptr(out))

@@ -17,40 +17,50 @@ pytestmark = pytest.mark.gpu
 
 
 class _Jit:
-    """small test batches on the run-time specialised kernels, matrix cores on (the default policy) or off"""
-    def __init__(self, xs, mfma=1):
-        self.xs = xs; self.mfma = mfma
+    """small test batches on the run-time specialised kernels, matrix cores on (the default policy) or off; tiles: a batch of few runs
+    whose C has several 16 x 16 tiles runs a wave per run and TILE (xsmm_jit_smm.cpp:smm_tile_split; the default) or per run"""
+    def __init__(self, xs, mfma=1, tiles=1):
+        self.xs = xs; self.mfma = mfma; self.tiles = tiles
 
     def __enter__(self):
-        self.old_env = os.environ.get("LIBXSMM_AMD_JIT_MINBATCH")
+        self.old_env = {k: os.environ.get(k) for k in ("LIBXSMM_AMD_JIT_MINBATCH", "XSMM_SMMJIT_TILESPLIT")}
         os.environ["LIBXSMM_AMD_JIT_MINBATCH"] = "1"
+        os.environ["XSMM_SMMJIT_TILESPLIT"] = str(self.tiles)
         self.old = self.xs.lib().libxsmm_amd_set_mfma(self.mfma)
 
     def __exit__(self, *exc):
         self.xs.lib().libxsmm_amd_set_mfma(self.old)
-        if self.old_env is None:
-            del os.environ["LIBXSMM_AMD_JIT_MINBATCH"]
-        else:
-            os.environ["LIBXSMM_AMD_JIT_MINBATCH"] = self.old_env
+        for k, v in self.old_env.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+
+
+def runs_kernel(dtype, m, n, tiles=1):
+    """the kernel a small index batch with shared C blocks lands on"""
+    split = tiles and (m > 16 or n > 16)
+    return "smm_f%d_mfma_runs_%sjit" % (64 if np.dtype(dtype) == np.float64 else 32, "tiles_" if split else "")
 
 
 SHAPES = [(13, 13, 13), (23, 23, 23), (32, 32, 32), (32, 13, 23), (13, 32, 32), (5, 7, 3), (16, 16, 16), (1, 1, 1), (17, 31, 29), (32, 32, 64), (9, 20, 2),
           (31, 2, 63)]
 
 
+@pytest.mark.parametrize("tiles", [1, 0])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("shape", SHAPES)
-def test_runs_on_the_matrix_cores_bitexact(xs, orc, torch_gpu, dtype, shape):
+def test_runs_on_the_matrix_cores_bitexact(xs, orc, torch_gpu, dtype, shape, tiles):
     """index batches: (1) permuted operands, every item its own C (index_base 1); (2) runs of 1 ... 200 products with gaps between
-    the C blocks that are used"""
+    the C blocks that are used. A wave per run, or -- these batches are small -- per run and 16 x 16 tile of C: the same bits"""
     torch = torch_gpu
     m, n, k = shape
     batch = 777
     rng = np.random.default_rng(m * 31 + n * 7 + k)
     prec = xs.F64 if dtype == np.float64 else xs.F32
     a = rng.uniform(-1, 1, batch * m * k).astype(dtype); b = rng.uniform(-1, 1, batch * k * n).astype(dtype)
-    want = "smm_f%d_mfma_runs_jit" % (64 if dtype == np.float64 else 32)
-    with _Jit(xs):
+    want = runs_kernel(dtype, m, n, tiles)
+    with _Jit(xs, tiles=tiles):
         c = rng.uniform(-1, 1, batch * m * n).astype(dtype)
         sa = (rng.permutation(batch) * m * k + 1).astype(np.int32); sb = (rng.permutation(batch) * k * n + 1).astype(np.int32)
         sc = (np.arange(batch) * m * n + 1).astype(np.int32)
@@ -144,7 +154,7 @@ def test_runs_with_gaps_in_the_leading_dimensions(xs, orc, torch_gpu, dtype, sha
         da, db, dc = (torch.from_numpy(x).cuda() for x in (a, b, c))
         xs.gemm_batch(prec, "N", "N", m, n, k, 1.0, da, lda, db, ldb, 1.0, dc, ldc, 0, 4, sa, sb, sc, batch)
         torch.cuda.synchronize()
-        assert xs.last_kernel().endswith("_mfma_runs_jit"), xs.last_kernel()
+        assert xs.last_kernel() == runs_kernel(dtype, m, n), xs.last_kernel()
     assert np.array_equal(dc.cpu().numpy(), ref)
 
 
@@ -174,7 +184,7 @@ def test_relaxed_order_on_the_matrix_cores(xs, orc, torch_gpu, dtype, shape):
         dc = torch.from_numpy(c).cuda()
         xs.gemm_batch(prec, "N", "N", m, n, k, 1.0, da, m, db, k, 1.0, dc, m, 0, 4, sa, sb, sc, batch, omp=True)
         torch.cuda.synchronize()
-        assert xs.last_kernel().endswith("_mfma_runs_jit"), xs.last_kernel()
+        assert xs.last_kernel() == runs_kernel(dtype, m, n), xs.last_kernel()
     out = dc.cpu().numpy()
     tol = np.finfo(dtype).eps * np.sqrt(float(lens.max()) * k) * 4
     assert np.max(np.abs(out - ref)) <= tol * np.max(np.abs(ref))

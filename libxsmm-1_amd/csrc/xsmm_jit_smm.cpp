@@ -1370,14 +1370,17 @@ extern "C" __global__ __launch_bounds__(64 * XWAVES) void xsmm_smm_op(DevAddr ad
 #if XGROUPED
 __device__ XENTRY_ATTR void xsmm_entry(const DevAddr& ad, long long batch, unsigned xbid, unsigned xgrid, T* lds)
 {
+#if !XTILEWG
   if ((int)(threadIdx.x >> 6) >= XWAVES) return; // (the grouped kernel's work-groups may have more waves than this body uses)
+#endif
 #else
 extern "C" __global__ __launch_bounds__(64 * XWAVES) void xsmm_smm_op(DevAddr ad, long long batch)
 {
   __shared__ __attribute__((aligned(16))) T lds[XWAVES * WAVE_LDS];
   const unsigned xbid = blockIdx.x, xgrid = gridDim.x;
 #endif
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, l16 = lane & 15, lq = lane >> 4;
+  // (XTILEWG: the waves of a work-group are the tiles of C of ONE walk -- each wave is the only wave of its body, lds is its own)
+  const int wave = XTILEWG ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, l16 = lane & 15, lq = lane >> 4;
   T* const Bs = lds + wave * WAVE_LDS;
   const long long w = (long long)xbid * XWAVES + wave, W = (long long)xgrid * XWAVES;
   // (walking the batch: chunks of 64 items, run heads, segments -- see the register-tiled wave form)
@@ -1576,6 +1579,16 @@ static int smm_mfma_handwait()
 {
   static const int env = []() { const char* e = getenv("XSMM_SMMJIT_HANDWAIT"); return (nullptr != e && 0 != *e) ? atoi(e) : 1; }();
   return 0 != env ? 1 : 0;
+}
+// XSMM_SMMJIT_TILESPLIT=2 (developer knob, re-read on every call): the tiles of a run as the waves of ONE work-group instead of work-groups
+// of one wave wherever the dispatcher puts them. Measured (profiles/r3_tile_split.txt): the tiles then share a CU's memory pipeline -- 10-20 %
+// faster for batches of 16 000-30 000 items in short runs (the halves of A and B two tiles share are requested from one CU), but a long run
+// is walked SLOWER than by a single wave (runs of 256: 0.41 ms against 0.18 ms for the tiles as groups and 0.31 ms for a wave per run; one
+// CP2K stack 0.19 against 0.14 ms): not the default.
+static int smm_tile_wg()
+{
+  const char* const e = getenv("XSMM_SMMJIT_TILESPLIT");
+  return (nullptr != e && 2 == atoi(e)) ? 1 : 0;
 }
 static int smm_mfma_runs_waves(size_t lds) { return (0 == lds) ? 0 : ((4 * lds <= 65536) ? 4 : ((2 * lds <= 65536) ? 2 : 1)); }
 // may batch s (shared C: runs) take that form?
@@ -1846,6 +1859,7 @@ std::string gen_smm_source(int typesize, int m, int n, int k, int flags, int var
     s += "#define XHANDWAIT " + std::to_string(smm_mfma_handwait()) + "\n";
     s += "#define XDEPTH " + std::to_string(smm_mfma_runs_depth(typesize, m, n, k, ldb)) + "\n";
     s += std::string("#define XSPLIT ") + ((variant & SMM_JIT_SPLIT) ? "1" : "0") + "\n";
+    s += "#define XTILEWG 0\n";
     s += SMM_JIT_PRELUDE; s += SMM_JIT_MFMA_RUNS_CONST; s += SMM_JIT_CHAIN; s += SMM_JIT_MFMA_RUNS_KERNEL;
     return s;
   }
@@ -2113,6 +2127,10 @@ std::string gen_smm_grouped_source(int typesize, const std::vector<GroupedBody>&
 {
   std::string s = "// generated by libxsmm-amd (dense SMM run kernels of several shapes behind one dispatcher)\n";
   s += std::string("typedef ") + (8 == typesize ? "double" : "float") + " T;\n#define XLOWP 0\n#define XFLAT 0\n#define XGROUPED 1\n";
+  // threads > 64 (XSMM_SMMJIT_TILESPLIT=2): the entries are the 16 x 16 tiles of C of ONE batch (smm_tile_split) and wave t of every
+  // work-group walks entry t -- the waves of a work-group walk the same runs
+  const bool tilewg = (threads > 64);
+  s += std::string("#define XTILEWG ") + (tilewg ? "1" : "0") + "\n";
   bool all_mfma = true;
   for (const GroupedBody& b : bodies) all_mfma = all_mfma && 0 != (b.variant & SMM_JIT_MFMA_RUNS);
   // The register-tiled bodies are called (inlined, the dispatcher carries the registers of all of them at once: measured slower);
@@ -2153,8 +2171,14 @@ std::string gen_smm_grouped_source(int typesize, const std::vector<GroupedBody>&
   const int grouped_wpe = (0 < grouped_wpe_env) ? grouped_wpe_env : 2;
   s += "extern \"C\" __global__ __launch_bounds__(" + std::to_string(threads) + ", " + std::to_string(grouped_wpe) + ") void xsmm_smm_grouped(const GroupEntry* __restrict__ tab, int nentries)\n{\n";
   s += "  extern __shared__ __attribute__((aligned(16))) unsigned char xsmm_dyn_lds[];\n";
-  s += "  int e = 0;\n  while (e + 1 < nentries && blockIdx.x >= tab[e + 1].block_begin) ++e;\n";
-  s += "  const GroupEntry g = tab[e];\n  const unsigned bid = blockIdx.x - g.block_begin;\n  T* const lds = reinterpret_cast<T*>(xsmm_dyn_lds);\n";
+  if (!tilewg) {
+    s += "  int e = 0;\n  while (e + 1 < nentries && blockIdx.x >= tab[e + 1].block_begin) ++e;\n";
+    s += "  const GroupEntry g = tab[e];\n  const unsigned bid = blockIdx.x - g.block_begin;\n  T* const lds = reinterpret_cast<T*>(xsmm_dyn_lds);\n";
+  }
+  else { // (pad: bytes of LDS per wave)
+    s += "  const int e = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);\n  if (e >= nentries) return;\n";
+    s += "  const GroupEntry g = tab[e];\n  const unsigned bid = blockIdx.x;\n  T* const lds = reinterpret_cast<T*>(xsmm_dyn_lds + (size_t)e * g.pad);\n";
+  }
   s += "  switch (g.body) {\n";
   for (size_t i = 0; i < bodies.size(); ++i) s += "    case " + std::to_string(i) + ": xg" + std::to_string(i) + "::xsmm_entry(g.ad, g.batch, bid, g.nblocks, lds); break;\n";
   s += "    default: break;\n  }\n}\n";
@@ -2208,7 +2232,7 @@ struct GroupedPlan { GroupedKey key; std::vector<GroupedEntry> entries; size_t l
 // 0.32 ms alone), 1.18 ms with all chains on the wave form.
 bool grouped_plan(const SmmBatch* groups, int ngroups, bool check_eligible, GroupedPlan& plan, bool tiles = false)
 { // tiles: the groups are the tiles of one batch of few runs (smm_tile_split)
-  plan.key.typesize = groups[0].typesize; plan.key.threads = 64; plan.key.bodies.clear(); plan.entries.clear(); plan.lds_max = 0;
+  plan.key.typesize = groups[0].typesize; plan.key.threads = (tiles && 0 != smm_tile_wg()) ? 64 * ngroups : 64; plan.key.bodies.clear(); plan.entries.clear(); plan.lds_max = 0;
   for (int g = 0; g < ngroups; ++g) {
     const SmmBatch& s = groups[g];
     if (s.typesize != groups[0].typesize || (check_eligible && !smm_jit_grouped_eligible(s))) return false;
@@ -2282,11 +2306,18 @@ static int launch_smm_jit_grouped_checked(const SmmBatch* groups, int ngroups, b
     t.batch = s.batch; t.block_begin = total; t.nblocks = (unsigned)plan.entries[i].blocks; t.body = plan.entries[i].body;
     total += t.nblocks;
   }
+  size_t lds_bytes = plan.lds_max;
+  if (plan.key.threads > 64) { // a work-group per chunk of 64 items, a wave per tile
+    const size_t per_wave = (plan.lds_max + 15) / 16 * 16;
+    total = tab[0].nblocks;
+    for (GroupEntryH& t : tab) { t.block_begin = 0; t.nblocks = total; t.pad = (int)per_wave; }
+    lds_bytes = per_wave * tab.size();
+  }
   void* d_tab = index_upload(tab.data(), tab.size() * sizeof(GroupEntryH));
   if (nullptr == d_tab) return 1;
   int nentries = (int)tab.size();
   void* args[] = { (void*)&d_tab, &nentries };
-  return jit_launch_dyn(kern, total, (unsigned)plan.key.threads, (unsigned)plan.lds_max, args, stream);
+  return jit_launch_dyn(kern, total, (unsigned)plan.key.threads, (unsigned)lds_bytes, args, stream);
 }
 
 // Matrix-core work-group kernels (32 < max(M, N) <= 64, K <= 64; independent items, or runs of a uniform length) with the

@@ -47,12 +47,13 @@ SHAPES = [(13, 13, 13), (23, 23, 23), (32, 32, 32), (32, 13, 23), (13, 32, 32), 
           (31, 2, 63)]
 
 
-@pytest.mark.parametrize("tiles", [1, 0])
+@pytest.mark.parametrize("tiles", [1, 2, 0])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("shape", SHAPES)
 def test_runs_on_the_matrix_cores_bitexact(xs, orc, torch_gpu, dtype, shape, tiles):
     """index batches: (1) permuted operands, every item its own C (index_base 1); (2) runs of 1 ... 200 products with gaps between
-    the C blocks that are used. A wave per run, or -- these batches are small -- per run and 16 x 16 tile of C: the same bits"""
+    the C blocks that are used. A wave per run (tiles = 0), or -- these batches are small -- per run and 16 x 16 tile of C, the tiles
+    as the groups of a grouped launch (1, the default) or as the waves of one work-group (2): the same bits"""
     torch = torch_gpu
     m, n, k = shape
     batch = 777

@@ -12,6 +12,8 @@ timeout -k 10 400 bash tools/pmc_headline.sh && echo "[round3] headline pmc done
  echo "== order relaxed (libxsmm_gemm_batch_omp semantics)"; timeout -k 10 200 python tools/bench_cp2k.py 524288 7 1 0 1;
  echo "== XSMM_SMMJIT_GROUPED_WPE=3"; XSMM_SMMJIT_GROUPED_WPE=3 timeout -k 10 200 python tools/bench_cp2k.py 524288 7 0 0 1;
  echo "== XSMM_SMMJIT_GROUPED_INLINE=0"; XSMM_SMMJIT_GROUPED_INLINE=0 timeout -k 10 200 python tools/bench_cp2k.py 524288 7 0 0 1;
+ echo "== XSMM_SMMJIT_HANDWAIT=0: the compiler's wait counts in the run form"; XSMM_SMMJIT_HANDWAIT=0 timeout -k 10 200 python tools/bench_cp2k.py 524288 7;
+ echo "== XSMM_SMMJIT_TILESPLIT=0: one call per shape with a wave per run"; XSMM_SMMJIT_TILESPLIT=0 timeout -k 10 200 python tools/bench_cp2k.py 524288 7;
  echo "== full config 5 on one GPU (4 194 304 products)"; timeout -k 10 200 python tools/bench_cp2k.py 4194304 5 0 0 1; timeout -k 10 200 python tools/bench_cp2k.py 4194304 5 1 0 1) 2>&1 | grep -v amdgpu.ids > gpurun_out/cp2k_stacks.txt
 echo "[round3] cp2k stacks done"
 timeout -k 10 300 bash tools/pmc_cp2k.sh > /dev/null 2>&1; echo "[round3] cp2k pmc done"
@@ -26,11 +28,12 @@ gcc -O2 -I include -I/opt/rocm/include tools/bench_call_latency.c -o /tmp/bench_
  (echo "--- default ---"; timeout -k 10 120 /tmp/bench_call_latency; echo "--- LIBXSMM_AMD_DEFER=1 ---"; LIBXSMM_AMD_DEFER=1 timeout -k 10 120 /tmp/bench_call_latency) >> gpurun_out/bench_calls.txt 2>&1
 echo "[round3] call benches done"
 timeout -k 10 300 python3 tools/bench_small_batches.py 2>&1 | grep -v amdgpu.ids > gpurun_out/small_batches.txt
+timeout -k 10 300 python3 tools/bench_tile_split.py 2>&1 | grep -v amdgpu.ids > gpurun_out/tile_split.txt
 timeout -k 10 500 python tools/bench_dense.py all 7 2>&1 | grep -v amdgpu.ids > gpurun_out/dense_shapes.txt
 (timeout -k 10 200 python tools/bench_sparse.py spmdm 10; timeout -k 10 200 python tools/bench_sparse.py fsspmdm 10; SP_BATCH=262144 timeout -k 10 200 python tools/bench_sparse.py fsspmdm 10) 2>&1 | grep -v amdgpu.ids > gpurun_out/sparse_phases.txt
 echo "[round3] dense + sparse done"
 (for a in "2048 32 f32" "2048 32 f64" "2048 64 f32" "2048 64 f64" "4096 32 f32" "4096 32 f64" "4096 64 f64"; do timeout -k 10 100 python3 tools/bench_blocked.py $a 2>&1 | tail -n 1; done;
- timeout -k 10 200 python3 tools/bench_spmdm_api.py 2048 0.15 2;
+ timeout -k 10 200 python3 tools/bench_spmdm_api.py 2048 0.15 10;
  timeout -k 10 200 python3 tools/bench_soa.py;
  echo "== bench_generic (matrix cores off: register-tiled forms)"; timeout -k 10 200 python3 tools/bench_generic.py;
  echo "== bench_generic (matrix cores on, the default policy)"; XSMM_BENCH_MFMA=1 timeout -k 10 200 python3 tools/bench_generic.py;

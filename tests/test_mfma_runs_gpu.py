@@ -88,6 +88,49 @@ def test_runs_on_the_matrix_cores_bitexact(xs, orc, torch_gpu, dtype, shape, til
         assert np.array_equal(dc2.cpu().numpy().view(np.uint8), ref2.view(np.uint8))
 
 
+def _random_run_shapes(count, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(count):
+        m, n, k = int(rng.integers(1, 33)), int(rng.integers(1, 33)), int(rng.integers(1, 65))
+        lda = m + int(rng.choice([0, 0, 1, 3, 8])); ldb = k + int(rng.choice([0, 0, 1, 5])); ldc = m + int(rng.choice([0, 0, 2, 7]))
+        out.append((m, n, k, lda, ldb, ldc))
+    return out
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("shape", _random_run_shapes(10, 20251005))
+def test_random_shapes_and_leading_dimensions_bitexact(xs, orc, torch_gpu, dtype, shape):
+    """shapes, leading dimensions and run structures drawn at random (fixed seed): every combination of tile counts (1, 2, 4 tiles of C),
+    K padding (K % 4), fragment windows (offsets beyond 4 KiB) and spans of B the generator can meet -- a wave per run and tile, then
+    a wave per run, both bit-equal to the oracle's sequential chain; elements of C in the gaps stay untouched"""
+    torch = torch_gpu
+    m, n, k, lda, ldb, ldc = shape
+    rng = np.random.default_rng(m * 1009 + n * 31 + k)
+    batch = 333
+    lens = []
+    while sum(lens) < batch:
+        lens.append(int(rng.choice([1, 1, 2, 5, 17, 70, 130])))
+    lens[-1] -= sum(lens) - batch
+    lens = np.array(lens, dtype=np.int64); nc = len(lens)
+    owners = np.sort(rng.choice(np.arange(nc + 3), size=nc, replace=False))
+    cidx = np.repeat(owners, lens)
+    a = rng.uniform(-1, 1, batch * lda * k).astype(dtype); b = rng.uniform(-1, 1, batch * ldb * n).astype(dtype)
+    c = rng.uniform(-1, 1, (nc + 3) * ldc * n).astype(dtype)
+    sa = (rng.permutation(batch) * lda * k).astype(np.int32); sb = (rng.permutation(batch) * ldb * n).astype(np.int32); sc = (cidx * ldc * n).astype(np.int32)
+    ref = c.copy()
+    assert 0 == orc.gemm_batch_idx(orc.FMA, 0, m, n, k, lda, ldb, ldc, a, b, ref, 0, sa, sb, sc, batch)
+    prec = xs.F64 if dtype == np.float64 else xs.F32
+    da, db = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    for tiles in (1, 0):
+        with _Jit(xs, tiles=tiles):
+            dc = torch.from_numpy(c).cuda()
+            xs.gemm_batch(prec, "N", "N", m, n, k, 1.0, da, lda, db, ldb, 1.0, dc, ldc, 0, 4, sa, sb, sc, batch)
+            torch.cuda.synchronize()
+            assert xs.last_kernel() == runs_kernel(dtype, m, n, tiles), (xs.last_kernel(), tiles)
+        assert np.array_equal(dc.cpu().numpy().view(np.uint8), ref.view(np.uint8)), tiles
+
+
 def test_signs_of_zeros_survive_the_k_padding(xs, orc, torch_gpu):
     """K = 13 is padded to 16 with A = -0, B = +0: the padded products are -0, the identity of the addition for every sum --
     also for a C that is -0 and stays untouched by real products of zero"""

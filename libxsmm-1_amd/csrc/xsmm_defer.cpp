@@ -257,6 +257,7 @@ void defer_flush()
 
 bool defer_call(Kernel* k, const void* a, const void* b, void* c)
 {
+  if (tl_spmdm_open) spmdm_flush_record(); // (recorded spmdm block calls come first: a burst runs at the stream position of its first call)
   if (!defer_enabled() || nullptr == k || KC_DENSE != k->kclass) return false;
   // small products only (the reference's own JIT domain, LIBXSMM_MAX_MNK = 64^3): a large product is a launch -- or a library
   // GEMM -- of its own that spreads over the chip
@@ -325,6 +326,7 @@ bool defer_call(Kernel* k, const void* a, const void* b, void* c)
 // from device memory), the following calls only count up as long as they continue the walk along the rows.
 bool defer_panels(const void* handle, JitKernel* jit, const void* B, void* C, int typesize, int M, int N, int K, long long ldb, long long ldc, int vec)
 {
+  if (tl_spmdm_open) spmdm_flush_record();
   if (!defer_enabled() || nullptr == handle || nullptr == jit || nullptr == B || nullptr == C) return false;
   Ring* const rp = my_ring();
   if (nullptr == rp) return false;

@@ -468,6 +468,7 @@ void add_rect(std::vector<SpmdmRect>& rects, SpmdmRect r)
 bool record_block(int kind, const libxsmm_spmdm_handle* handle, const void* src, bool bf16, char trans, char transc, float beta, float* c, SpmdmRect r)
 {
   if (!defer_bracket_open() || !pure_device(src) || (2 == kind && !pure_device(c))) return false;
+  if (tl_defer_open) defer_flush(); // an open burst of per-call kernels is sealed: later calls of that kernel must not run ahead of this block
   SpmdmRecord& p = tl_record;
   if (tl_spmdm_open && !(p.kind == kind && p.handle.base_ptr_scratch_A == handle->base_ptr_scratch_A && p.src == src && p.bf16 == bf16
       && is_trans(p.trans) == is_trans(trans) && is_trans(p.transc) == is_trans(transc) && p.beta == beta && p.c == c)) spmdm_flush_record();

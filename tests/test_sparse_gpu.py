@@ -635,6 +635,45 @@ def test_spmdm_block_calls_inside_a_bracket(xs, orc, torch_gpu):
         assert np.array_equal(outs[0], ref) and np.array_equal(outs[1], ref), (ta, tb, tc)
 
 
+def test_spmdm_blocks_and_per_call_kernels_inside_one_bracket(xs, orc, torch_gpu):
+    """Recorded spmdm block calls and bursts of per-call dense kernels keep the order of the calls among themselves: a dense call
+    that reads the C of a recorded spmdm block, and a spmdm block whose B a dense call of an open burst has written -- same bits as
+    the same sequence with a launch per call (that path is checked against the oracle in the tests above)."""
+    torch = torch_gpu
+    L = xs.lib()
+    M, N, K = 64, 32, 64
+    a, b, c = spmdm_inputs(M, N, K, 0.6, 5, orc)
+    rng = np.random.default_rng(11)
+    x = rng.uniform(-1, 1, 1024).astype(np.float32); y = rng.uniform(-1, 1, 1024).astype(np.float32); z = rng.uniform(-1, 1, 1024).astype(np.float32)
+    fn = L.libxsmm_smmdispatch(32, 32, 32, None, None, None, None, None, None, None)
+    assert fn
+    alpha = C.c_float(1.0)
+    outs = []
+    for bracket in (False, True):
+        h = xs.SpmdmHandle(); slices = C.POINTER(xs.CSRSlice)()
+        L.libxsmm_spmdm_init(M, N, K, 1, C.byref(h), C.byref(slices))
+        assert L.libxsmm_spmdm_get_num_compute_blocks(C.byref(h)) == 1
+        da, db, dc, dc2 = (torch.from_numpy(v.copy()).cuda() for v in (a, b, c, c))
+        dx, dy, dz1, dz2 = (torch.from_numpy(v.copy()).cuda() for v in (x, y, z, z))
+        be0 = C.c_float(0.0)
+        if bracket:
+            L.libxsmm_amd_defer_begin()
+        xs.call_kernel(fn, dx, dy, dz1)                                   # opens a burst (inside the bracket)
+        L.libxsmm_spmdm_createSparseSlice_fp32_thread(C.byref(h), b"N", xs.dptr(da), slices, 0, 0, 1)
+        L.libxsmm_spmdm_compute_fp32_thread(C.byref(h), b"N", b"N", C.byref(alpha), slices, xs.dptr(db), b"N", C.byref(be0), xs.dptr(dc), 0, 0, 1)
+        xs.call_kernel(fn, dc, dy, dz2)                                   # A = the first 1024 numbers of the spmdm result
+        xs.call_kernel(fn, dx, dz2, db)                                   # ... and the first 1024 numbers of the spmdm B updated by a dense call
+        L.libxsmm_spmdm_compute_fp32_thread(C.byref(h), b"N", b"N", C.byref(alpha), slices, xs.dptr(db), b"N", C.byref(be0), xs.dptr(dc2), 0, 0, 1)
+        if bracket:
+            L.libxsmm_amd_defer_end()
+        torch.cuda.synchronize()
+        outs.append([t.cpu().numpy() for t in (dz1, dc, dz2, db, dc2)])
+        L.libxsmm_spmdm_destroy(C.byref(h))
+    for u, v in zip(*outs):
+        assert np.array_equal(u.view(np.uint32), v.view(np.uint32))
+    assert not np.array_equal(outs[0][4], outs[0][1])  # (the second product really saw another B)
+
+
 @pytest.mark.parametrize("case", [
     # M, N, K, keep-threshold, (ta, tb, tc), beta
     (700, 515, 330, 0.85, ("N", "N", "N"), 1.0),     # N % 4 != 0: element-wide global accesses

@@ -1154,6 +1154,10 @@ int launch_spmdm_compute_tiled(int M, int N, int K, int bm, int bk, int mb, int 
   // long as the whole problem (0.113 vs 0.125 ms). 16-row tiles: 0.9 + 0.7 + 1.8 us, and every panel of B is staged four times as often
   // (2 GB through L2 for the whole problem: 0.265 ms). The caller's remedy is the bracket (xsmm_sparse.cpp:record_block): the block
   // calls of a sweep become one launch, 0.125 ms. XSMM_SPMDM_TILE_ROWS=16: developer knob.
+  // Also measured and dropped: a wave's four rows walked side by side, two entries per row and step with the next step's entries requested
+  // behind this step's B rows (one LDS round trip per step instead of ~20 dependent ones per block): 0.162 ms for the whole problem against
+  // 0.125 (50 % density: 0.61 against 0.35) -- with sixteen waves per CU the round trips of one wave are covered by the others; what the
+  // CU runs out of is LDS bandwidth and issue slots, and the B rows fetched for slots past the end of a row (~40 % more) cost exactly those.
   static const int rows_env = []() { const char* e = getenv("XSMM_SPMDM_TILE_ROWS"); return (nullptr != e && 0 != *e) ? atoi(e) : 0; }();
   const bool small = (16 == rows_env);
   (void)total64;

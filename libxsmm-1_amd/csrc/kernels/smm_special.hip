@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256, 4)
 void smm32_f32_fma_kernel(DevAddr ad, long long batch)
 {
   __shared__ __align__(16) float lds[4][2048];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63; // (uniform by construction: addresses and indexes live in scalar registers)
   const int tx = lane & 7, ty = lane >> 3;
   float* const As = lds[wave];
   float* const Bs = lds[wave] + 1024;
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256, 4)
 void smm32_f32_mfma_kernel(DevAddr ad, long long batch, int runlen)
 { // RUNS: a unit is a run of `runlen` consecutive items with one C block (blocked GEMM), C stays in the accumulators
   __shared__ __align__(16) float lds[4][2048];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63; // (uniform by construction: addresses and indexes live in scalar registers)
   const int lo = lane & 31, hi = lane >> 5;
   float* const As = lds[wave];
   float* const Bs = lds[wave] + 1024;
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256)
 void stream_abc_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ b, f32x4* __restrict__ c, long long items)
 {
   const int lane = threadIdx.x & 63;
-  const long long w = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, W = ((long long)gridDim.x * blockDim.x) >> 6;
+  const long long w = (long long)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), W = ((long long)gridDim.x * blockDim.x) >> 6; // (blockDim.x is a multiple of 64)
   if (w >= items) return;
   f32x4 ra[4], rb[4], rc[4];
 #pragma unroll

@@ -61,7 +61,7 @@ void spmdm_create_kernel(long long nslices, int nrows_full, int ncols_full, int 
                          long long rowidx_stride, long long cap)
 {
   const int lane = threadIdx.x & 63;
-  const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // (uniform by construction; blockDim.x is a multiple of 64)
   const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
   for (long long s = wave; s < nslices; s += nwaves) {
     const float* in; int nrows, ncols;
@@ -186,9 +186,9 @@ void spmdm_create_staged_kernel(long long nslices, int nrows, int ncols, int tra
   __shared__ __align__(16) float lds_vals[4][SPC_CAP + 64];
   __shared__ __align__(16) uint16_t lds_cols[4][SPC_CAP + 64];
   __shared__ __align__(16) uint16_t lds_rows[4][264];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   float* const bv = lds_vals[wv]; uint16_t* const bc = lds_cols[wv]; uint16_t* const br = lds_rows[wv];
-  const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // (uniform by construction; blockDim.x is a multiple of 64)
   const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
   const bool in_range = (lane < ncols);
   typedef unsigned sp_u32x4c __attribute__((ext_vector_type(4)));
@@ -614,7 +614,7 @@ void spmdm_compute_mfma_kernel(long long batch, int M_arg, int K_arg, float beta
   unsigned short* const ris = reinterpret_cast<unsigned short*>(meta + SPM_META); // [M + 1]
   float* const spare = reinterpret_cast<float*>(ris + 72) + (threadIdx.x & 63);     // a word per lane nobody reads (inactive scatter lanes; one shared word would be a 32-way bank conflict)
   int* const nonfinite = reinterpret_cast<int*>(reinterpret_cast<float*>(ris + 72) + 64); // [2]: "this item's B tile holds inf / NaN", one word per register set
-  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  const int t = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
   const int M = FULL ? 64 : M_arg, K = FULL ? 64 : K_arg;
   constexpr int N = 16 * NT, n4 = 4 * NT;
   const int tile = K * N, nv4 = tile >> 2, ksteps = K >> 2;

@@ -251,7 +251,7 @@ void smm64_f32_mfma_kernel(DevAddr ad, long long batch)
 {
   __shared__ __align__(16) float As[4096];
   __shared__ __align__(16) float Bs[4096];
-  const int t = threadIdx.x, wave = t >> 6, lane = t & 63, lo = lane & 31, hi = lane >> 5;
+  const int t = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, lo = lane & 31, hi = lane >> 5;
   const int mq = wave & 1, nq = wave >> 1;
   const int m = 32 * mq + lo, n = 32 * nq + lo;
   const int coff = (32 * nq + 4 * hi) * 64 + m; // lane's first C element

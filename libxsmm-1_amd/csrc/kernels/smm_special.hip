@@ -404,7 +404,8 @@ int launch_smm_special(const SmmBatch& s, void* stream, const char** name)
     const int bpc = env_int("XSMM_SMM32_BPC", 3), nt = env_int("XSMM_SMM32_NT", 1);
     const int variant = env_int("XSMM_SMM32_VARIANT", 0 != s.use_mfma ? 0 : 1);
     long long blocks = (s.batch + 3) / 4;
-    const long long resident = 256LL * (bpc > 0 ? bpc : 3);
+    const int grid_env = env_int("XSMM_SMM32_GRID", 0); // developer knob: the persistent grid in work-groups (0: 256 x bpc)
+    const long long resident = (0 < grid_env) ? grid_env : 256LL * (bpc > 0 ? bpc : 3);
     if (blocks > resident) blocks = resident;
     if (1 == variant) return (0 != nt) ? launch_smm32<true, true>(s, st, (unsigned)blocks, name) : launch_smm32<false, true>(s, st, (unsigned)blocks, name);
     return (0 != nt) ? launch_smm32<true, false>(s, st, (unsigned)blocks, name) : launch_smm32<false, false>(s, st, (unsigned)blocks, name);

@@ -2123,6 +2123,7 @@ namespace {
 struct GroupedBody { int m, n, k, flags, variant, lda, ldb, ldc; };
 inline bool operator==(const GroupedBody& a, const GroupedBody& b) { return 0 == memcmp(&a, &b, sizeof(a)); }
 
+constexpr int GROUPED_BYVAL = 32; // table entries a grouped launch carries as a kernel argument
 std::string gen_smm_grouped_source(int typesize, const std::vector<GroupedBody>& bodies, int threads)
 {
   std::string s = "// generated by libxsmm-amd (dense SMM run kernels of several shapes behind one dispatcher)\n";
@@ -2169,15 +2170,24 @@ std::string gen_smm_grouped_source(int typesize, const std::vector<GroupedBody>&
   // shapes, 524 288 products, batch order: 0.80-0.81 ms per call with two waves per SIMD, 0.82 ms with three (1.00 ms when the
   // light bodies keep four products in flight as well), 1.46 ms with four; profiles/r3_cp2k_stacks.txt)
   const int grouped_wpe = (0 < grouped_wpe_env) ? grouped_wpe_env : 2;
-  s += "extern \"C\" __global__ __launch_bounds__(" + std::to_string(threads) + ", " + std::to_string(grouped_wpe) + ") void xsmm_smm_grouped(const GroupEntry* __restrict__ tab, int nentries)\n{\n";
+  // The table travels as a kernel argument (up to GROUPED_BYVAL entries: 3.8 KiB of the 4 KiB a launch may carry) -- no staging copy on the
+  // stream in front of the launch (a blit kernel of ~5 us per call: 27 CP2K calls of ~90 us each paid it 27 times); longer tables come
+  // through memory (tabp != nullptr).
+  s += "struct GroupTab { GroupEntry e[" + std::to_string(GROUPED_BYVAL) + "]; };\n";
+  s += "extern \"C\" __global__ __launch_bounds__(" + std::to_string(threads) + ", " + std::to_string(grouped_wpe) + ") void xsmm_smm_grouped(const GroupTab tabv, const GroupEntry* __restrict__ tabp, int nentries)\n{\n";
   s += "  extern __shared__ __attribute__((aligned(16))) unsigned char xsmm_dyn_lds[];\n";
+
+  // (the two homes of the table are two address spaces: each is read through its own scalar loads)
   if (!tilewg) {
-    s += "  int e = 0;\n  while (e + 1 < nentries && blockIdx.x >= tab[e + 1].block_begin) ++e;\n";
-    s += "  const GroupEntry g = tab[e];\n  const unsigned bid = blockIdx.x - g.block_begin;\n  T* const lds = reinterpret_cast<T*>(xsmm_dyn_lds);\n";
+    s += "  int e = 0;\n  GroupEntry g;\n";
+    s += "  if (nullptr != tabp) { while (e + 1 < nentries && blockIdx.x >= tabp[e + 1].block_begin) ++e; g = tabp[e]; }\n";
+    s += "  else { while (e + 1 < nentries && blockIdx.x >= tabv.e[e + 1].block_begin) ++e; g = tabv.e[e]; }\n";
+    s += "  const unsigned bid = blockIdx.x - g.block_begin;\n  T* const lds = reinterpret_cast<T*>(xsmm_dyn_lds);\n";
   }
   else { // (pad: bytes of LDS per wave)
     s += "  const int e = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);\n  if (e >= nentries) return;\n";
-    s += "  const GroupEntry g = tab[e];\n  const unsigned bid = blockIdx.x;\n  T* const lds = reinterpret_cast<T*>(xsmm_dyn_lds + (size_t)e * g.pad);\n";
+    s += "  GroupEntry g;\n  if (nullptr != tabp) g = tabp[e]; else g = tabv.e[e];\n";
+    s += "  const unsigned bid = blockIdx.x;\n  T* const lds = reinterpret_cast<T*>(xsmm_dyn_lds + (size_t)e * g.pad);\n";
   }
   s += "  switch (g.body) {\n";
   for (size_t i = 0; i < bodies.size(); ++i) s += "    case " + std::to_string(i) + ": xg" + std::to_string(i) + "::xsmm_entry(g.ad, g.batch, bid, g.nblocks, lds); break;\n";
@@ -2313,10 +2323,17 @@ static int launch_smm_jit_grouped_checked(const SmmBatch* groups, int ngroups, b
     for (GroupEntryH& t : tab) { t.block_begin = 0; t.nblocks = total; t.pad = (int)per_wave; }
     lds_bytes = per_wave * tab.size();
   }
-  void* d_tab = index_upload(tab.data(), tab.size() * sizeof(GroupEntryH));
-  if (nullptr == d_tab) return 1;
+  struct GroupTabH { GroupEntryH e[GROUPED_BYVAL]; };
+  static_assert(sizeof(GroupTabH) + 16 <= 4096, "kernel arguments of a launch");
   int nentries = (int)tab.size();
-  void* args[] = { (void*)&d_tab, &nentries };
+  void* d_tab = nullptr;
+  GroupTabH byval; // (as a kernel argument when it fits: see gen_smm_grouped_source)
+  if (tab.size() <= (size_t)GROUPED_BYVAL) memcpy(&byval, tab.data(), tab.size() * sizeof(GroupEntryH));
+  else {
+    d_tab = index_upload(tab.data(), tab.size() * sizeof(GroupEntryH));
+    if (nullptr == d_tab) return 1;
+  }
+  void* args[] = { (void*)&byval, (void*)&d_tab, &nentries };
   return jit_launch_dyn(kern, total, (unsigned)plan.key.threads, (unsigned)lds_bytes, args, stream);
 }
 
@@ -2567,12 +2584,7 @@ int launch_smm_jit(const SmmBatch& s, void* stream, const char** name)
   }
   if (smm_mfma_runs_ok(s)) { // shared C on the matrix cores: a wave per run (batch order; segments + atomics if the verdict or a relaxed order say so)
     { SmmBatch tiles[4];
-      int nt = smm_tile_split(s, tiles);
-      if (1 < nt) { // (the table of a grouped launch travels through a pinned staging buffer that later calls reuse: not inside a stream capture)
-        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        if (hipSuccess != hipStreamIsCapturing((hipStream_t)stream, &cap)) { (void)hipGetLastError(); cap = hipStreamCaptureStatusActive; }
-        if (hipStreamCaptureStatusNone != cap) nt = 0;
-      }
+      const int nt = smm_tile_split(s, tiles); // (at most four entries: the table is a kernel argument -- nothing staged, fine inside a stream capture)
       if (1 < nt) {
         const int e = launch_smm_jit_grouped_checked(tiles, nt, false, stream, name);
         if (0 <= e) { *name = f64 ? "smm_f64_mfma_runs_tiles_jit" : "smm_f32_mfma_runs_tiles_jit"; return e; }

@@ -131,6 +131,53 @@ def test_random_shapes_and_leading_dimensions_bitexact(xs, orc, torch_gpu, dtype
         assert np.array_equal(dc.cpu().numpy().view(np.uint8), ref.view(np.uint8)), tiles
 
 
+def test_batch_calls_captured_in_a_graph(xs, orc, torch_gpu):
+    """libxsmm_gemm_batch calls on device index arrays recorded into a HIP graph and replayed (an index batch makes no host round trip:
+    ordering check, verdict and multiplication are all launches): a batch that runs a wave per run and tile -- its table travels as a
+    kernel argument, nothing is staged -- and one that runs a wave per run; every replay adds the products once more, bit-equal to the
+    oracle applied as often"""
+    torch = torch_gpu
+    L = xs.lib()
+    rng = np.random.default_rng(3)
+    cases = []
+    for (m, n, k) in ((23, 23, 23), (13, 13, 13)):
+        batch, runlen = 600, 50
+        a = rng.uniform(-1, 1, batch * m * k); b = rng.uniform(-1, 1, batch * k * n); c = rng.uniform(-1, 1, (batch // runlen) * m * n)
+        sa = (rng.permutation(batch) * m * k).astype(np.int32); sb = (np.arange(batch) * k * n).astype(np.int32); sc = ((np.arange(batch) // runlen) * m * n).astype(np.int32)
+        cases.append((m, n, k, batch, a, b, c, sa, sb, sc))
+    with _Jit(xs):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        dev = []
+        for (m, n, k, batch, a, b, c, sa, sb, sc) in cases:
+            dev.append([torch.from_numpy(x).cuda() for x in (a, b, c, sa, sb, sc)])
+        torch.cuda.synchronize()
+
+        def calls():
+            for (m, n, k, batch, *_), (da, db, dc, dsa, dsb, dsc) in zip(cases, dev):
+                xs.gemm_batch(xs.F64, "N", "N", m, n, k, 1.0, da, m, db, k, 1.0, dc, m, 0, 4, dsa, dsb, dsc, batch)
+        names = []
+        try:
+            with torch.cuda.stream(side):
+                L.libxsmm_amd_set_stream(C.c_void_p(side.cuda_stream))
+                calls()  # warm-up on the capture stream (kernels resolved, scratch in place): application 1
+                side.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=side):
+                    calls()  # (captured, not run)
+                names.append(xs.last_kernel())
+                graph.replay(); graph.replay()  # applications 2 and 3
+                side.synchronize()
+        finally:
+            L.libxsmm_amd_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert names[0] == "smm_f64_mfma_runs_jit"  # (the last call of the capture: 13^3, one tile)
+        for (m, n, k, batch, a, b, c, sa, sb, sc), (da, db, dc, *_) in zip(cases, dev):
+            ref = c.copy()
+            for _ in range(3):
+                assert 0 == orc.gemm_batch_idx(orc.FMA, 0, m, n, k, m, k, m, a, b, ref, 0, sa, sb, sc, batch)
+            assert np.array_equal(dc.cpu().numpy().view(np.uint64), ref.view(np.uint64)), (m, n, k)
+
+
 def test_signs_of_zeros_survive_the_k_padding(xs, orc, torch_gpu):
     """K = 13 is padded to 16 with A = -0, B = +0: the padded products are -0, the identity of the addition for every sum --
     also for a C that is -0 and stays untouched by real products of zero"""

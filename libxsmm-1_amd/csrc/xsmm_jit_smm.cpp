@@ -2170,24 +2170,20 @@ std::string gen_smm_grouped_source(int typesize, const std::vector<GroupedBody>&
   // shapes, 524 288 products, batch order: 0.80-0.81 ms per call with two waves per SIMD, 0.82 ms with three (1.00 ms when the
   // light bodies keep four products in flight as well), 1.46 ms with four; profiles/r3_cp2k_stacks.txt)
   const int grouped_wpe = (0 < grouped_wpe_env) ? grouped_wpe_env : 2;
-  // The table travels as a kernel argument (up to GROUPED_BYVAL entries: 3.8 KiB of the 4 KiB a launch may carry) -- no staging copy on the
-  // stream in front of the launch (a blit kernel of ~5 us per call: 27 CP2K calls of ~90 us each paid it 27 times); longer tables come
-  // through memory (tabp != nullptr).
+  // The table travels as a kernel argument (up to GROUPED_BYVAL entries: 3.8 KiB of the 4 KiB a launch may carry; the callers fuse at
+  // most that many batches per launch -- the ordering check carries its table the same way) -- no staging copy on the stream in front of
+  // the launch (a blit kernel of ~5 us per call: 27 CP2K calls of ~90 us each paid it 27 times), nothing that a stream capture must not see.
   s += "struct GroupTab { GroupEntry e[" + std::to_string(GROUPED_BYVAL) + "]; };\n";
-  s += "extern \"C\" __global__ __launch_bounds__(" + std::to_string(threads) + ", " + std::to_string(grouped_wpe) + ") void xsmm_smm_grouped(const GroupTab tabv, const GroupEntry* __restrict__ tabp, int nentries)\n{\n";
+  s += "extern \"C\" __global__ __launch_bounds__(" + std::to_string(threads) + ", " + std::to_string(grouped_wpe) + ") void xsmm_smm_grouped(const GroupTab tabv, int nentries)\n{\n";
   s += "  extern __shared__ __attribute__((aligned(16))) unsigned char xsmm_dyn_lds[];\n";
 
-  // (the two homes of the table are two address spaces: each is read through its own scalar loads)
   if (!tilewg) {
-    s += "  int e = 0;\n  GroupEntry g;\n";
-    s += "  if (nullptr != tabp) { while (e + 1 < nentries && blockIdx.x >= tabp[e + 1].block_begin) ++e; g = tabp[e]; }\n";
-    s += "  else { while (e + 1 < nentries && blockIdx.x >= tabv.e[e + 1].block_begin) ++e; g = tabv.e[e]; }\n";
-    s += "  const unsigned bid = blockIdx.x - g.block_begin;\n  T* const lds = reinterpret_cast<T*>(xsmm_dyn_lds);\n";
+    s += "  int e = 0;\n  while (e + 1 < nentries && blockIdx.x >= tabv.e[e + 1].block_begin) ++e;\n";
+    s += "  const GroupEntry g = tabv.e[e];\n  const unsigned bid = blockIdx.x - g.block_begin;\n  T* const lds = reinterpret_cast<T*>(xsmm_dyn_lds);\n";
   }
   else { // (pad: bytes of LDS per wave)
     s += "  const int e = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);\n  if (e >= nentries) return;\n";
-    s += "  GroupEntry g;\n  if (nullptr != tabp) g = tabp[e]; else g = tabv.e[e];\n";
-    s += "  const unsigned bid = blockIdx.x;\n  T* const lds = reinterpret_cast<T*>(xsmm_dyn_lds + (size_t)e * g.pad);\n";
+    s += "  const GroupEntry g = tabv.e[e];\n  const unsigned bid = blockIdx.x;\n  T* const lds = reinterpret_cast<T*>(xsmm_dyn_lds + (size_t)e * g.pad);\n";
   }
   s += "  switch (g.body) {\n";
   for (size_t i = 0; i < bodies.size(); ++i) s += "    case " + std::to_string(i) + ": xg" + std::to_string(i) + "::xsmm_entry(g.ad, g.batch, bid, g.nblocks, lds); break;\n";
@@ -2326,14 +2322,10 @@ static int launch_smm_jit_grouped_checked(const SmmBatch* groups, int ngroups, b
   struct GroupTabH { GroupEntryH e[GROUPED_BYVAL]; };
   static_assert(sizeof(GroupTabH) + 16 <= 4096, "kernel arguments of a launch");
   int nentries = (int)tab.size();
-  void* d_tab = nullptr;
-  GroupTabH byval; // (as a kernel argument when it fits: see gen_smm_grouped_source)
-  if (tab.size() <= (size_t)GROUPED_BYVAL) memcpy(&byval, tab.data(), tab.size() * sizeof(GroupEntryH));
-  else {
-    d_tab = index_upload(tab.data(), tab.size() * sizeof(GroupEntryH));
-    if (nullptr == d_tab) return 1;
-  }
-  void* args[] = { (void*)&byval, (void*)&d_tab, &nentries };
+  if (tab.size() > (size_t)GROUPED_BYVAL) return -1; // (never: the callers fuse at most 32 batches per launch)
+  GroupTabH byval; // (a kernel argument: see gen_smm_grouped_source)
+  memcpy(&byval, tab.data(), tab.size() * sizeof(GroupEntryH));
+  void* args[] = { (void*)&byval, &nentries };
   return jit_launch_dyn(kern, total, (unsigned)plan.key.threads, (unsigned)lds_bytes, args, stream);
 }
 

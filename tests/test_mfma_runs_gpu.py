@@ -318,6 +318,35 @@ def test_cp2k_27_shape_grouped_launch_bitexact(xs, orc, torch_gpu, mfma, host_in
         assert np.array_equal(dc.cpu().numpy().view(np.uint64), ref.view(np.uint64)), shapes[gi]
 
 
+def test_more_groups_than_one_launch_takes(xs, orc, torch_gpu):
+    """A fused launch takes up to 32 groups (the ordering check and the grouped kernel carry their tables as kernel arguments); a call
+    of 40 groups (five shapes, eight stacks each) becomes two fused launches, in the order of the groups, bit-equal to the oracle"""
+    torch = torch_gpu
+    L = xs.lib()
+    base = [(13, 13, 13), (23, 23, 23), (32, 32, 32), (13, 32, 23), (5, 7, 9)]
+    shapes = [base[i % len(base)] for i in range(40)]
+    rng = np.random.default_rng(40)
+    groups, sizes = [], []
+    for gi, (m, n, k) in enumerate(shapes):
+        s = 200 + 11 * gi
+        u = 1 + gi % 7; nc = (s + u - 1) // u
+        a = rng.uniform(-1, 1, s * m * k); b = rng.uniform(-1, 1, s * k * n); c = rng.uniform(-1, 1, nc * m * n)
+        idx = np.arange(s)
+        sa = (rng.permutation(s) * m * k).astype(np.int32); sb = (idx * k * n).astype(np.int32); sc = ((idx // u) * m * n).astype(np.int32)
+        ref = c.copy()
+        assert 0 == orc.gemm_batch_idx(orc.FMA, 0, m, n, k, m, k, m, a, b, ref, 0, sa, sb, sc, s)
+        groups.append(tuple(torch.from_numpy(x).cuda() for x in (a, b, c, sa, sb, sc)) + (ref,)); sizes.append(s)
+    with _Jit(xs):
+        before = L.libxsmm_amd_launch_count()
+        assert 0 == xs.gemm_batch_groups(xs.F64, shapes, [g[0] for g in groups], [g[1] for g in groups], [g[2] for g in groups],
+                                         [g[3] for g in groups], [g[4] for g in groups], [g[5] for g in groups], sizes)
+        torch.cuda.synchronize()
+        assert xs.last_kernel() == "smm_f64_jit_shape_runs_grouped", xs.last_kernel()
+        assert L.libxsmm_amd_launch_count() == before + 2
+    for gi, g in enumerate(groups):
+        assert np.array_equal(g[2].cpu().numpy().view(np.uint64), g[6].view(np.uint64)), (gi, shapes[gi])
+
+
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("shape", [(23, 23, 23, 24, 24, 24), (13, 13, 13, 16, 16, 16), (32, 32, 32, 40, 40, 40), (5, 7, 3, 8, 8, 8), (16, 31, 35, 16, 35, 24),
                                    (23, 23, 23, 23, 23, 23), (32, 32, 32, 32, 32, 32), (1, 1, 1, 1, 1, 1), (31, 2, 63, 33, 64, 31),

@@ -59,6 +59,45 @@ __global__ __launch_bounds__(256) void k_item(const f32x4* __restrict__ a, const
   }
 }
 
+// the same, CH consecutive items per wave and step (a wave's accesses are CH x 4 KiB contiguous per stream)
+template<int CH>
+__global__ __launch_bounds__(256) void k_item_ch(const f32x4* __restrict__ a, const f32x4* __restrict__ b, f32x4* __restrict__ c, long long items)
+{
+  const int lane = threadIdx.x & 63;
+  const long long w = (long long)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), W = ((long long)gridDim.x * blockDim.x) >> 6;
+  const long long groups = items / CH;
+  f32x4 ra[CH][4], rb[CH][4], rc[CH][4];
+  if (w >= groups) return;
+#pragma unroll
+  for (int q = 0; q < CH; ++q)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long long o = (w * CH + q) * 256 + 64 * j + lane;
+      ra[q][j] = __builtin_nontemporal_load(a + o); rb[q][j] = __builtin_nontemporal_load(b + o); rc[q][j] = __builtin_nontemporal_load(c + o);
+    }
+  for (long long it = w; it < groups; it += W) {
+    f32x4 r[CH][4];
+#pragma unroll
+    for (int q = 0; q < CH; ++q)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) r[q][j] = ra[q][j] + rb[q][j] + rc[q][j];
+    const long long nx = it + W;
+    if (nx < groups) {
+#pragma unroll
+      for (int q = 0; q < CH; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const long long o = (nx * CH + q) * 256 + 64 * j + lane;
+          ra[q][j] = __builtin_nontemporal_load(a + o); rb[q][j] = __builtin_nontemporal_load(b + o); rc[q][j] = __builtin_nontemporal_load(c + o);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < CH; ++q)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) __builtin_nontemporal_store(r[q][j], c + (it * CH + q) * 256 + 64 * j + lane);
+  }
+}
+
 __global__ void k_copy(const f32x4* __restrict__ a, f32x4* __restrict__ c, long long n4)
 {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) c[i] = a[i];
@@ -107,6 +146,16 @@ int main(int argc, char** argv)
     printf("item nt-st  bpc=%2d  %.3f ms  %.0f GB/s\n", bpc, t, gb4 / t * 1e3);
     t = time_ms([&] { hipLaunchKernelGGL((k_item<false, false, 0>), dim3(grid), dim3(256), 0, 0, a, b, c, items); }, 5);
     printf("item rd-only bpc=%2d  %.3f ms  %.0f GB/s (3 reads)\n", bpc, t, gb3 / t * 1e3);
+  }
+  for (int bpc : {1, 2, 3, 4}) {
+    const unsigned grid = 256u * bpc;
+    float t;
+    t = time_ms([&] { hipLaunchKernelGGL((k_item_ch<1>), dim3(grid), dim3(256), 0, 0, a, b, c, items); }, 5);
+    printf("item nt x1  bpc=%2d  %.3f ms  %.0f GB/s\n", bpc, t, gb4 / t * 1e3);
+    t = time_ms([&] { hipLaunchKernelGGL((k_item_ch<2>), dim3(grid), dim3(256), 0, 0, a, b, c, items); }, 5);
+    printf("item nt x2  bpc=%2d  %.3f ms  %.0f GB/s\n", bpc, t, gb4 / t * 1e3);
+    t = time_ms([&] { hipLaunchKernelGGL((k_item_ch<4>), dim3(grid), dim3(256), 0, 0, a, b, c, items); }, 5);
+    printf("item nt x4  bpc=%2d  %.3f ms  %.0f GB/s\n", bpc, t, gb4 / t * 1e3);
   }
   return 0;
 }

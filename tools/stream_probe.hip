@@ -98,6 +98,37 @@ __global__ __launch_bounds__(256) void k_item_ch(const f32x4* __restrict__ a, co
   }
 }
 
+// a wave per item, the batch cut into R regions that are walked side by side (R windows per stream instead of one): wave w works in
+// region w % R
+__global__ __launch_bounds__(256) void k_item_regions(const f32x4* __restrict__ a, const f32x4* __restrict__ b, f32x4* __restrict__ c, long long items, int R)
+{
+  const int lane = threadIdx.x & 63;
+  const long long w = (long long)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), W = ((long long)gridDim.x * blockDim.x) >> 6;
+  const long long per = items / R, region = w % R, first = w / R, step = W / R;
+  if (first >= per) return;
+  f32x4 ra[4], rb[4], rc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const long long o = (region * per + first) * 256 + 64 * j + lane;
+    ra[j] = __builtin_nontemporal_load(a + o); rb[j] = __builtin_nontemporal_load(b + o); rc[j] = __builtin_nontemporal_load(c + o);
+  }
+  for (long long i = first; i < per; i += step) {
+    f32x4 r[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r[j] = ra[j] + rb[j] + rc[j];
+    const long long nx = i + step;
+    if (nx < per) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const long long o = (region * per + nx) * 256 + 64 * j + lane;
+        ra[j] = __builtin_nontemporal_load(a + o); rb[j] = __builtin_nontemporal_load(b + o); rc[j] = __builtin_nontemporal_load(c + o);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) __builtin_nontemporal_store(r[j], c + (region * per + i) * 256 + 64 * j + lane);
+  }
+}
+
 __global__ void k_copy(const f32x4* __restrict__ a, f32x4* __restrict__ c, long long n4)
 {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) c[i] = a[i];
@@ -156,6 +187,11 @@ int main(int argc, char** argv)
     printf("item nt x2  bpc=%2d  %.3f ms  %.0f GB/s\n", bpc, t, gb4 / t * 1e3);
     t = time_ms([&] { hipLaunchKernelGGL((k_item_ch<4>), dim3(grid), dim3(256), 0, 0, a, b, c, items); }, 5);
     printf("item nt x4  bpc=%2d  %.3f ms  %.0f GB/s\n", bpc, t, gb4 / t * 1e3);
+  }
+  for (int R : {1, 2, 4, 8, 16, 32, 64, 128, 256, 768}) {
+    const unsigned grid = 256u * 3;
+    const float t = time_ms([&] { hipLaunchKernelGGL(k_item_regions, dim3(grid), dim3(256), 0, 0, a, b, c, items, R); }, 5);
+    printf("item nt, %3d regions  bpc= 3  %.3f ms  %.0f GB/s\n", R, t, gb4 / t * 1e3);
   }
   return 0;
 }

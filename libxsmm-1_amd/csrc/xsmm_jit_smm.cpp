@@ -174,7 +174,8 @@ __device__ __forceinline__ void park_c(T* Cs, int lane, const T (&rc)[NLC][VC])
 // 16-bit inputs (XLOWP 1: i16, T = int; 3: bf16, T = float), stored as the reference's low-precision kernels expect them: A in
 // pairs of k (a[(k/2)*M*2 + m*2 + k%2]), B column-major -- both are sequences of 32-bit k pairs. They are fetched as such and
 // widened on the way into LDS, where the images are the ones of the fp32 / int kernels; everything after that is shared.
-constexpr int PA = (M * XK) / 2, PB = (XK * N) / 2;                // k pairs per operand (XK is even)
+constexpr int PA1 = (M * XK) / 2, PB1 = (XK * N) / 2;              // k pairs per operand and item (XK is even)
+constexpr int PA = G * PA1, PB = G * PB1;                          // ... of the XPACK items a wave handles at a time (back to back in memory)
 constexpr int VPA = (0 == (PA * 4) % 16 && !XSCALAR) ? 4 : 1, VPB = (0 == (PB * 4) % 16 && !XSCALAR) ? 4 : 1;
 constexpr int NPA = (PA + 64 * VPA - 1) / (64 * VPA), NPB = (PB + 64 * VPB - 1) / (64 * VPB);
 template<int V> struct PVec { typedef unsigned type __attribute__((ext_vector_type(V))); };
@@ -205,9 +206,10 @@ __device__ __forceinline__ void park_pairs(T* As, T* Bs, int lane, const unsigne
     for (int q = 0; q < VPA; ++q) {
       const int e = (64 * j + lane) * VPA + q;
       if (e < PA) {
-        const int sp = e / M, m = e - sp * M;
-        if (1 == XLOWP) As[sp * M + m] = (T)ra[j][q]; // packed pair
-        else { As[(2 * sp) * M + m] = widen_lo(ra[j][q]); As[(2 * sp + 1) * M + m] = widen_hi(ra[j][q]); }
+        const int it = e / PA1, e1 = e - it * PA1, sp = e1 / M, m = e1 - sp * M;
+        T* const Ai = As + it * AS1;
+        if (1 == XLOWP) Ai[sp * M + m] = (T)ra[j][q]; // packed pair
+        else { Ai[(2 * sp) * M + m] = widen_lo(ra[j][q]); Ai[(2 * sp + 1) * M + m] = widen_hi(ra[j][q]); }
       }
     }
   }
@@ -217,9 +219,10 @@ __device__ __forceinline__ void park_pairs(T* As, T* Bs, int lane, const unsigne
     for (int q = 0; q < VPB; ++q) {
       const int e = (64 * j + lane) * VPB + q;
       if (e < PB) {
-        const int n = e / (XK / 2), sp = e - n * (XK / 2);
-        if (1 == XLOWP) Bs[n * KP + sp] = (T)rb[j][q];
-        else { Bs[n * KP + 2 * sp] = widen_lo(rb[j][q]); Bs[n * KP + 2 * sp + 1] = widen_hi(rb[j][q]); }
+        const int it = e / PB1, e1 = e - it * PB1, n = e1 / (XK / 2), sp = e1 - n * (XK / 2);
+        T* const Bi = Bs + it * BS1;
+        if (1 == XLOWP) Bi[n * KP + sp] = (T)rb[j][q];
+        else { Bi[n * KP + 2 * sp] = widen_lo(rb[j][q]); Bi[n * KP + 2 * sp + 1] = widen_hi(rb[j][q]); }
       }
     }
   }
@@ -227,7 +230,7 @@ __device__ __forceinline__ void park_pairs(T* As, T* Bs, int lane, const unsigne
 #if (2 == XLOWP)
 // bf16 -> bf16: C travels as 32-bit pairs of bf16 as well (M is a multiple of 16: a pair never straddles a column); the sums
 // are float, a result is the upper half of the float (truncation, as the reference's harness does)
-constexpr int PC = (M * N) / 2;
+constexpr int PC = G * ((M * N) / 2); // (the items' C blocks are contiguous in memory and in the wave's C buffer alike)
 constexpr int VPC = (0 == (PC * 4) % 16 && !XSCALAR) ? 4 : 1;
 constexpr int NPC = (PC + 64 * VPC - 1) / (64 * VPC);
 template<int V> __device__ __forceinline__ void store_pvec(const unsigned* v, XGLOBAL unsigned* dst)
@@ -246,13 +249,13 @@ __device__ __forceinline__ void park_c_pairs(T* Cs, int lane, const unsigned (&r
     for (int q = 0; q < VPC; ++q) { const int e = (64 * j + lane) * VPC + q; if (e < PC) { Cs[2 * e] = widen_lo(rc[j][q]); Cs[2 * e + 1] = widen_hi(rc[j][q]); } }
   }
 }
-__device__ __forceinline__ void store_c_pairs(T* Cs, unsigned* pc, int lane, int tx, int ty, const T (&acc)[TM][TN])
-{
+__device__ __forceinline__ void store_c_pairs(T* Cs, unsigned* pc, int lane, int tx, int ty, const T (&acc)[TM][TN], T* Ci)
+{ // (Ci: this lane's item inside the wave's C buffer Cs)
   wave_lds_sync();
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
-    for (int j = 0; j < TN; ++j) { const int m = tx * TM + i, n = ty * TN + j; if (m < M && n < N) Cs[n * M + m] = acc[i][j]; }
+    for (int j = 0; j < TN; ++j) { const int m = tx * TM + i, n = ty * TN + j; if (m < M && n < N) Ci[n * M + m] = acc[i][j]; }
   }
   wave_lds_sync();
 #pragma unroll
@@ -749,7 +752,7 @@ extern "C" __global__ __launch_bounds__(64 * XWAVES) void xsmm_smm_op(DevAddr ad
     acc_from_c(Cs + grp * CT1, tx, ty, acc, XBETA0);
     multiply(As + grp * AS1, Bs + grp * BS1, tx, ty * TN, acc);
 #if (2 == XLOWP)
-    store_c_pairs(Cs, pc, lane, tx, ty, acc);
+    store_c_pairs(Cs, pc, lane, tx, ty, acc, Cs + grp * CT1);
 #else
     if (XDEFER) { c_to_lds(Cs + grp * CT1, tx, ty, acc); pend = pc; }
     else store_c(Cs, pc, lane, tx, ty, acc, Cs + grp * CT1);
@@ -2491,8 +2494,33 @@ int launch_smm_jit_lowp(const SmmBatch& s, void* stream, const char** name)
   SmmBatch j = s;
   j.typesize = 4; j.lowp = 0; j.sync = SYNC_NONE; // (the kernel itself addresses A and B -- and a bf16 C -- in elements of 16 bits)
   const uintptr_t bits = reinterpret_cast<uintptr_t>(s.a) | reinterpret_cast<uintptr_t>(s.b) | reinterpret_cast<uintptr_t>(s.c);
-  const int variant = ((back_to_back && 0 == (bits & 15)) ? 0 : SMM_JIT_SCALAR) | ((4 == s.lowp ? 2 : s.lowp) << 11); // XLOWP: 1 i16 -> i32, 2 bf16 -> bf16, 3 bf16 -> f32
+  const int lowp_bits = ((4 == s.lowp ? 2 : s.lowp) << 11); // XLOWP: 1 i16 -> i32, 2 bf16 -> bf16, 3 bf16 -> f32
+  const bool wide = (back_to_back && 0 == (bits & 15));
+  const int variant = (wide ? 0 : SMM_JIT_SCALAR) | lowp_bits;
   *name = (1 == s.lowp) ? "smm_i16i32_jit_shape_lowp" : (4 == s.lowp ? "smm_bf16_jit_shape_lowp" : "smm_bf16f32_jit_shape_lowp");
+  if (wide) { // small items laid out back to back: several per wave and pass, as the fp32 / fp64 streaming form takes them (a 16^3 item is
+    // 1.5-2 KB: one per wave leaves most lanes of every access idle and the kernel bound by its instruction count per item)
+    const char* const pack_e = getenv("XSMM_SMMJIT_LOWP_PACK"); // developer knob (re-read on every call: the tests sweep it)
+    const int pack_env = (nullptr != pack_e && 0 != *pack_e) ? atoi(pack_e) : 0;
+    const size_t item = 2 * ((size_t)s.m * s.k + (size_t)s.k * s.n) + (size_t)(4 == s.lowp ? 2 : 4) * s.m * s.n;
+    int pack = 1;
+    if (0 < pack_env) pack = pack_env;
+    else if (item < 6000) while (pack < 8 && 2 * pack * item <= 16384) pack *= 2;
+    while (0 != (pack & (pack - 1))) --pack;
+    while (1 < pack && ((size_t)pack * 4 * ((size_t)s.m * s.k + (size_t)s.k * s.n + (size_t)s.m * s.n) > 28672 || 0 == smm_jit_waves(4, s.m, s.n, s.k, s.flags, pack))) pack /= 2;
+    if (1 < pack && s.batch >= pack) {
+      const int e = smm_jit_launch_variant(j, variant | smm_jit_pack_bits(pack), stream);
+      if (0 == e) {
+        const long long done = (s.batch / pack) * pack;
+        if (done == s.batch) return 0;
+        SmmBatch rest = j; // (strides in elements of the operands: 16 bits, C of the result's width)
+        rest.a = (const char*)s.a + done * s.sa * 2; rest.b = (const char*)s.b + done * s.sb * 2;
+        rest.c = (char*)s.c + done * s.sc * (4 == s.lowp ? 2 : 4); rest.batch = s.batch - done;
+        return smm_jit_launch_variant(rest, variant, stream);
+      }
+      if (0 < e) return e; // (< 0: the packed flavour is not available -- one item per wave)
+    }
+  }
   return smm_jit_launch_variant(j, variant, stream);
 }
 

@@ -239,6 +239,57 @@ def test_low_precision_batches(xs, orc, torch_gpu, kind):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind", [0, 2, 3])
+@pytest.mark.parametrize("shape", [(16, 16, 16), (8, 12, 6), (16, 8, 32)])
+def test_small_low_precision_items_several_per_wave(xs, orc, torch_gpu, kind, shape):
+    """Items laid out back to back (libxsmm_amd_gemm_batch_strided on a low-precision descriptor) of a few hundred bytes to 2 KB: the
+    streaming form takes 2, 4 or 8 of them per wave and pass (XSMM_SMMJIT_LOWP_PACK; by default as many as make up 8-16 KB), the items
+    that are left over one at a time -- bit-equal to the gold loops (samples/xgemm/kernel.c:915-927,1007-1021) whatever the packing.
+    Parity unpinned beyond the gold loops (no reference-held vector)."""
+    import os
+    torch = torch_gpu
+    L = xs.lib()
+    m, n, k = shape
+    batch = 37
+    rng = np.random.default_rng(kind * 100 + m)
+    if kind == 0:
+        a = rng.integers(-300, 300, batch * m * k).astype(np.int16).view(np.uint16); b = rng.integers(-300, 300, batch * k * n).astype(np.int16).view(np.uint16)
+        c = rng.integers(-1000, 1000, batch * m * n).astype(np.int32)
+    else:
+        a = _bf16(rng.uniform(-1, 1, batch * m * k)); b = _bf16(rng.uniform(-1, 1, batch * k * n))
+        c = rng.uniform(-1, 1, batch * m * n).astype(np.float32) if kind == 2 else _bf16(rng.uniform(-1, 1, batch * m * n))
+    if kind == 3 and 0 != m % 16:
+        pytest.skip("a bf16 result needs m % 16 == 0")
+    ref = c.copy()
+    for i in range(batch):
+        assert 0 == orc.gemm_lowp(kind, 0, m, n, k, m, k, m, a[i * m * k:(i + 1) * m * k], b[i * k * n:(i + 1) * k * n], ref[i * m * n:(i + 1) * m * n], 1.0)
+    blob = xs.DescriptorBlob()
+    L.libxsmm_gemm_descriptor_dinit2.restype = C.c_void_p
+    L.libxsmm_gemm_descriptor_dinit2.argtypes = [C.c_void_p] + [C.c_int] * 8 + [C.c_double, C.c_double, C.c_int, C.c_int]
+    ip, op = {0: (xs.I16, xs.I32), 2: (xs.BF16, xs.F32), 3: (xs.BF16, xs.BF16)}[kind]
+    desc = L.libxsmm_gemm_descriptor_dinit2(C.byref(blob), ip, op, m, n, k, m, k, m, 1.0, 1.0, 0, 0)
+    assert desc
+    da, db = (torch.from_numpy(x.view(np.int16)).cuda() for x in (a, b))
+    old = {key: os.environ.get(key) for key in ("LIBXSMM_AMD_JIT_MINBATCH", "XSMM_SMMJIT_LOWP_PACK")}
+    os.environ["LIBXSMM_AMD_JIT_MINBATCH"] = "1"
+    try:
+        for pack in (0, 1, 2, 4, 8):
+            os.environ["XSMM_SMMJIT_LOWP_PACK"] = str(pack)
+            dc = torch.from_numpy(c.view(np.int16) if kind == 3 else c).cuda()
+            assert 0 == L.libxsmm_amd_gemm_batch_strided(C.c_void_p(desc), da.data_ptr(), db.data_ptr(), dc.data_ptr(), m * k, k * n, m * n, batch)
+            torch.cuda.synchronize()
+            assert "_jit_shape_lowp" in xs.last_kernel(), xs.last_kernel()
+            got = dc.cpu().numpy(); got = got.view(np.uint16) if kind == 3 else got
+            assert np.array_equal(got.view(np.uint8), ref.view(np.uint8)), pack
+    finally:
+        for key, val in old.items():
+            if val is None:
+                os.environ.pop(key, None)
+            else:
+                os.environ[key] = val
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("kind", [2, 3])
 @pytest.mark.parametrize("shape", [(48, 48, 48), (64, 40, 56), (64, 64, 64), (16, 64, 8), (40, 33, 16), (45, 40, 26), (48, 50, 12)])
 def test_low_precision_wave_kernel(xs, orc, torch_gpu, kind, shape):

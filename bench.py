@@ -240,6 +240,18 @@ def main():
             variants["libxsmm_gemm_batch_index_arrays"] = {"kernel": xs.last_kernel(), "ms": round(mi, 4), "hbm_gbs": round(float(B) * bytes_item / (mi * 1e-3) / 1e9, 1),
                                                             "frac": round(float(B) * bytes_item / (mi * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
             del ia, ib, ic
+            # (c) BASELINE configs[1] names both policies ("MFMA off vs on"): the same strided call with the matrix cores switched off
+            # (libxsmm_amd_set_mfma(0): the scalar-FMA kernel; bit-identical results)
+            if 0 != args.mfma:
+                old_policy = L.libxsmm_amd_set_mfma(0)
+                try:
+                    step(); torch.cuda.synchronize()
+                    _, tf = time_steps(torch, step, 10, 2, None)
+                    mf = sum(tf) / len(tf)
+                    variants["matrix_cores_off"] = {"kernel": xs.last_kernel(), "ms": round(mf, 4), "hbm_gbs": round(float(B) * bytes_item / (mf * 1e-3) / 1e9, 1),
+                                                    "frac": round(float(B) * bytes_item / (mf * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                finally:
+                    L.libxsmm_amd_set_mfma(old_policy)
             a2 = torch.empty(na, device="cuda", dtype=torch.float32).uniform_(-0.5, 0.5, generator=g)
             b2 = torch.empty(nb, device="cuda", dtype=torch.float32).uniform_(-0.5, 0.5, generator=g)
             c2 = torch.empty(nc, device="cuda", dtype=torch.float32).uniform_(-0.5, 0.5, generator=g)

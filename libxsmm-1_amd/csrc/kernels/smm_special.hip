@@ -401,7 +401,9 @@ int launch_smm_special(const SmmBatch& s, void* stream, const char** name)
     // work-groups per CU of the persistent grid, address space of the operand accesses (1 = global), non-temporal hint
     // Defaults from same-process sweeps (profiles/r1_smm32_variant_sweep.txt): 3 work-groups per CU for both kernels; the
     // MFMA kernel is 4 % faster with generic pointers (FLAT accesses), the scalar-FMA kernel 10 % faster with global ones.
-    const int bpc = env_int("XSMM_SMM32_BPC", 3), nt = env_int("XSMM_SMM32_NT", 1);
+    // (index / pointer batches: four work-groups per CU -- the address lookups one item ahead add latency a fourth work-group covers:
+    // 1 M items through libxsmm_gemm_batch with index arrays 3.15 -> 2.96 ms, profiles/r3_smm32_sweep.txt; strided batches lose with four)
+    const int bpc = env_int("XSMM_SMM32_BPC", (ADDR_STRIDED == s.mode || 0 == s.use_mfma) ? 3 : 4), nt = env_int("XSMM_SMM32_NT", 1);
     const int variant = env_int("XSMM_SMM32_VARIANT", 0 != s.use_mfma ? 0 : 1);
     long long blocks = (s.batch + 3) / 4;
     const int grid_env = env_int("XSMM_SMM32_GRID", 0); // developer knob: the persistent grid in work-groups (0: 256 x bpc)

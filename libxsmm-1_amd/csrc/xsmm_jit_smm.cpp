@@ -2379,6 +2379,14 @@ int launch_smm_jit_mfma(const SmmBatch& s, void* stream, const char** name)
         int per_cu = (int)((160u * 1024u) / wlds);
         const int by_regs = 4 * smm_mfma_wave_wpe(wlds, s.typesize, s.m, s.n, s.k, wide ? chunk : 1, s.lda, s.ldb, s.ldc);
         if (per_cu > by_regs) per_cu = by_regs;
+        { // The memory system is at its best with ~100 KB of operands in flight per CU (the fp32 32^3 kernel: twelve waves of 12 KB); a wave
+          // here has a whole item of 19-55 KB in flight. Waves per CU, % of the HBM peak (tools/bench_dense.py, XSMM_SMMJIT_WAVE_PERCU sweep):
+          // f32 40^3 3: 71.8, 4: 73.8, 8: 67.9, 12: 67.5 | f64 40^3 3: 72.2, 4: 69.3, 8: 69.0 | f32 48^3 3: 72.9, 4: 70.3, 8: 68.3 |
+          // f64 48^3 3: 68.8, 8: 69.1, 12: 69.7 | f32 56^3 3: 69.8, 4: 68.6, 8: 67.6; five to seven waves (uneven over the four SIMDs) lose 3-15 points.
+          const size_t item_bytes = (size_t)s.typesize * ((size_t)s.lda * s.k + (size_t)s.ldb * bcnt + (size_t)s.ldc * s.n);
+          if (wide && item_bytes >= 16384) { const int fit = (int)(100u * 1024u / item_bytes); per_cu = (fit >= 4) ? 4 : 3; if (per_cu > by_regs) per_cu = by_regs; }
+          const char* const e = getenv("XSMM_SMMJIT_WAVE_PERCU"); if (nullptr != e && 0 < atoi(e)) per_cu = atoi(e); // developer knob
+        }
         long long wblocks = 256LL * per_cu;
         if (wblocks > s.batch) wblocks = s.batch;
         void* wargs[] = { &wad, &wbatch, &one };
@@ -2472,6 +2480,14 @@ int launch_smm_jit_lowp(const SmmBatch& s, void* stream, const char** name)
         int per_cu = (int)((160u * 1024u) / wlds);
         const int by_regs = 4 * smm_mfma_wave_wpe(wlds);
         if (per_cu > by_regs) per_cu = by_regs;
+        { // Eight waves per CU (tools/bench_dense.py lowp, XSMM_SMMJIT_WAVE_PERCU sweep, % of the HBM peak at 8 / as many as LDS and
+          // registers allow: bf16 -> f32 48^3 70.5 / 67.4, 64^3 74.4 / 67.7; bf16 -> bf16 32^3 73.5 / 67.6, 48^3 73.5 / 62.5, 64^3 60.3 / 54.7;
+          // three or four -- the optimum of the fp32 / fp64 wave kernels -- lose 5-30 points here: the widening and rounding work per item
+          // wants more waves to overlap with)
+          // (eight per CU also where the estimate above says fewer fit: whatever is not resident at once starts as the others finish)
+          per_cu = 8;
+          const char* const e = getenv("XSMM_SMMJIT_WAVE_PERCU"); if (nullptr != e && 0 < atoi(e)) per_cu = atoi(e); // developer knob
+        }
         long long wblocks = 256LL * per_cu;
         if (wblocks > s.batch) wblocks = s.batch;
         void* wargs[] = { &wad, &wbatch, &one };
